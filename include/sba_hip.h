@@ -1,0 +1,175 @@
+/*
+ * sba_hip.h -- C ABI of libsba_hip.so, the MI355X (gfx950) sparse bundle-adjustment engine.
+ *
+ * The reference (JohnsonLabJanelia/laserCalib) is pure Python: there is no FFI to mirror, so each
+ * entry point below names the reference *Python* interface it stands in for.  The host-side mirror
+ * (lasercalib_amd/pySBA.py) binds these with ctypes; INTEGRATION.md shows the binding a reference
+ * maintainer would add.
+ *
+ * Conventions: extern "C", POD structs, plain pointers + sizes, no exceptions cross the boundary.
+ * Every function returns 0 on success or a negative sba_status; sba_last_error() gives the text.
+ * All array pointers are CALLER-OWNED HOST memory unless a name ends in _dev.  Host arrays at the
+ * boundary are float64 / int64 exactly as the reference's numpy arrays are (pySBA.py:28-59),
+ * whatever dtype the device computes in.
+ *
+ * Camera row layout (11 doubles): [rotvec(3), t(3), f, k1, k2, cx, cy]      (pySBA.py:31-35)
+ * Parameter vector x:  [cams.ravel() (11*C), points.ravel() (3*N)]           (pySBA.py:138)
+ * Residual vector:     interleaved [u0,v0,u1,v1,...] in the caller's observation order (pySBA.py:101)
+ */
+#ifndef SBA_HIP_H
+#define SBA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBA_ABI_VERSION 1
+#define SBA_CAM_PARAMS 11
+
+typedef enum {
+  SBA_OK = 0,
+  SBA_ERR_INVALID = -1,      /* bad argument / shape / index out of range           */
+  SBA_ERR_NO_DEVICE = -2,    /* no usable gfx950 device / HIP runtime error at init */
+  SBA_ERR_HIP = -3,          /* a HIP call failed                                   */
+  SBA_ERR_NONFINITE = -4,    /* residuals are not finite at the initial point (scipy raises
+                                ValueError there: scipy/optimize/_lsq/least_squares.py:844-845) */
+  SBA_ERR_STATE = -5,        /* call out of order (e.g. solve before upload)        */
+  SBA_ERR_UNSUPPORTED = -6
+} sba_status;
+
+typedef enum { SBA_F64 = 0, SBA_F32 = 1 } sba_dtype;
+
+/* Which parameters are free -- selects the reference solver variant being replaced. */
+typedef enum {
+  SBA_MODE_FULL = 0,       /* PySBA.bundleAdjust            (pySBA.py:132-147) cameras + points     */
+  SBA_MODE_POINTS_ONLY = 1,/* PySBA.bundleAdjust_nocam      (pySBA.py:237-250) cameras held fixed   */
+  SBA_MODE_SHARED_INTR = 2 /* PySBA.bundleAdjust_sharedcam  (pySBA.py:297-325) f,k1,k2 shared      */
+} sba_mode;
+
+typedef struct sba_handle sba_handle;
+
+typedef struct {
+  int32_t n_cams;        /* C */
+  int32_t n_points;      /* N (points owned by THIS handle; a multi-GPU job gives each rank a slice) */
+  int64_t n_obs;         /* M */
+  int32_t dtype;         /* sba_dtype: arithmetic type of the per-observation math               */
+  int32_t device;        /* HIP device ordinal                                                    */
+  void*   stream;        /* hipStream_t to run on, or NULL to create a private stream             */
+  int32_t reserved[4];
+} sba_problem_desc;
+
+typedef struct {
+  double  ftol, xtol, gtol;   /* scipy.optimize.least_squares semantics (defaults 1e-8 there;
+                                 the reference passes ftol only, pySBA.py:141)                    */
+  int64_t max_nfev;           /* <=0: 100*n like scipy (scipy/optimize/_lsq/trf.py:437-438)       */
+  int32_t mode;               /* sba_mode                                                         */
+  int32_t verbose;            /* 0 silent, 1 summary, 2 per-iteration table (pySBA.py:141 uses 2) */
+  int32_t max_iter;           /* <=0: unlimited; bench uses it to run exactly K LM iterations     */
+  int32_t always_relinearize; /* bench only: rebuild the normal equations even after a rejection  */
+  double  lambda0;            /* <=0: library default                                             */
+  int32_t reserved[4];
+} sba_lm_opts;
+
+typedef struct {
+  double  cost;            /* 0.5*sum r^2 at the returned parameters            */
+  double  initial_cost;
+  double  optimality;      /* ||J^T r||_inf at the returned parameters          */
+  double  step_norm;       /* last trial step 2-norm                            */
+  double  lambda;          /* final damping                                     */
+  int64_t nfev, njev;      /* residual / Jacobian evaluations, scipy counting   */
+  int32_t iterations;      /* LM trial steps taken (accepted + rejected)        */
+  int32_t accepted;        /* accepted steps                                    */
+  int32_t status;          /* 0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 ftol+xtol (scipy codes) */
+  int32_t reserved;
+  double  seconds_total;   /* wall time inside sba_solve_lm                     */
+  double  seconds_device;  /* HIP-event time of the iteration loop              */
+} sba_lm_report;
+
+/* One row of the per-iteration log (same columns scipy prints with verbose=2,
+ * scipy/optimize/_lsq/common.py:545-563). */
+typedef struct {
+  int32_t iteration; int32_t accepted;
+  int64_t nfev;
+  double  cost, cost_reduction, step_norm, optimality, lambda, rho;
+} sba_lm_iter_log;
+
+/* ---------------------------------------------------------------- library / device */
+int         sba_abi_version(void);
+int         sba_device_count(void);                 /* usable HIP devices, 0 if none */
+const char* sba_last_error(const sba_handle* h);    /* h may be NULL: last create error */
+
+/* ---------------------------------------------------------------- stateless model calls
+ * sba_rotate  <-> PySBA.rotate(points, rot_vecs)      (pySBA.py:61-73)   gathered rows, n each
+ * sba_project <-> PySBA.project(points, cameraArray)  (pySBA.py:76-89)
+ */
+int sba_rotate(int device, int dtype, int64_t n, const double* points /*n*3*/,
+               const double* rot_vecs /*n*3*/, double* out /*n*3*/);
+int sba_project(int device, int dtype, int64_t n, const double* points /*n*3*/,
+                const double* cam_rows /*n*11*/, double* uv_out /*n*2*/);
+
+/* ---------------------------------------------------------------- problem handle
+ * sba_create/sba_upload <-> PySBA.__init__ state (pySBA.py:28-59): observation list + initial x.
+ * weights may be NULL (reference default = ones, pySBA.py:56-58).
+ * Observations need not be sorted; the library groups them by point internally and returns
+ * residuals in the caller's order.
+ */
+int sba_create(const sba_problem_desc* desc, sba_handle** out);
+int sba_upload(sba_handle* h, const double* cams /*C*11*/, const double* points /*N*3*/,
+               const double* uv /*M*2*/, const int64_t* cam_idx /*M*/, const int64_t* pt_idx /*M*/,
+               const double* weights /*M or NULL*/);
+int sba_set_params(sba_handle* h, const double* x /*11C+3N*/);
+int sba_get_params(sba_handle* h, double* cams_out /*C*11*/, double* points_out /*N*3*/);
+int sba_destroy(sba_handle* h);
+
+/* J^T r blocks of the last linearization (after sba_solve_lm / sba_lm_finish: at the returned point).
+ * gc_out: 11*C camera part (THIS handle's observations only), gp_out: 3*N point part.  Either may be NULL. */
+int sba_get_gradient(sba_handle* h, double* gc_out, double* gp_out);
+
+/* sba_residual <-> PySBA.fun(params, ...) (pySBA.py:92-101). x==NULL: use the handle's parameters. */
+int sba_residual(sba_handle* h, const double* x, double* r_out /*2M or NULL*/, double* cost_out);
+
+/* Analytic replacement of scipy's 3-point finite-difference Jacobian (scipy/optimize/_numdiff.py:
+ * 628-705) for PySBA.fun: per-observation blocks, rows (u,v): Jc[M][2][11], Jp[M][2][3], in the
+ * caller's observation order.  Column placement = PySBA.bundle_adjustment_sparsity (pySBA.py:103-118). */
+int sba_residual_jacobian(sba_handle* h, const double* x, double* r_out /*2M or NULL*/,
+                          double* Jc_out /*M*22*/, double* Jp_out /*M*6*/);
+
+/* sba_solve_lm <-> PySBA.bundleAdjust / _nocam / _sharedcam: the whole Levenberg-Marquardt loop
+ * (analytic Jacobian, Schur complement, dense reduced camera solve) runs on the device.
+ * log may be NULL; otherwise up to log_capacity rows are written and *log_rows is set. */
+int sba_solve_lm(sba_handle* h, const sba_lm_opts* opts, double* cams_out /*C*11*/,
+                 double* points_out /*N*3*/, sba_lm_report* report,
+                 sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows);
+
+/* ---------------------------------------------------------------- phase-level LM (multi-GPU)
+ * One rank = one handle holding a slice of the points and all their observations; cameras are
+ * replicated.  The caller all-reduces (SUM) the exchange buffer between sba_lm_form_reduced and
+ * sba_lm_solve_trial, and all-gathers the per-rank scalars between sba_lm_solve_trial and
+ * sba_lm_decide.  Exchange layout (float64, n = 11*C):  [S n*n | rhs n | diagU n | gc n | cost 1].
+ * exchange_dev / scalars_dev are DEVICE pointers owned by the caller (e.g. torch tensors), used on
+ * the handle's stream.
+ */
+#define SBA_LM_NSCALARS 8
+int64_t sba_lm_exchange_size(const sba_handle* h);            /* number of doubles */
+int sba_lm_begin(sba_handle* h, const sba_lm_opts* opts);
+int sba_lm_linearize(sba_handle* h);
+int sba_lm_form_reduced(sba_handle* h, double* exchange_dev);
+int sba_lm_solve_trial(sba_handle* h, const double* exchange_dev, double* scalars_dev /*8*/);
+int sba_lm_decide(sba_handle* h, const double* scalars_all_dev /*n_ranks*8*/, int32_t n_ranks,
+                  int32_t* status_out /* -1 = continue */, int32_t* accepted_out,
+                  sba_lm_iter_log* row_out /* may be NULL */);
+int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report);
+
+/* ---------------------------------------------------------------- measurement hooks (bench.py)
+ * Runs `reps` launches of one named kernel on the current parameters and returns the mean launch
+ * duration in microseconds measured with HIP events on the handle's stream.
+ * names: "residual", "resjac" (materialising), "linearize_points", "linearize_cams", "schur",
+ *        "backsub".  */
+int sba_time_kernel(sba_handle* h, const char* name, int32_t reps, double* mean_us_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBA_HIP_H */

@@ -1,0 +1,775 @@
+// sba_api.hip -- C ABI (include/sba_hip.h) over the HIP kernels.  gfx950 only; no CPU fallback:
+// every entry point fails with SBA_ERR_NO_DEVICE / SBA_ERR_HIP when the GPU is not usable.
+#include "../../include/sba_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "sba_lm_kernels.hpp"
+
+using namespace sba;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct HipError { hipError_t e; const char* what; int line; };
+#define HIPCHK(expr)                                                 \
+  do {                                                               \
+    hipError_t _e = (expr);                                          \
+    if (_e != hipSuccess) throw HipError{_e, #expr, __LINE__};       \
+  } while (0)
+
+template <typename U>
+struct DevBuf {
+  U* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    free();
+    n = count;
+    if (count) HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(U)));
+  }
+  void free() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+  ~DevBuf() { free(); }
+  void upload(const std::vector<U>& h, hipStream_t s) {
+    if (h.size() != n) alloc(h.size());
+    if (n) HIPCHK(hipMemcpyAsync(p, h.data(), n * sizeof(U), hipMemcpyHostToDevice, s));
+  }
+  void zero(hipStream_t s) { if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(U), s)); }
+};
+
+struct EngineBase {
+  virtual ~EngineBase() {}
+  std::string err;
+};
+
+}  // namespace
+
+// ============================================================================================== engine
+template <typename T>
+struct Engine : EngineBase {
+  using T2 = typename Vec2<T>::type;
+  int C = 0, N = 0;
+  int64_t M = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool uploaded = false;
+  bool has_w = false;
+  bool identity_perm = true;
+  std::vector<int64_t> perm;          // pm position -> caller's observation index
+  int nblk = 0, nchunk = 0, ngroups = 0, npairs = 0, ksplit = 1;
+  int n = 0;                          // 11*C
+
+  // static problem data
+  DevBuf<T2> uv_pm, uv_cm;
+  DevBuf<T> w_pm, w_cm;
+  DevBuf<int32_t> ci_pm, pi_pm, pt_start, blk_pt, pi_cm, chunk_cam, chunk_begin, chunk_end, cam_chunk_start;
+  DevBuf<int32_t> pair_ga, pair_gb;
+  // parameters (double-buffered: cur / trial)
+  DevBuf<double> cams[2], pts[2];
+  DevBuf<T> ptsT[2], campre[2];
+  int cur = 0;
+  // linearization + LM work space
+  DevBuf<double> V, gp, D2p, D2c, U, gc, Upart, bpart, E_own, scal_own, delta_c, cost_part, gmax_part, trial_part;
+  DevBuf<T> slabs;
+  DevBuf<T2> r_pm;
+  DevBuf<T> Jc_pm, Jp_pm;
+  DevBuf<LMState> d_state;
+  LMState* h_state = nullptr;         // pinned
+  sba_lm_opts opts{};
+  bool lm_active = false;
+  bool need_linearize = true;
+  double initial_cost = 0;
+  std::vector<sba_lm_iter_log> log;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  ~Engine() override {
+    if (h_state) (void)hipHostFree(h_state);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+
+  void init(const sba_problem_desc& d) {
+    C = d.n_cams; N = d.n_points; M = d.n_obs; device = d.device; n = C * NCP;
+    HIPCHK(hipSetDevice(device));
+    if (d.stream) { stream = reinterpret_cast<hipStream_t>(d.stream); own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(LMState), hipHostMallocDefault));
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    d_state.alloc(1);
+    // kernels whose dynamic LDS can exceed the 64 KB default
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residual<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+  }
+
+  void sync() { HIPCHK(hipStreamSynchronize(stream)); }
+
+  // ------------------------------------------------------------------ upload + host-side layout
+  int upload(const double* cams_h, const double* pts_h, const double* uv_h, const int64_t* ci_h,
+             const int64_t* pi_h, const double* w_h) {
+    HIPCHK(hipSetDevice(device));
+    if (C <= 0 || N < 0 || M < 0) { err = "bad problem size"; return SBA_ERR_INVALID; }
+    if (C > 128) { err = "more than 128 cameras is not supported yet"; return SBA_ERR_UNSUPPORTED; }
+    if (M > (int64_t)0x7fffffff - 1024) { err = "too many observations for int32 device indices"; return SBA_ERR_UNSUPPORTED; }
+    bool sorted = true;
+    for (int64_t i = 0; i < M; ++i) {
+      if (ci_h[i] < 0 || ci_h[i] >= C || pi_h[i] < 0 || pi_h[i] >= N) {
+        err = "camera/point index out of range at observation " + std::to_string(i);
+        return SBA_ERR_INVALID;
+      }
+      if (i && pi_h[i] < pi_h[i - 1]) sorted = false;
+    }
+    // point-major order (stable counting sort by point)
+    std::vector<int32_t> ptstart(N + 1, 0);
+    for (int64_t i = 0; i < M; ++i) ptstart[pi_h[i] + 1]++;
+    int maxdeg = 0;
+    for (int p = 0; p < N; ++p) { maxdeg = std::max(maxdeg, ptstart[p + 1]); ptstart[p + 1] += ptstart[p]; }
+    if (maxdeg > PM_BLOCK) { err = "a point has more than 256 observations"; return SBA_ERR_UNSUPPORTED; }
+    perm.resize(M);
+    identity_perm = sorted;
+    if (sorted) { for (int64_t i = 0; i < M; ++i) perm[i] = i; }
+    else {
+      std::vector<int32_t> fill(ptstart.begin(), ptstart.end() - 1);
+      for (int64_t i = 0; i < M; ++i) perm[fill[pi_h[i]]++] = i;
+    }
+    has_w = (w_h != nullptr);
+    std::vector<T2> uvp(M);
+    std::vector<T> wp(has_w ? M : 0);
+    std::vector<int32_t> cip(M), pip(M);
+    for (int64_t k = 0; k < M; ++k) {
+      const int64_t i = perm[k];
+      uvp[k].x = (T)uv_h[2 * i]; uvp[k].y = (T)uv_h[2 * i + 1];
+      if (has_w) wp[k] = (T)w_h[i];
+      cip[k] = (int32_t)ci_h[i]; pip[k] = (int32_t)pi_h[i];
+    }
+    // point-aligned blocks of <= 256 observations
+    std::vector<int32_t> blk;
+    blk.push_back(0);
+    {
+      int p = 0;
+      while (p < N) {
+        int q = p; int cnt = 0;
+        while (q < N && cnt + (ptstart[q + 1] - ptstart[q]) <= PM_BLOCK && (q - p) < PM_BLOCK) { cnt += ptstart[q + 1] - ptstart[q]; ++q; }
+        if (q == p) ++q;   // cannot happen (maxdeg <= 256) but never loop forever
+        blk.push_back(q);
+        p = q;
+      }
+    }
+    nblk = (int)blk.size() - 1;
+    // camera-major order of the pm list (stable => points ascending inside a camera)
+    std::vector<int32_t> camcount(C + 1, 0);
+    for (int64_t k = 0; k < M; ++k) camcount[cip[k] + 1]++;
+    for (int c = 0; c < C; ++c) camcount[c + 1] += camcount[c];
+    std::vector<T2> uvc(M);
+    std::vector<T> wc(has_w ? M : 0);
+    std::vector<int32_t> pic(M);
+    {
+      std::vector<int32_t> fill(camcount.begin(), camcount.end() - 1);
+      for (int64_t k = 0; k < M; ++k) {
+        const int32_t d = fill[cip[k]]++;
+        uvc[d] = uvp[k]; pic[d] = pip[k];
+        if (has_w) wc[d] = wp[k];
+      }
+    }
+    std::vector<int32_t> ch_cam, ch_beg, ch_end, cam_ch(C + 1, 0);
+    for (int c = 0; c < C; ++c) {
+      cam_ch[c] = (int32_t)ch_cam.size();
+      for (int32_t b = camcount[c]; b < camcount[c + 1]; b += CM_CHUNK) {
+        ch_cam.push_back(c); ch_beg.push_back(b); ch_end.push_back(std::min(camcount[c + 1], b + CM_CHUNK));
+      }
+    }
+    cam_ch[C] = (int32_t)ch_cam.size();
+    nchunk = (int)ch_cam.size();
+    // camera groups / pairs for the Schur kernel
+    ngroups = (C + GROUP_CAMS - 1) / GROUP_CAMS;
+    std::vector<int32_t> pga, pgb;
+    for (int a = 0; a < ngroups; ++a) { pga.push_back(a); pgb.push_back(a); }   // diagonal pairs first
+    for (int a = 0; a < ngroups; ++a)
+      for (int b = a + 1; b < ngroups; ++b) { pga.push_back(a); pgb.push_back(b); }
+    npairs = (int)pga.size();
+    {
+      int target = 256;
+      if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
+      int ks = std::max(1, target / npairs);
+      const int maxks = std::max(1, (N + SCHUR_PTS - 1) / SCHUR_PTS);
+      ksplit = std::min(ks, maxks);
+    }
+
+    uv_pm.upload(uvp, stream); ci_pm.upload(cip, stream); pi_pm.upload(pip, stream);
+    if (has_w) { w_pm.upload(wp, stream); w_cm.upload(wc, stream); }
+    pt_start.upload(ptstart, stream); blk_pt.upload(blk, stream);
+    uv_cm.upload(uvc, stream); pi_cm.upload(pic, stream);
+    chunk_cam.upload(ch_cam, stream); chunk_begin.upload(ch_beg, stream); chunk_end.upload(ch_end, stream);
+    cam_chunk_start.upload(cam_ch, stream);
+    pair_ga.upload(pga, stream); pair_gb.upload(pgb, stream);
+
+    for (int b = 0; b < 2; ++b) {
+      cams[b].alloc((size_t)C * NCP); pts[b].alloc((size_t)N * 3);
+      ptsT[b].alloc((size_t)N * 3); campre[b].alloc((size_t)C * CAMPRE);
+    }
+    V.alloc((size_t)N * 6); gp.alloc((size_t)N * 3); D2p.alloc((size_t)N * 3); D2c.alloc(n);
+    U.alloc((size_t)C * 121); gc.alloc(n); Upart.alloc((size_t)std::max(1, nchunk) * 4 * 256);
+    bpart.alloc((size_t)ngroups * ksplit * GROUP_ROWS);
+    slabs.alloc((size_t)npairs * ksplit * GROUP_TILES * GROUP_TILES * 256);
+    E_own.alloc((size_t)n * n + 3 * n + 1); scal_own.alloc(NSCAL); delta_c.alloc(n);
+    const int nres_blocks = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
+    cost_part.alloc((size_t)std::max(std::max(nblk, nres_blocks), 1)); gmax_part.alloc(std::max(nblk, 1));
+    trial_part.alloc((size_t)4 * std::max(nblk, 1));
+    sync();   // the staging vectors go out of scope now
+    uploaded = true;
+    cur = 0;
+    set_params(cams_h, pts_h);
+    return SBA_OK;
+  }
+
+  void set_params(const double* cams_h, const double* pts_h) {
+    HIPCHK(hipMemcpyAsync(cams[cur].p, cams_h, sizeof(double) * C * NCP, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(pts[cur].p, pts_h, sizeof(double) * (size_t)N * 3, hipMemcpyHostToDevice, stream));
+    std::vector<T> pt((size_t)N * 3);
+    for (size_t i = 0; i < pt.size(); ++i) pt[i] = (T)pts_h[i];
+    HIPCHK(hipMemcpyAsync(ptsT[cur].p, pt.data(), sizeof(T) * pt.size(), hipMemcpyHostToDevice, stream));
+    cam_prep(cur);
+    sync();
+    need_linearize = true;
+  }
+
+  void cam_prep(int b) {
+    hipLaunchKernelGGL(k_cam_prep<T>, dim3((C + 63) / 64), dim3(64), 0, stream, cams[b].p, campre[b].p, C);
+  }
+
+  size_t lds_cams() const { return (size_t)C * CAMPRE * sizeof(T); }
+
+  // ------------------------------------------------------------------ kernel launchers
+  void launch_residual(T2* r_out) {
+    const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
+    if (g == 0) return;
+    hipLaunchKernelGGL(k_residual<T>, dim3(g), dim3(PM_BLOCK), lds_cams(), stream, campre[cur].p, C, ptsT[cur].p,
+                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, r_out, cost_part.p);
+  }
+  void launch_resjac(T2* r_out) {
+    const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
+    if (g == 0) return;
+    const size_t lds = (((size_t)C * CAMPRE + 3) & ~(size_t)3) * sizeof(T) + (size_t)PM_BLOCK * 29 * sizeof(T);
+    hipLaunchKernelGGL(k_resjac<T>, dim3(g), dim3(PM_BLOCK), lds, stream, campre[cur].p, C, ptsT[cur].p, uv_pm.p,
+                       has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, r_out, Jc_pm.p, Jp_pm.p);
+  }
+  void launch_linearize_points() {
+    if (nblk == 0) return;
+    const size_t lds = (size_t)PM_BLOCK * 9 * sizeof(double) + lds_cams();
+    hipLaunchKernelGGL(k_linearize_points<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, campre[cur].p, C, ptsT[cur].p,
+                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pt_start.p, blk_pt.p, V.p, gp.p, D2p.p,
+                       cost_part.p, gmax_part.p);
+  }
+  void launch_linearize_cams() {
+    if (nchunk == 0) return;
+    hipLaunchKernelGGL(k_linearize_cams<T>, dim3(nchunk), dim3(256), 0, stream, campre[cur].p, ptsT[cur].p, uv_cm.p,
+                       has_w ? w_cm.p : nullptr, pi_cm.p, chunk_cam.p, chunk_begin.p, chunk_end.p, Upart.p);
+    hipLaunchKernelGGL(k_reduce_cams, dim3(C), dim3(256), 0, stream, Upart.p, cam_chunk_start.p, U.p, gc.p);
+  }
+  size_t schur_lds(bool diag) const {
+    const size_t panels = (diag ? 1 : 2) * (size_t)SCHUR_K * GROUP_ROWS;
+    return (panels + 2 * GROUP_CAMS * CAMPRE + SCHUR_K) * sizeof(T);
+  }
+  void launch_schur() {
+    // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
+    hipLaunchKernelGGL((k_schur<T, true>), dim3(ksplit, ngroups), dim3(SchurCfg<true>::THREADS), schur_lds(true), stream,
+                       campre[cur].p, C, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pt_start.p, N, V.p, gp.p,
+                       D2p.p, &d_state.p->lam, pair_ga.p, pair_gb.p, 0, ksplit, slabs.p, bpart.p);
+    if (npairs > ngroups)
+      hipLaunchKernelGGL((k_schur<T, false>), dim3(ksplit, npairs - ngroups), dim3(SchurCfg<false>::THREADS),
+                         schur_lds(false), stream, campre[cur].p, C, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr,
+                         ci_pm.p, pt_start.p, N, V.p, gp.p, D2p.p, &d_state.p->lam, pair_ga.p, pair_gb.p, ngroups, ksplit,
+                         slabs.p, bpart.p);
+  }
+  void launch_backsub_trial() {
+    if (nblk == 0) return;
+    const size_t lds = (size_t)PM_BLOCK * 6 * sizeof(double) + (2 * (size_t)C * CAMPRE + (size_t)C * NCP) * sizeof(T);
+    hipLaunchKernelGGL(k_backsub_trial<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, campre[cur].p, campre[1 - cur].p, C,
+                       pts[cur].p, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pt_start.p, blk_pt.p,
+                       V.p, gp.p, D2p.p, delta_c.p, d_state.p, pts[1 - cur].p, ptsT[1 - cur].p, trial_part.p, nblk);
+  }
+
+  // ------------------------------------------------------------------ model evaluation entry points
+  int residual(const double* x, double* r_out, double* cost_out) {
+    if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
+    HIPCHK(hipSetDevice(device));
+    if (x) set_params(x, x + (size_t)C * NCP);
+    if (r_out && r_pm.n != (size_t)M) r_pm.alloc(M);
+    launch_residual(r_out ? r_pm.p : nullptr);
+    const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
+    std::vector<double> part(g);
+    if (g) HIPCHK(hipMemcpyAsync(part.data(), cost_part.p, sizeof(double) * g, hipMemcpyDeviceToHost, stream));
+    std::vector<T2> r(r_out ? M : 0);
+    if (r_out && M) HIPCHK(hipMemcpyAsync(r.data(), r_pm.p, sizeof(T2) * M, hipMemcpyDeviceToHost, stream));
+    sync();
+    HIPCHK(hipGetLastError());
+    double c = 0;
+    for (double v : part) c += v;
+    if (cost_out) *cost_out = c;
+    if (r_out)
+      for (int64_t k = 0; k < M; ++k) { const int64_t i = perm[k]; r_out[2 * i] = (double)r[k].x; r_out[2 * i + 1] = (double)r[k].y; }
+    return SBA_OK;
+  }
+
+  int residual_jacobian(const double* x, double* r_out, double* Jc_out, double* Jp_out) {
+    if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
+    HIPCHK(hipSetDevice(device));
+    if (x) set_params(x, x + (size_t)C * NCP);
+    if (r_pm.n != (size_t)M) r_pm.alloc(M);
+    if (Jc_pm.n != (size_t)M * 22) { Jc_pm.alloc((size_t)M * 22); Jp_pm.alloc((size_t)M * 6); }
+    launch_resjac(r_pm.p);
+    std::vector<T2> r(M);
+    std::vector<T> jc((size_t)M * 22), jp((size_t)M * 6);
+    if (M) {
+      HIPCHK(hipMemcpyAsync(r.data(), r_pm.p, sizeof(T2) * M, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(jc.data(), Jc_pm.p, sizeof(T) * jc.size(), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(jp.data(), Jp_pm.p, sizeof(T) * jp.size(), hipMemcpyDeviceToHost, stream));
+    }
+    sync();
+    HIPCHK(hipGetLastError());
+    for (int64_t k = 0; k < M; ++k) {
+      const int64_t i = perm[k];
+      if (r_out) { r_out[2 * i] = (double)r[k].x; r_out[2 * i + 1] = (double)r[k].y; }
+      if (Jc_out) for (int e = 0; e < 22; ++e) Jc_out[(size_t)i * 22 + e] = (double)jc[(size_t)k * 22 + e];
+      if (Jp_out) for (int e = 0; e < 6; ++e) Jp_out[(size_t)i * 6 + e] = (double)jp[(size_t)k * 6 + e];
+    }
+    return SBA_OK;
+  }
+
+  // ------------------------------------------------------------------ LM phases
+  int64_t exchange_size() const { return (int64_t)n * n + 3 * (int64_t)n + 1; }
+
+  int lm_begin(const sba_lm_opts* o) {
+    if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
+    HIPCHK(hipSetDevice(device));
+    opts = *o;
+    if (opts.mode != SBA_MODE_FULL && opts.mode != SBA_MODE_POINTS_ONLY) { err = "unsupported mode"; return SBA_ERR_UNSUPPORTED; }
+    // initial cost; scipy raises ValueError when it is not finite (least_squares.py:844-845)
+    double c0 = 0;
+    int rc = residual(nullptr, nullptr, &c0);
+    if (rc) return rc;
+    initial_cost = c0;
+    LMState s{};
+    s.lam = opts.lambda0 > 0 ? opts.lambda0 : 1e-4;
+    s.nu = 2.0;
+    s.cost = c0;
+    s.ftol = opts.ftol; s.xtol = opts.xtol; s.gtol = opts.gtol;
+    s.lam_min = 1e-12; s.lam_max = 1e12;
+    s.nfev = 1; s.njev = 1;
+    const long long nparam = (opts.mode == SBA_MODE_FULL ? (long long)n : 0) + 3LL * N;
+    s.max_nfev = opts.max_nfev > 0 ? opts.max_nfev : 100 * nparam;
+    s.status = -1; s.fresh = 1;
+    s.free_cams = (opts.mode == SBA_MODE_FULL) ? 1 : 0;
+    *h_state = s;
+    HIPCHK(hipMemcpyAsync(d_state.p, h_state, sizeof(LMState), hipMemcpyHostToDevice, stream));
+    D2p.zero(stream); D2c.zero(stream); delta_c.zero(stream);
+    // trial buffers start as copies so that points-only mode has valid trial cameras
+    HIPCHK(hipMemcpyAsync(cams[1 - cur].p, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(campre[1 - cur].p, campre[cur].p, sizeof(T) * C * CAMPRE, hipMemcpyDeviceToDevice, stream));
+    sync();
+    log.clear();
+    lm_active = true;
+    need_linearize = true;
+    if (!std::isfinite(c0)) { err = "Residuals are not finite in the initial point."; return SBA_ERR_NONFINITE; }
+    return SBA_OK;
+  }
+
+  int lm_linearize() {
+    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    launch_linearize_points();
+    if (h_state->free_cams) launch_linearize_cams();
+    need_linearize = false;
+    return SBA_OK;
+  }
+
+  int lm_form_reduced(double* E) {
+    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    if (h_state->free_cams) {
+      launch_schur();
+      hipLaunchKernelGGL(k_schur_reduce<T>, dim3(GROUP_TILES * GROUP_TILES, npairs), dim3(256), 0, stream, slabs.p, ksplit,
+                         pair_ga.p, pair_gb.p, U.p, C, E);
+    }
+    hipLaunchKernelGGL(k_pack_exchange, dim3(1), dim3(256), 0, stream, U.p, gc.p, bpart.p, ksplit, cost_part.p, nblk, C,
+                       (int)h_state->free_cams, E);
+    return SBA_OK;
+  }
+
+  int lm_solve_trial(double* E, double* scal) {
+    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    if (h_state->free_cams) {
+      if (n <= CHOL_LDS_MAX_N) {
+        const size_t lds = (size_t)n * (n + 1) / 2 * sizeof(double);
+        hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, E, C, d_state.p, D2c.p,
+                           cams[cur].p, delta_c.p, cams[1 - cur].p, campre[1 - cur].p);
+      } else {
+        hipLaunchKernelGGL((k_cholesky_solve<false, T>), dim3(1), dim3(CHOL_THREADS), 0, stream, E, C, d_state.p, D2c.p,
+                           cams[cur].p, delta_c.p, cams[1 - cur].p, campre[1 - cur].p);
+      }
+    } else {
+      hipLaunchKernelGGL(k_nocam_step, dim3(1), dim3(64), 0, stream, d_state.p, E, n);
+    }
+    launch_backsub_trial();
+    hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, nblk, d_state.p, scal);
+    return SBA_OK;
+  }
+
+  int lm_decide(const double* scal_all, int n_ranks, int32_t* status_out, int32_t* accepted_out, sba_lm_iter_log* row) {
+    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, stream, d_state.p, scal_all, n_ranks);
+    HIPCHK(hipMemcpyAsync(h_state, d_state.p, sizeof(LMState), hipMemcpyDeviceToHost, stream));
+    sync();
+    HIPCHK(hipGetLastError());
+    const LMState& s = *h_state;
+    if (s.accepted) { cur = 1 - cur; need_linearize = true; }
+    if (opts.always_relinearize) need_linearize = true;
+    sba_lm_iter_log r{};
+    r.iteration = s.iter; r.accepted = s.accepted; r.nfev = s.nfev;
+    r.cost = s.cost;
+    r.cost_reduction = s.actual; r.step_norm = s.step_norm; r.optimality = s.gnorm; r.lambda = s.lam; r.rho = s.rho;
+    log.push_back(r);
+    if (row) *row = r;
+    int status = s.status;
+    if (status < 0 && opts.max_iter > 0 && s.iter >= opts.max_iter) status = 0;
+    if (status_out) *status_out = status;
+    if (accepted_out) *accepted_out = s.accepted;
+    return SBA_OK;
+  }
+
+  int lm_finish(double* cams_out, double* pts_out, sba_lm_report* rep) {
+    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    // gradient norm at the returned point (scipy reports optimality there, trf.py:546-551)
+    launch_linearize_points();
+    double gmax = 0;
+    std::vector<double> gm(nblk), cp(nblk);
+    if (nblk) {
+      HIPCHK(hipMemcpyAsync(gm.data(), gmax_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(cp.data(), cost_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
+    }
+    std::vector<double> gch(n, 0.0);
+    if (h_state->free_cams) {
+      launch_linearize_cams();
+      HIPCHK(hipMemcpyAsync(gch.data(), gc.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    } else {
+      gc.zero(stream);
+    }
+    if (cams_out) HIPCHK(hipMemcpyAsync(cams_out, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    if (pts_out) HIPCHK(hipMemcpyAsync(pts_out, pts[cur].p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost, stream));
+    sync();
+    HIPCHK(hipGetLastError());
+    double cost = 0;
+    for (int i = 0; i < nblk; ++i) { gmax = std::max(gmax, gm[i]); cost += cp[i]; }
+    for (double v : gch) gmax = std::max(gmax, std::fabs(v));
+    if (rep) {
+      const LMState& s = *h_state;
+      rep->cost = cost; rep->initial_cost = initial_cost; rep->optimality = gmax; rep->step_norm = s.step_norm;
+      rep->lambda = s.lam; rep->nfev = s.nfev; rep->njev = s.njev; rep->iterations = s.iter; rep->accepted = s.n_accepted;
+      rep->status = s.status < 0 ? 0 : s.status;
+    }
+    lm_active = false;
+    need_linearize = true;
+    return SBA_OK;
+  }
+
+  int solve(const sba_lm_opts* o, double* cams_out, double* pts_out, sba_lm_report* rep, sba_lm_iter_log* lg, int cap,
+            int32_t* rows) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = lm_begin(o);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev0, stream));
+    int32_t status = -1, acc = 0;
+    while (status < 0) {
+      if (need_linearize) lm_linearize();
+      lm_form_reduced(E_own.p);
+      lm_solve_trial(E_own.p, scal_own.p);
+      rc = lm_decide(scal_own.p, 1, &status, &acc, nullptr);
+      if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(ev1, stream));
+    HIPCHK(hipEventSynchronize(ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    h_state->status = status;
+    rc = lm_finish(cams_out, pts_out, rep);
+    if (rc) return rc;
+    if (rep) {
+      rep->status = status;
+      rep->seconds_device = ms * 1e-3;
+      rep->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    const int nrow = std::min<int>(cap, (int)log.size());
+    if (lg) for (int i = 0; i < nrow; ++i) lg[i] = log[i];
+    if (rows) *rows = (int32_t)log.size();
+    return SBA_OK;
+  }
+
+  // ------------------------------------------------------------------ measurement hook
+  int time_kernel(const char* name, int reps, double* mean_us) {
+    if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
+    HIPCHK(hipSetDevice(device));
+    const std::string k(name);
+    if (reps < 1) reps = 1;
+    // make sure everything the kernel reads exists
+    if (k == "resjac" && Jc_pm.n != (size_t)M * 22) { r_pm.alloc(M); Jc_pm.alloc((size_t)M * 22); Jp_pm.alloc((size_t)M * 6); }
+    if (k == "schur" || k == "backsub") {
+      sba_lm_opts o{}; o.ftol = o.xtol = o.gtol = 0; o.mode = SBA_MODE_FULL;
+      if (!lm_active) { int rc = lm_begin(&o); if (rc) return rc; }
+      lm_linearize(); lm_form_reduced(E_own.p); lm_solve_trial(E_own.p, scal_own.p);
+    }
+    auto once = [&]() {
+      if (k == "residual") launch_residual(nullptr);
+      else if (k == "resjac") launch_resjac(r_pm.p);
+      else if (k == "linearize_points") launch_linearize_points();
+      else if (k == "linearize_cams") launch_linearize_cams();
+      else if (k == "schur") launch_schur();
+      else if (k == "backsub") launch_backsub_trial();
+      else return false;
+      return true;
+    };
+    if (!once()) { err = "unknown kernel name"; return SBA_ERR_INVALID; }
+    sync();
+    HIPCHK(hipEventRecord(ev0, stream));
+    for (int i = 0; i < reps; ++i) once();
+    HIPCHK(hipEventRecord(ev1, stream));
+    HIPCHK(hipEventSynchronize(ev1));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    *mean_us = (double)ms * 1e3 / reps;
+    return SBA_OK;
+  }
+};
+
+// ============================================================================================== C ABI
+struct sba_handle {
+  int dtype;
+  std::unique_ptr<EngineBase> eng;
+  std::string err;
+};
+
+namespace {
+
+template <typename F>
+int guarded(sba_handle* h, F&& f) {
+  try {
+    int rc = f();
+    if (rc && h) h->err = h->eng ? h->eng->err : h->err;
+    return rc;
+  } catch (const HipError& e) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at sba_api.hip:%d: %s", (int)e.e, hipGetErrorString(e.e), e.line, e.what);
+    if (h) h->err = buf; else g_last_error = buf;
+    return SBA_ERR_HIP;
+  } catch (const std::exception& e) {
+    if (h) h->err = e.what(); else g_last_error = e.what();
+    return SBA_ERR_INVALID;
+  }
+}
+
+#define DISPATCH(h, ...)                                                                    \
+  ((h)->dtype == SBA_F32 ? static_cast<Engine<float>*>((h)->eng.get())->__VA_ARGS__         \
+                         : static_cast<Engine<double>*>((h)->eng.get())->__VA_ARGS__)
+
+int check_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) { g_last_error = "no HIP device is visible (libsba_hip needs an MI355X / gfx950 GPU)"; return SBA_ERR_NO_DEVICE; }
+  if (device < 0 || device >= n) { g_last_error = "device ordinal out of range"; return SBA_ERR_NO_DEVICE; }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) { g_last_error = "hipGetDeviceProperties failed"; return SBA_ERR_NO_DEVICE; }
+  if (std::string(p.gcnArchName).rfind("gfx950", 0) != 0) {
+    g_last_error = std::string("device is ") + p.gcnArchName + ", libsba_hip is built for gfx950 only";
+    return SBA_ERR_NO_DEVICE;
+  }
+  return SBA_OK;
+}
+
+template <typename T>
+int rows_call(bool project, int device, int64_t nrows, const double* pts, const double* other, double* out) {
+  HIPCHK(hipSetDevice(device));
+  if (nrows == 0) return SBA_OK;
+  const int64_t ow = project ? 11 : 3, rw = project ? 2 : 3;
+  DevBuf<double> d_pts, d_o, d_out;
+  d_pts.alloc(nrows * 3); d_o.alloc(nrows * ow); d_out.alloc(nrows * rw);
+  HIPCHK(hipMemcpy(d_pts.p, pts, sizeof(double) * nrows * 3, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_o.p, other, sizeof(double) * nrows * ow, hipMemcpyHostToDevice));
+  const int g = (int)((nrows + 255) / 256);
+  if (project) hipLaunchKernelGGL(k_project_rows<T>, dim3(g), dim3(256), 0, 0, d_pts.p, d_o.p, d_out.p, nrows);
+  else hipLaunchKernelGGL(k_rotate_rows<T>, dim3(g), dim3(256), 0, 0, d_pts.p, d_o.p, d_out.p, nrows);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d_out.p, sizeof(double) * nrows * rw, hipMemcpyDeviceToHost));
+  return SBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sba_abi_version(void) { return SBA_ABI_VERSION; }
+
+int sba_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* sba_last_error(const sba_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int sba_rotate(int device, int dtype, int64_t n, const double* points, const double* rot_vecs, double* out) {
+  if (n < 0 || (n > 0 && (!points || !rot_vecs || !out))) { g_last_error = "null argument"; return SBA_ERR_INVALID; }
+  int rc = check_device(device);
+  if (rc) return rc;
+  return guarded(nullptr, [&] {
+    return dtype == SBA_F32 ? rows_call<float>(false, device, n, points, rot_vecs, out)
+                            : rows_call<double>(false, device, n, points, rot_vecs, out);
+  });
+}
+
+int sba_project(int device, int dtype, int64_t n, const double* points, const double* cam_rows, double* uv_out) {
+  if (n < 0 || (n > 0 && (!points || !cam_rows || !uv_out))) { g_last_error = "null argument"; return SBA_ERR_INVALID; }
+  int rc = check_device(device);
+  if (rc) return rc;
+  return guarded(nullptr, [&] {
+    return dtype == SBA_F32 ? rows_call<float>(true, device, n, points, cam_rows, uv_out)
+                            : rows_call<double>(true, device, n, points, cam_rows, uv_out);
+  });
+}
+
+int sba_create(const sba_problem_desc* desc, sba_handle** out) {
+  if (!desc || !out) { g_last_error = "null argument"; return SBA_ERR_INVALID; }
+  *out = nullptr;
+  if (desc->dtype != SBA_F64 && desc->dtype != SBA_F32) { g_last_error = "dtype must be SBA_F64 or SBA_F32"; return SBA_ERR_INVALID; }
+  int rc = check_device(desc->device);
+  if (rc) return rc;
+  auto h = std::make_unique<sba_handle>();
+  h->dtype = desc->dtype;
+  rc = guarded(nullptr, [&] {
+    if (desc->dtype == SBA_F32) { auto e = std::make_unique<Engine<float>>(); e->init(*desc); h->eng = std::move(e); }
+    else { auto e = std::make_unique<Engine<double>>(); e->init(*desc); h->eng = std::move(e); }
+    return (int)SBA_OK;
+  });
+  if (rc) return rc;
+  *out = h.release();
+  return SBA_OK;
+}
+
+int sba_destroy(sba_handle* h) {
+  if (!h) return SBA_OK;
+  delete h;
+  return SBA_OK;
+}
+
+int sba_upload(sba_handle* h, const double* cams, const double* points, const double* uv, const int64_t* cam_idx,
+               const int64_t* pt_idx, const double* weights) {
+  if (!h) return SBA_ERR_INVALID;
+  if (!cams || !points || ((!uv || !cam_idx || !pt_idx))) { h->err = "null argument"; return SBA_ERR_INVALID; }
+  return guarded(h, [&] { return DISPATCH(h, upload(cams, points, uv, cam_idx, pt_idx, weights)); });
+}
+
+int sba_set_params(sba_handle* h, const double* x) {
+  if (!h || !x) return SBA_ERR_INVALID;
+  return guarded(h, [&] {
+    if (h->dtype == SBA_F32) { auto* e = static_cast<Engine<float>*>(h->eng.get()); if (!e->uploaded) { e->err = "not uploaded"; return (int)SBA_ERR_STATE; } e->set_params(x, x + (size_t)e->C * NCP); }
+    else { auto* e = static_cast<Engine<double>*>(h->eng.get()); if (!e->uploaded) { e->err = "not uploaded"; return (int)SBA_ERR_STATE; } e->set_params(x, x + (size_t)e->C * NCP); }
+    return (int)SBA_OK;
+  });
+}
+
+int sba_get_params(sba_handle* h, double* cams_out, double* points_out) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] {
+    auto get = [&](auto* e) {
+      if (!e->uploaded) { e->err = "not uploaded"; return (int)SBA_ERR_STATE; }
+      if (cams_out) HIPCHK(hipMemcpyAsync(cams_out, e->cams[e->cur].p, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
+      if (points_out) HIPCHK(hipMemcpyAsync(points_out, e->pts[e->cur].p, sizeof(double) * (size_t)e->N * 3, hipMemcpyDeviceToHost, e->stream));
+      e->sync();
+      return (int)SBA_OK;
+    };
+    return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
+  });
+}
+
+int sba_get_gradient(sba_handle* h, double* gc_out, double* gp_out) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] {
+    auto get = [&](auto* e) {
+      if (!e->uploaded) { e->err = "not uploaded"; return (int)SBA_ERR_STATE; }
+      if (gc_out) HIPCHK(hipMemcpyAsync(gc_out, e->gc.p, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
+      if (gp_out) HIPCHK(hipMemcpyAsync(gp_out, e->gp.p, sizeof(double) * (size_t)e->N * 3, hipMemcpyDeviceToHost, e->stream));
+      e->sync();
+      return (int)SBA_OK;
+    };
+    return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
+  });
+}
+
+int sba_residual(sba_handle* h, const double* x, double* r_out, double* cost_out) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, residual(x, r_out, cost_out)); });
+}
+
+int sba_residual_jacobian(sba_handle* h, const double* x, double* r_out, double* Jc_out, double* Jp_out) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, residual_jacobian(x, r_out, Jc_out, Jp_out)); });
+}
+
+int sba_solve_lm(sba_handle* h, const sba_lm_opts* opts, double* cams_out, double* points_out, sba_lm_report* report,
+                 sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows) {
+  if (!h || !opts) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, solve(opts, cams_out, points_out, report, log, log_capacity, log_rows)); });
+}
+
+int64_t sba_lm_exchange_size(const sba_handle* h) {
+  if (!h) return 0;
+  return h->dtype == SBA_F32 ? static_cast<Engine<float>*>(h->eng.get())->exchange_size()
+                             : static_cast<Engine<double>*>(h->eng.get())->exchange_size();
+}
+
+int sba_lm_begin(sba_handle* h, const sba_lm_opts* opts) {
+  if (!h || !opts) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, lm_begin(opts)); });
+}
+int sba_lm_linearize(sba_handle* h) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, lm_linearize()); });
+}
+int sba_lm_form_reduced(sba_handle* h, double* exchange_dev) {
+  if (!h || !exchange_dev) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, lm_form_reduced(exchange_dev)); });
+}
+int sba_lm_solve_trial(sba_handle* h, const double* exchange_dev, double* scalars_dev) {
+  if (!h || !exchange_dev || !scalars_dev) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, lm_solve_trial(const_cast<double*>(exchange_dev), scalars_dev)); });
+}
+int sba_lm_decide(sba_handle* h, const double* scalars_all_dev, int32_t n_ranks, int32_t* status_out,
+                  int32_t* accepted_out, sba_lm_iter_log* row_out) {
+  if (!h || !scalars_all_dev || n_ranks < 1) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, lm_decide(scalars_all_dev, n_ranks, status_out, accepted_out, row_out)); });
+}
+int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, lm_finish(cams_out, points_out, report)); });
+}
+
+int sba_time_kernel(sba_handle* h, const char* name, int32_t reps, double* mean_us_out) {
+  if (!h || !name || !mean_us_out) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, time_kernel(name, reps, mean_us_out)); });
+}
+
+}  // extern "C"

@@ -1,0 +1,522 @@
+// sba_kernels.hpp -- HIP kernels of the bundle-adjustment hot path (gfx950 / CDNA4 only).
+//
+// Data layout in HBM (all static per problem, built once by sba_upload):
+//   point-major (pm) observation arrays   uv_pm[M] (T2), w_pm[M] (T), ci_pm[M] (i32), pi_pm[M] (i32)
+//       observations of one point are contiguous (the order scripts/get_points3d.py:78-86 emits);
+//       pt_start[N+1] is the CSR offset, blk_pt[B+1] cuts the list into POINT-ALIGNED blocks of
+//       <= 256 observations so no point straddles a workgroup (no global atomics, deterministic sums).
+//   camera-major (cm) copies               uv_cm[M], w_cm[M], pi_cm[M]; chunk table {cam, begin, end}
+//       every chunk holds observations of ONE camera, so a wave's J^T J is a single 16x16 MFMA
+//       accumulation with no cross-lane traffic.
+//   parameters: cams (C x 11, f64 master), pts (N x 3, f64 master) + T-typed shadow of the points,
+//       CamPre table (C x 25, T) rebuilt by k_cam_prep whenever the cameras change.
+//
+// wavefront = 64 everywhere; workgroup sizes are multiples of 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sba_model.hpp"
+
+namespace sba {
+
+constexpr int PM_BLOCK = 256;      // threads (= max observations) of a point-major workgroup
+constexpr int CM_WAVE_OBS = 64;    // observations a wave turns into one 128-row MFMA tile
+constexpr int CM_CHUNK = 1024;     // observations per camera-major workgroup (256 threads x 4)
+constexpr int SCHUR_THREADS = 512; // 8 waves
+constexpr int SCHUR_PTS = 16;      // points per panel chunk  (K = 48 panel rows)
+constexpr int SCHUR_K = 3 * SCHUR_PTS;
+constexpr int GROUP_CAMS = 16;     // cameras per Schur camera group: 16*11 = 176 = 11 MFMA tiles exactly
+constexpr int GROUP_ROWS = GROUP_CAMS * NCP;   // 176
+constexpr int GROUP_TILES = GROUP_ROWS / 16;   // 11
+constexpr int NSCAL = 8;
+
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
+// ------------------------------------------------------------------ small helpers
+__device__ inline double fmax_pos(double d) { return d > 0.0 ? d : 1.0; }   // scale 0 -> 1 (scipy common.py:598-610)
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum of a double; result valid in thread 0.  scratch: >= blockDim/64 doubles of LDS.
+__device__ inline double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) s += scratch[i];
+  return s;
+}
+__device__ inline double block_max(double v, double* scratch) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) s = fmax(s, scratch[i]);
+  return s;
+}
+
+// 3x3 SPD:  V' = V + lam*D  ->  Linv (lower, 6 values: l00,l10,l11,l20,l21,l22 of L^-1).  ok=false if not PD.
+template <typename T>
+__device__ inline bool chol3_inv(const T v[6] /*v00,v01,v02,v11,v12,v22*/, T li[6]) {
+  const T a00 = v[0], a10 = v[1], a20 = v[2], a11 = v[3], a21 = v[4], a22 = v[5];
+  if (!(a00 > (T)0)) return false;
+  const T l00 = sqrt(a00);
+  const T i00 = (T)1 / l00;
+  const T l10 = a10 * i00, l20 = a20 * i00;
+  const T d11 = a11 - l10 * l10;
+  if (!(d11 > (T)0)) return false;
+  const T l11 = sqrt(d11);
+  const T i11 = (T)1 / l11;
+  const T l21 = (a21 - l20 * l10) * i11;
+  const T d22 = a22 - l20 * l20 - l21 * l21;
+  if (!(d22 > (T)0)) return false;
+  const T l22 = sqrt(d22);
+  const T i22 = (T)1 / l22;
+  // inverse of lower-triangular L
+  li[0] = i00;
+  li[1] = -l10 * i00 * i11;
+  li[2] = i11;
+  li[3] = (-l20 * i00 - l21 * li[1]) * i22;   // -(l20*li00 + l21*li10)/l22
+  li[4] = -l21 * i11 * i22;
+  li[5] = i22;
+  return true;
+}
+
+// ------------------------------------------------------------------ K0: CamPre table
+template <typename T>
+__global__ void k_cam_prep(const double* __restrict__ cams, T* __restrict__ campre, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) campre_build<T>(cams + (size_t)c * NCP, campre + (size_t)c * CAMPRE);
+}
+
+template <typename T>
+__device__ inline void stage_campre(const T* __restrict__ campre, T* __restrict__ s_cam, int C) {
+  for (int i = threadIdx.x; i < C * CAMPRE; i += blockDim.x) s_cam[i] = campre[i];
+}
+
+// ------------------------------------------------------------------ stateless rotate / project (gathered rows)
+template <typename T>
+__global__ void k_rotate_rows(const double* __restrict__ pts, const double* __restrict__ rv,
+                              double* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T P0, P1, P2;
+  rotate_raw<T>((T)rv[3 * i], (T)rv[3 * i + 1], (T)rv[3 * i + 2], (T)pts[3 * i], (T)pts[3 * i + 1],
+                (T)pts[3 * i + 2], P0, P1, P2);
+  out[3 * i] = P0; out[3 * i + 1] = P1; out[3 * i + 2] = P2;
+}
+
+template <typename T>
+__global__ void k_project_rows(const double* __restrict__ pts, const double* __restrict__ cam,
+                               double* __restrict__ uv, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* c = cam + 11 * i;
+  T P0, P1, P2;
+  rotate_raw<T>((T)c[0], (T)c[1], (T)c[2], (T)pts[3 * i], (T)pts[3 * i + 1], (T)pts[3 * i + 2], P0, P1, P2);
+  const T p0 = P0 + (T)c[3], p1 = P1 + (T)c[4], p2 = P2 + (T)c[5];
+  const T x = p0 / p2, y = p1 / p2;
+  const T nn = x * x + y * y;
+  const T r = (T)1 + (T)c[7] * nn + (T)c[8] * nn * nn;
+  uv[2 * i] = x * (r * (T)c[6]) + (T)c[9];
+  uv[2 * i + 1] = y * (r * (T)c[6]) + (T)c[10];
+}
+
+// ------------------------------------------------------------------ K1: residual (+ cost partial)
+// One thread per observation in pm order; grid-strided is unnecessary: grid = ceil(M/256).
+// r_out (if non-null) is written in pm order as T2 -> fully coalesced.
+template <typename T>
+__global__ __launch_bounds__(PM_BLOCK) void k_residual(
+    const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
+    const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, int64_t M,
+    typename Vec2<T>::type* __restrict__ r_out, double* __restrict__ cost_part) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* s_cam = reinterpret_cast<T*>(smem);
+  __shared__ double s_red[PM_BLOCK / 64];
+  stage_campre(campre, s_cam, C);
+  __syncthreads();
+  const int64_t o = (int64_t)blockIdx.x * PM_BLOCK + threadIdx.x;
+  double sq = 0;
+  if (o < M) {
+    const int c = ci[o];
+    const int p = pi[o];
+    const auto m = uv[o];
+    const T ww = w ? w[o] : (T)1;
+    T u, v;
+    obs_project<T>(s_cam + c * CAMPRE, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2], u, v);
+    const T r0 = ww * (u - m.x), r1 = ww * (v - m.y);
+    if (r_out) { typename Vec2<T>::type rr; rr.x = r0; rr.y = r1; r_out[o] = rr; }
+    sq = (double)r0 * (double)r0 + (double)r1 * (double)r1;
+  }
+  const double s = block_sum(sq, s_red);
+  if (threadIdx.x == 0) cost_part[blockIdx.x] = 0.5 * s;
+}
+
+// ------------------------------------------------------------------ K2: materialising residual + Jacobian
+// Writes r (T2), Jc (22 T) and Jp (6 T) per observation in pm order.  The 28 Jacobian values of a
+// lane are staged through LDS so that global stores are contiguous across the wave.
+template <typename T>
+__global__ __launch_bounds__(PM_BLOCK) void k_resjac(
+    const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
+    const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, int64_t M,
+    typename Vec2<T>::type* __restrict__ r_out, T* __restrict__ Jc_out, T* __restrict__ Jp_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* s_cam = reinterpret_cast<T*>(smem);
+  T* s_j = s_cam + ((C * CAMPRE + 3) & ~3);          // [256][29] (odd stride: conflict-free lane writes)
+  stage_campre(campre, s_cam, C);
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * PM_BLOCK;
+  const int64_t o = base + threadIdx.x;
+  const int nvalid = (int)min((int64_t)PM_BLOCK, M - base);
+  if (o < M) {
+    const int c = ci[o];
+    const int p = pi[o];
+    const auto m = uv[o];
+    const T ww = w ? w[o] : (T)1;
+    T r[2], Jc[2][NCP], Jp[2][3];
+    obs_resjac<T>(s_cam + c * CAMPRE, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2],
+                  m.x, m.y, ww, r, Jc, Jp);
+    if (r_out) { typename Vec2<T>::type rr; rr.x = r[0]; rr.y = r[1]; r_out[o] = rr; }
+    T* dst = s_j + threadIdx.x * 29;
+#pragma unroll
+    for (int k = 0; k < NCP; ++k) { dst[k] = Jc[0][k]; dst[NCP + k] = Jc[1][k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dst[22 + k] = Jp[0][k]; dst[25 + k] = Jp[1][k]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nvalid * 22; i += PM_BLOCK) {
+    const int l = i / 22, k = i - l * 22;
+    Jc_out[base * 22 + i] = s_j[l * 29 + k];
+  }
+  for (int i = threadIdx.x; i < nvalid * 6; i += PM_BLOCK) {
+    const int l = i / 6, k = i - l * 6;
+    Jp_out[base * 6 + i] = s_j[l * 29 + 22 + k];
+  }
+}
+
+// ------------------------------------------------------------------ K3a: linearize, point side
+// Workgroup b owns points [blk_pt[b], blk_pt[b+1]) and all their observations (<= 256, one per thread).
+// Outputs per point: V (6: v00 v01 v02 v11 v12 v22), gp (3), D2p <- max(D2p, diag V); per block:
+// cost partial and max|gp| partial.
+template <typename T>
+__global__ __launch_bounds__(PM_BLOCK) void k_linearize_points(
+    const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
+    const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pt_start,
+    const int32_t* __restrict__ blk_pt, double* __restrict__ V, double* __restrict__ gp,
+    double* __restrict__ D2p, double* __restrict__ cost_part, double* __restrict__ gmax_part) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_red = reinterpret_cast<double*>(smem);              // [256][9]
+  T* s_cam = reinterpret_cast<T*>(s_red + PM_BLOCK * 9);
+  __shared__ double s_scr[PM_BLOCK / 64];
+  __shared__ int s_pt_lo;
+  stage_campre(campre, s_cam, C);
+  const int p_lo = blk_pt[blockIdx.x], p_hi = blk_pt[blockIdx.x + 1];
+  const int o_lo = pt_start[p_lo], o_hi = pt_start[p_hi];
+  const int nobs = o_hi - o_lo;
+  __syncthreads();
+  double sq = 0;
+  if ((int)threadIdx.x < nobs) {
+    const int o = o_lo + threadIdx.x;
+    // binary search of the owning point inside [p_lo, p_hi)
+    int lo = p_lo, hi = p_hi;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pt_start[mid] <= o) lo = mid; else hi = mid; }
+    const int p = lo;
+    const int c = ci[o];
+    const auto m = uv[o];
+    const T ww = w ? w[o] : (T)1;
+    T r[2], Jc[2][NCP], Jp[2][3];
+    obs_resjac<T>(s_cam + c * CAMPRE, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2],
+                  m.x, m.y, ww, r, Jc, Jp);
+    sq = (double)r[0] * r[0] + (double)r[1] * r[1];
+    double* d = s_red + threadIdx.x * 9;
+    d[0] = (double)Jp[0][0] * Jp[0][0] + (double)Jp[1][0] * Jp[1][0];
+    d[1] = (double)Jp[0][0] * Jp[0][1] + (double)Jp[1][0] * Jp[1][1];
+    d[2] = (double)Jp[0][0] * Jp[0][2] + (double)Jp[1][0] * Jp[1][2];
+    d[3] = (double)Jp[0][1] * Jp[0][1] + (double)Jp[1][1] * Jp[1][1];
+    d[4] = (double)Jp[0][1] * Jp[0][2] + (double)Jp[1][1] * Jp[1][2];
+    d[5] = (double)Jp[0][2] * Jp[0][2] + (double)Jp[1][2] * Jp[1][2];
+    d[6] = (double)Jp[0][0] * r[0] + (double)Jp[1][0] * r[1];
+    d[7] = (double)Jp[0][1] * r[0] + (double)Jp[1][1] * r[1];
+    d[8] = (double)Jp[0][2] * r[0] + (double)Jp[1][2] * r[1];
+  }
+  __syncthreads();
+  double gmax = 0;
+  const int npts = p_hi - p_lo;
+  for (int item = threadIdx.x; item < npts * 9; item += PM_BLOCK) {
+    const int q = item / 9, e = item - q * 9;
+    const int a = pt_start[p_lo + q] - o_lo, b = pt_start[p_lo + q + 1] - o_lo;
+    double s = 0;
+    for (int k = a; k < b; ++k) s += s_red[k * 9 + e];
+    const size_t p = (size_t)(p_lo + q);
+    if (e < 6) {
+      V[p * 6 + e] = s;
+      const int dsel = (e == 0) ? 0 : (e == 3) ? 1 : (e == 5) ? 2 : -1;
+      if (dsel >= 0) D2p[p * 3 + dsel] = fmax(D2p[p * 3 + dsel], s);
+    } else {
+      gp[p * 3 + (e - 6)] = s;
+      gmax = fmax(gmax, fabs(s));
+    }
+  }
+  const double cs = block_sum(sq, s_scr);
+  const double gm = block_max(gmax, s_scr);
+  if (threadIdx.x == 0) { cost_part[blockIdx.x] = 0.5 * cs; gmax_part[blockIdx.x] = gm; }
+  (void)s_pt_lo;
+}
+
+// ------------------------------------------------------------------ MFMA wrappers (16x16x4, A and B one value per lane)
+//   f64: v_mfma_f64_16x16x4_f64, D rows = (lane>>4) + 4*reg, col = lane&15
+//   f32: v_mfma_f32_16x16x4_f32, D rows = 4*(lane>>4) + reg, col = lane&15
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+  using acc_t = __attribute__((ext_vector_type(4))) double;
+  __device__ static inline acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  __device__ static inline int row_of(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma<float> {
+  using acc_t = __attribute__((ext_vector_type(4))) float;
+  __device__ static inline acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  __device__ static inline int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+// ------------------------------------------------------------------ K3b: linearize, camera side
+// Chunk = up to CM_CHUNK observations of ONE camera (cm order).  Each wave processes 64 observations
+// at a time: every lane writes the 2 rows [Jc(11) | r | 0 0 0 0] of its observation into a 128x16
+// LDS tile, then 32 MFMAs (A = B = tile fragment) accumulate tile^T * tile = [[U, g],[g^T, r.r]]
+// (16x16) in 4 accumulator registers.  No shuffles, no atomics; one 16x16 partial per wave.
+template <typename T>
+__global__ __launch_bounds__(256) void k_linearize_cams(
+    const T* __restrict__ campre, const T* __restrict__ ptsT,
+    const typename Vec2<T>::type* __restrict__ uv_cm, const T* __restrict__ w_cm,
+    const int32_t* __restrict__ pi_cm, const int32_t* __restrict__ chunk_cam,
+    const int32_t* __restrict__ chunk_begin, const int32_t* __restrict__ chunk_end,
+    double* __restrict__ Upart /* [n_chunks*4][256] */) {
+  constexpr int LD = 130;                       // [16 params][128 rows + 2]: conflict-free lane writes and MFMA reads
+  __shared__ T s_tile[4][16 * LD];
+  __shared__ T s_cam[CAMPRE];
+  using M_ = Mfma<T>;
+  const int chunk = blockIdx.x;
+  const int cam = chunk_cam[chunk];
+  const int beg = chunk_begin[chunk], end = chunk_end[chunk];
+  if (threadIdx.x < CAMPRE) s_cam[threadIdx.x] = campre[(size_t)cam * CAMPRE + threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  T* tile = s_tile[wid];
+  typename M_::acc_t acc = {0, 0, 0, 0};
+  for (int o0 = beg + wid * 64; o0 < end; o0 += 256) {
+    const int o = o0 + lane;
+    T row0[16], row1[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { row0[k] = 0; row1[k] = 0; }
+    if (o < end) {
+      const int p = pi_cm[o];
+      const auto m = uv_cm[o];
+      const T ww = w_cm ? w_cm[o] : (T)1;
+      T r[2], Jc[2][NCP], Jp[2][3];
+      obs_resjac<T>(s_cam, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2], m.x, m.y, ww, r, Jc, Jp);
+#pragma unroll
+      for (int k = 0; k < NCP; ++k) { row0[k] = Jc[0][k]; row1[k] = Jc[1][k]; }
+      row0[NCP] = r[0]; row1[NCP] = r[1];
+    }
+    // tile[param][row], row = lane (u rows) and 64 + lane (v rows): row order is irrelevant to J^T J
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { tile[k * LD + lane] = row0[k]; tile[k * LD + 64 + lane] = row1[k]; }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+      const T v = tile[(lane & 15) * LD + 4 * s + (lane >> 4)];
+      acc = M_::mma(v, v, acc);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  double* dst = Upart + ((size_t)chunk * 4 + wid) * 256;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) dst[M_::row_of(lane, rg) * 16 + (lane & 15)] = (double)acc[rg];
+}
+
+// Sum the per-wave 16x16 partials of each camera: U (C x 121), gc (C x 11).  grid = C, block = 256.
+__global__ void k_reduce_cams(const double* __restrict__ Upart, const int32_t* __restrict__ cam_chunk_start /*C+1*/,
+                              double* __restrict__ U, double* __restrict__ gc) {
+  const int c = blockIdx.x;
+  const int e = threadIdx.x;              // entry of the 16x16
+  const int a = cam_chunk_start[c] * 4, b = cam_chunk_start[c + 1] * 4;
+  double s = 0;
+  for (int k = a; k < b; ++k) s += Upart[(size_t)k * 256 + e];
+  const int i = e >> 4, j = e & 15;
+  if (i < NCP && j < NCP) U[(size_t)c * 121 + i * NCP + j] = s;
+  if (i < NCP && j == NCP) gc[(size_t)c * NCP + i] = s;
+}
+
+// ------------------------------------------------------------------ K4: Schur complement partials (MFMA)
+// Pair (ga, gb), ga <= gb, of camera groups (16 cameras = 176 rows each).  Each workgroup walks its
+// slice of the point list in chunks of SCHUR_PTS points: lanes (one per observation) write
+// Ytilde_i = W_i L^-T (11x3) into the [K=48][176] LDS panel(s) of their camera group, then the waves
+// accumulate panel products into their 16x16 output tiles with 16x16x4 MFMAs.  Partials go to slabs;
+// k_schur_reduce sums them in a fixed order (deterministic, no atomics).
+//   DIAG  (ga == gb): one panel, 66 upper-triangular tiles over 8 waves  (grid = (ksplit, ngroups))
+//   !DIAG (ga <  gb): two panels, 121 tiles over 16 waves                (grid = (ksplit, npairs - ngroups))
+//   slab layout: [pair][ks][tile (121 slots)][reg 4][lane 64]   (acc type T)
+//   bpart layout: [ga][ks][176] doubles (only diagonal pairs contribute)
+template <bool DIAG> struct SchurCfg {
+  static constexpr int THREADS = DIAG ? 512 : 1024;
+  static constexpr int NW = THREADS / 64;
+  static constexpr int NTILE = DIAG ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : GROUP_TILES * GROUP_TILES;
+  static constexpr int MAXSLOT = (NTILE + NW - 1) / NW;     // 9 or 8
+};
+
+__device__ inline void schur_tile_rc(bool diag, int t, int& R, int& Tc) {
+  if (diag) {  // upper-triangular enumeration: row R has (11-R) tiles
+    int rem = t; R = 0;
+    while (rem >= GROUP_TILES - R) { rem -= GROUP_TILES - R; ++R; }
+    Tc = R + rem;
+  } else { R = t / GROUP_TILES; Tc = t - R * GROUP_TILES; }
+}
+
+template <typename T, bool DIAG>
+__global__ __launch_bounds__(SchurCfg<DIAG>::THREADS) void k_schur(
+    const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
+    const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pt_start, int N,
+    const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
+    const double* __restrict__ lam_ptr, const int32_t* __restrict__ pair_ga, const int32_t* __restrict__ pair_gb,
+    int pair0, int ksplit, T* __restrict__ slabs, double* __restrict__ bpart) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using M_ = Mfma<T>;
+  using Cfg = SchurCfg<DIAG>;
+  constexpr int THREADS = Cfg::THREADS, NW = Cfg::NW, MAXSLOT = Cfg::MAXSLOT, NTILE = Cfg::NTILE;
+  const int pair = pair0 + blockIdx.y;
+  const int ga = pair_ga[pair], gb = pair_gb[pair];
+  const int camA0 = ga * GROUP_CAMS, camB0 = gb * GROUP_CAMS;
+  const int nA = min(GROUP_CAMS, C - camA0), nB = min(GROUP_CAMS, C - camB0);
+  T* panelA = reinterpret_cast<T*>(smem);                       // [SCHUR_K][GROUP_ROWS]
+  T* panelB = DIAG ? panelA : panelA + SCHUR_K * GROUP_ROWS;
+  T* s_cam = panelA + (DIAG ? 1 : 2) * SCHUR_K * GROUP_ROWS;    // [32][CAMPRE] : group A then group B
+  T* s_z = s_cam + 2 * GROUP_CAMS * CAMPRE;                     // [SCHUR_K]
+  for (int i = threadIdx.x; i < nA * CAMPRE; i += THREADS) s_cam[i] = campre[(size_t)camA0 * CAMPRE + i];
+  if (!DIAG)
+    for (int i = threadIdx.x; i < nB * CAMPRE; i += THREADS)
+      s_cam[GROUP_CAMS * CAMPRE + i] = campre[(size_t)camB0 * CAMPRE + i];
+  const double lam = *lam_ptr;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  typename M_::acc_t acc[MAXSLOT];
+#pragma unroll
+  for (int s = 0; s < MAXSLOT; ++s) acc[s] = typename M_::acc_t{0, 0, 0, 0};
+  double bacc = 0;   // thread rho < 176 accumulates the rhs contribution of row rho (diag pairs only)
+  const int lane_off = (lane >> 4) * GROUP_ROWS + (lane & 15);
+
+  // slice of points for this k-split (multiple of SCHUR_PTS)
+  int per = (N + ksplit - 1) / ksplit;
+  per = ((per + SCHUR_PTS - 1) / SCHUR_PTS) * SCHUR_PTS;
+  const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
+  for (int p0 = pbeg; p0 < pend; p0 += SCHUR_PTS) {
+    const int p1 = min(pend, p0 + SCHUR_PTS);
+    __syncthreads();   // previous chunk's MFMA reads are done
+    for (int i = threadIdx.x; i < (DIAG ? 1 : 2) * SCHUR_K * GROUP_ROWS; i += THREADS) panelA[i] = (T)0;
+    if (threadIdx.x < SCHUR_K) s_z[threadIdx.x] = (T)0;
+    __syncthreads();
+    const int o_lo = pt_start[p0], o_hi = pt_start[p1];
+    for (int o = o_lo + threadIdx.x; o < o_hi; o += THREADS) {
+      const int c = ci[o];
+      const bool inA = (c >= camA0 && c < camA0 + nA);
+      const bool inB = !DIAG && (c >= camB0 && c < camB0 + nB);
+      if (!inA && !inB) continue;
+      int lo = p0, hi = p1;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pt_start[mid] <= o) lo = mid; else hi = mid; }
+      const int p = lo, q = p - p0;
+      T v6[6], li[6];
+      v6[0] = (T)(V[(size_t)p * 6 + 0] + lam * fmax_pos(D2p[(size_t)p * 3 + 0]));
+      v6[1] = (T)V[(size_t)p * 6 + 1];
+      v6[2] = (T)V[(size_t)p * 6 + 2];
+      v6[3] = (T)(V[(size_t)p * 6 + 3] + lam * fmax_pos(D2p[(size_t)p * 3 + 1]));
+      v6[4] = (T)V[(size_t)p * 6 + 4];
+      v6[5] = (T)(V[(size_t)p * 6 + 5] + lam * fmax_pos(D2p[(size_t)p * 3 + 2]));
+      if (!chol3_inv<T>(v6, li)) continue;   // degenerate point: contributes nothing (its step is zeroed in back-substitution too)
+      const auto m = uv[o];
+      const T ww = w ? w[o] : (T)1;
+      const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
+      T r[2], Jc[2][NCP], Jp[2][3];
+      obs_resjac<T>(cp, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2], m.x, m.y, ww, r, Jc, Jp);
+      // Jp~ = Jp * L^-T  (2x3):  (L^-T)[k][d] = Linv[d][k]
+      T Jt[2][3];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        Jt[rr][0] = Jp[rr][0] * li[0];
+        Jt[rr][1] = Jp[rr][0] * li[1] + Jp[rr][1] * li[2];
+        Jt[rr][2] = Jp[rr][0] * li[3] + Jp[rr][1] * li[4] + Jp[rr][2] * li[5];
+      }
+      T* pan = inA ? panelA : panelB;
+      const int col0 = (inA ? (c - camA0) : (c - camB0)) * NCP;
+#pragma unroll
+      for (int e = 0; e < NCP; ++e) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          pan[(3 * q + d) * GROUP_ROWS + col0 + e] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
+      }
+      if (DIAG && o == pt_start[p]) {   // first observation of the point publishes z = L^-1 gp
+        const T g0 = (T)gp[(size_t)p * 3], g1 = (T)gp[(size_t)p * 3 + 1], g2 = (T)gp[(size_t)p * 3 + 2];
+        s_z[3 * q + 0] = li[0] * g0;
+        s_z[3 * q + 1] = li[1] * g0 + li[2] * g1;
+        s_z[3 * q + 2] = li[3] * g0 + li[4] * g1 + li[5] * g2;
+      }
+    }
+    __syncthreads();
+    // rhs: b[rho] += sum_k panel[k][rho] * z[k]
+    if (DIAG && threadIdx.x < GROUP_ROWS) {
+      T s = 0;
+#pragma unroll 8
+      for (int k = 0; k < SCHUR_K; ++k) s += panelA[k * GROUP_ROWS + threadIdx.x] * s_z[k];
+      bacc += (double)s;
+    }
+    // tiles
+#pragma unroll
+    for (int s = 0; s < MAXSLOT; ++s) {
+      const int t = wid + NW * s;
+      if (t < NTILE) {
+        int R, Tc;
+        schur_tile_rc(DIAG, t, R, Tc);
+        const T* pa = panelA + lane_off + 16 * R;
+        const T* pb = panelB + lane_off + 16 * Tc;
+#pragma unroll
+        for (int ks = 0; ks < SCHUR_K / 4; ++ks)
+          acc[s] = M_::mma(pa[ks * 4 * GROUP_ROWS], pb[ks * 4 * GROUP_ROWS], acc[s]);
+      }
+    }
+  }
+  // write partial tiles
+  T* slab = slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
+#pragma unroll
+  for (int s = 0; s < MAXSLOT; ++s) {
+    const int t = wid + NW * s;
+    if (t < NTILE) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) slab[(size_t)t * 256 + rg * 64 + lane] = acc[s][rg];
+    }
+  }
+  if (DIAG && threadIdx.x < GROUP_ROWS)
+    bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + threadIdx.x] = bacc;
+}
+
+}  // namespace sba

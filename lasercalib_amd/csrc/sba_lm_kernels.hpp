@@ -1,0 +1,378 @@
+// sba_lm_kernels.hpp -- the Levenberg-Marquardt control path on the device: reduced-system assembly,
+// dense Cholesky of the camera system, back-substitution fused with the trial residual, and the
+// accept/reject + termination logic.  Replaces the scipy TRF loop the reference drives
+// (scipy/optimize/_lsq/trf.py:401-560) with an exact damped solve; termination tests and status
+// codes keep scipy's meaning (scipy/optimize/_lsq/common.py:705-717).
+#pragma once
+#include "sba_kernels.hpp"
+
+namespace sba {
+
+struct LMState {
+  double lam, nu;
+  double cost, cost_new, pred, rho, actual;
+  double step_norm, x_norm, gnorm;
+  double ftol, xtol, gtol;
+  double pred_c, dx2_c, x2_c, gmax_c;
+  double lam_min, lam_max;
+  long long nfev, njev, max_nfev;
+  int status;        // -1: keep iterating; else scipy status code
+  int accepted;      // decision of the last trial
+  int chol_fail;
+  int fresh;         // a new linearization is waiting to be absorbed into the camera scaling
+  int iter, n_accepted;
+  int free_cams;     // 0: points-only mode
+  int pad;
+};
+
+constexpr int CHOL_THREADS = 1024;
+constexpr int CHOL_LDS_MAX_N = 176;    // packed lower triangle of 176x176 doubles = 124.6 KB of the 160 KB LDS
+
+// ------------------------------------------------------------------ reduced system assembly
+// S(i,j) = [same camera] U(i,j) - sum_ks slab ; written symmetric into E.  grid = (ntile_max, n_pairs), block 256.
+template <typename T>
+__global__ void k_schur_reduce(const T* __restrict__ slabs, int ksplit, const int32_t* __restrict__ pair_ga,
+                               const int32_t* __restrict__ pair_gb, const double* __restrict__ U, int C,
+                               double* __restrict__ E) {
+  using M_ = Mfma<T>;
+  const int ga = pair_ga[blockIdx.y], gb = pair_gb[blockIdx.y];
+  const bool diag = (ga == gb);
+  const int ntile = diag ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : GROUP_TILES * GROUP_TILES;
+  const int t = blockIdx.x;
+  if (t >= ntile) return;
+  int R = 0, Tc = 0;
+  if (diag) { int rem = t; while (rem >= GROUP_TILES - R) { rem -= GROUP_TILES - R; ++R; } Tc = R + rem; }
+  else { R = t / GROUP_TILES; Tc = t - R * GROUP_TILES; }
+  const int rg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t stride = (size_t)(GROUP_TILES * GROUP_TILES) * 256;
+  const T* src = slabs + (size_t)blockIdx.y * ksplit * stride + (size_t)t * 256 + threadIdx.x;
+  double s = 0;
+  for (int k = 0; k < ksplit; ++k) s += (double)src[(size_t)k * stride];
+  const int n = C * NCP;
+  const int i = ga * GROUP_ROWS + 16 * R + M_::row_of(lane, rg);
+  const int j = gb * GROUP_ROWS + 16 * Tc + (lane & 15);
+  if (i >= n || j >= n) return;
+  const int ci_ = i / NCP, cj_ = j / NCP;
+  double v = -s;
+  if (ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
+  E[(size_t)i * n + j] = v;
+  if (!(diag && R == Tc)) E[(size_t)j * n + i] = v;
+}
+
+// rhs = -gc + sum_ks bpart ; diagU ; gc ; cost = sum cost_part.   one block of 256 threads.
+__global__ void k_pack_exchange(const double* __restrict__ U, const double* __restrict__ gc,
+                                const double* __restrict__ bpart, int ksplit, const double* __restrict__ cost_part,
+                                int n_cost_part, int C, int free_cams, double* __restrict__ E) {
+  __shared__ double scr[4];
+  const int n = C * NCP;
+  double* rhs = E + (size_t)n * n;
+  double* dU = rhs + n;
+  double* g = dU + n;
+  if (free_cams) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int grp = i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;
+      double b = 0;
+      for (int k = 0; k < ksplit; ++k) b += bpart[((size_t)grp * ksplit + k) * GROUP_ROWS + rho];
+      const int c = i / NCP, e = i - c * NCP;
+      rhs[i] = -gc[i] + b;
+      dU[i] = U[(size_t)c * 121 + e * NCP + e];
+      g[i] = gc[i];
+    }
+  }
+  double s = 0;
+  for (int i = threadIdx.x; i < n_cost_part; i += blockDim.x) s += cost_part[i];
+  s = block_sum(s, scr);
+  if (threadIdx.x == 0) E[(size_t)n * n + 3 * n] = s;
+}
+
+// ------------------------------------------------------------------ dense Cholesky + solve of the reduced camera system
+// Single workgroup.  A = S + lam*diag(D2c) ; A = L L^T ; delta_c = A^-1 rhs.  LDSMODE keeps the packed
+// lower triangle in LDS (n <= 176); otherwise factors in place in the caller's S copy in global memory.
+struct TriLds {
+  double* a;
+  __device__ inline double& at(int i, int j) const { return a[(size_t)i * (i + 1) / 2 + j]; }   // i >= j
+};
+struct TriGlobal {
+  double* a; int n;
+  __device__ inline double& at(int i, int j) const { return a[(size_t)i * n + j]; }
+};
+
+template <bool LDSMODE, typename T>
+__global__ __launch_bounds__(CHOL_THREADS) void k_cholesky_solve(
+    double* __restrict__ E /* summed exchange buffer; S is destroyed in global mode */, int C,
+    LMState* __restrict__ st, double* __restrict__ D2c, const double* __restrict__ cams,
+    double* __restrict__ delta_c, double* __restrict__ cams_new, T* __restrict__ campre_new) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double s_y[GROUP_ROWS * 8 > 1408 ? GROUP_ROWS * 8 : 1408];   // rhs / solution, n <= 1408
+  __shared__ double s_piv;
+  __shared__ int s_fail;
+  __shared__ double s_scr[CHOL_THREADS / 64];
+  const int n = C * NCP;
+  const int tid = threadIdx.x;
+  double* S = E;
+  const double* rhs = E + (size_t)n * n;
+  const double* dU = rhs + n;
+  const double* gct = dU + n;
+  const double lam = st->lam;
+  // camera scaling: monotone max of the column norms (x_scale='jac', scipy trf.py:424,545)
+  const bool fresh = st->fresh != 0;
+  for (int i = tid; i < n; i += CHOL_THREADS) {
+    double d = D2c[i];
+    if (fresh) { d = fmax(d, dU[i]); D2c[i] = d; }
+    s_y[i] = rhs[i];
+  }
+  if (tid == 0) { s_fail = 0; if (tid == 0 && E) st->cost = E[(size_t)n * n + 3 * n]; }
+  __syncthreads();
+  TriLds Ll{reinterpret_cast<double*>(smem)};
+  TriGlobal Lg{S, n};
+  auto AT = [&](int i, int j) -> double& { if constexpr (LDSMODE) return Ll.at(i, j); else return Lg.at(i, j); };
+  // load (+ damping)
+  for (int idx = tid; idx < n * n; idx += CHOL_THREADS) {
+    const int i = idx / n, j = idx - i * n;
+    if (j > i) continue;
+    double v = S[idx];
+    if (i == j) v += lam * fmax_pos(D2c[i]);
+    AT(i, j) = v;
+  }
+  __syncthreads();
+  const int tx = tid & 31, ty = tid >> 5;
+  for (int k = 0; k < n; ++k) {
+    if (tid == 0) {
+      const double d = AT(k, k);
+      if (!(d > 0.0) || !isfinite(d)) { s_fail = 1; s_piv = 1.0; }
+      else s_piv = 1.0 / sqrt(d);
+    }
+    __syncthreads();
+    if (s_fail) break;
+    const double ip = s_piv;
+    for (int i = k + tid; i < n; i += CHOL_THREADS) AT(i, k) *= ip;    // includes the diagonal: L_kk = sqrt(d)
+    __syncthreads();
+    for (int i = k + 1 + ty; i < n; i += 32) {
+      const double lik = AT(i, k);
+      for (int j = k + 1 + tx; j <= i; j += 32) AT(i, j) -= lik * AT(j, k);
+    }
+    __syncthreads();
+  }
+  const bool fail = s_fail != 0;
+  // triangular solves inside wave 0 (no workgroup barriers): L y = rhs ; L^T x = y
+  if (!fail && tid < 64) {
+    for (int k = 0; k < n; ++k) {
+      const double yk = s_y[k] / AT(k, k);
+      __builtin_amdgcn_wave_barrier();
+      if (tid == 0) s_y[k] = yk;
+      for (int i = k + 1 + tid; i < n; i += 64) s_y[i] -= AT(i, k) * yk;
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int k = n - 1; k >= 0; --k) {
+      const double xk = s_y[k] / AT(k, k);
+      __builtin_amdgcn_wave_barrier();
+      if (tid == 0) s_y[k] = xk;
+      for (int i = tid; i < k; i += 64) s_y[i] -= AT(k, i) * xk;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  double pred = 0, dx2 = 0, x2 = 0, gm = 0;
+  for (int i = tid; i < n; i += CHOL_THREADS) {
+    const double d = fail ? 0.0 : s_y[i];
+    delta_c[i] = d;
+    const double x = cams[i];
+    cams_new[i] = x + d;
+    pred += 0.5 * d * (lam * fmax_pos(D2c[i]) * d - gct[i]);
+    dx2 += d * d;
+    x2 += x * x;
+    gm = fmax(gm, fabs(gct[i]));
+  }
+  pred = block_sum(pred, s_scr);
+  dx2 = block_sum(dx2, s_scr);
+  x2 = block_sum(x2, s_scr);
+  gm = block_max(gm, s_scr);
+  if (tid == 0) {
+    st->pred_c = pred; st->dx2_c = dx2; st->x2_c = x2; st->gmax_c = gm;
+    st->chol_fail = fail ? 1 : 0;
+    st->fresh = 0;
+  }
+  __syncthreads();
+  if (tid < C) campre_build<T>(cams_new + (size_t)tid * NCP, campre_new + (size_t)tid * CAMPRE);
+}
+
+// points-only mode: no camera system.  Zero step for the cameras, cost from the partials.
+__global__ void k_nocam_step(LMState* __restrict__ st, const double* __restrict__ E, int n) {
+  if (threadIdx.x == 0) {
+    st->cost = E[(size_t)n * n + 3 * n];
+    st->pred_c = 0; st->dx2_c = 0; st->x2_c = 0; st->gmax_c = 0; st->chol_fail = 0; st->fresh = 0;
+  }
+}
+
+// ------------------------------------------------------------------ K6: back-substitution + trial point + trial residual
+// Same point-aligned workgroups as k_linearize_points.
+//   phase 1 (lane = observation): t_i = Jp^T (Jc delta_c[cam])                      -> LDS
+//   phase 2 (lane = point):       delta_p = -(V + lam D)^-1 (gp + sum_i t_i) ; X_new -> LDS + global
+//   phase 3 (lane = observation): residual at (cams_new, X_new)                     -> cost partial
+// partials per block: trial_part[4][nblk] = cost_new, pred_p, |delta_p|^2, |X|^2
+template <typename T>
+__global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
+    const T* __restrict__ campre, const T* __restrict__ campre_new, int C, const double* __restrict__ pts,
+    const T* __restrict__ ptsT, const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ blk_pt,
+    const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
+    const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ pts_new,
+    T* __restrict__ ptsT_new, double* __restrict__ trial_part, int nblk) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_t = reinterpret_cast<double*>(smem);          // [256][3]
+  double* s_xn = s_t + PM_BLOCK * 3;                      // [256][3] new point coordinates (per local point)
+  T* s_cam = reinterpret_cast<T*>(s_xn + PM_BLOCK * 3);   // [C][CAMPRE] current
+  T* s_camn = s_cam + C * CAMPRE;                         // [C][CAMPRE] trial
+  T* s_dc = s_camn + C * CAMPRE;                          // [C*11]
+  __shared__ double s_scr[PM_BLOCK / 64];
+  const bool free_cams = st->free_cams != 0;
+  const double lam = st->lam;
+  stage_campre(campre, s_cam, C);
+  stage_campre(campre_new, s_camn, C);
+  for (int i = threadIdx.x; i < C * NCP; i += PM_BLOCK) s_dc[i] = (T)delta_c[i];
+  const int p_lo = blk_pt[blockIdx.x], p_hi = blk_pt[blockIdx.x + 1];
+  const int o_lo = pt_start[p_lo], o_hi = pt_start[p_hi];
+  const int nobs = o_hi - o_lo, npts = p_hi - p_lo;
+  __syncthreads();
+  int my_p = -1, my_c = 0;
+  typename Vec2<T>::type my_uv; my_uv.x = 0; my_uv.y = 0;
+  T my_w = (T)1;
+  if ((int)threadIdx.x < nobs) {
+    const int o = o_lo + threadIdx.x;
+    int lo = p_lo, hi = p_hi;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pt_start[mid] <= o) lo = mid; else hi = mid; }
+    my_p = lo;
+    my_c = ci[o];
+    my_uv = uv[o];
+    my_w = w ? w[o] : (T)1;
+    double t0 = 0, t1 = 0, t2 = 0;
+    if (free_cams) {
+      T r[2], Jc[2][NCP], Jp[2][3];
+      obs_resjac<T>(s_cam + my_c * CAMPRE, ptsT[3 * (size_t)my_p], ptsT[3 * (size_t)my_p + 1],
+                    ptsT[3 * (size_t)my_p + 2], my_uv.x, my_uv.y, my_w, r, Jc, Jp);
+      T s0 = 0, s1 = 0;
+#pragma unroll
+      for (int e = 0; e < NCP; ++e) { s0 += Jc[0][e] * s_dc[my_c * NCP + e]; s1 += Jc[1][e] * s_dc[my_c * NCP + e]; }
+      t0 = (double)(Jp[0][0] * s0 + Jp[1][0] * s1);
+      t1 = (double)(Jp[0][1] * s0 + Jp[1][1] * s1);
+      t2 = (double)(Jp[0][2] * s0 + Jp[1][2] * s1);
+    }
+    s_t[threadIdx.x * 3 + 0] = t0; s_t[threadIdx.x * 3 + 1] = t1; s_t[threadIdx.x * 3 + 2] = t2;
+  }
+  __syncthreads();
+  double pred = 0, dx2 = 0, x2 = 0;
+  for (int q = threadIdx.x; q < npts; q += PM_BLOCK) {
+    const size_t p = (size_t)(p_lo + q);
+    const int a = pt_start[p] - o_lo, b = pt_start[p + 1] - o_lo;
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int k = a; k < b; ++k) { t0 += s_t[k * 3]; t1 += s_t[k * 3 + 1]; t2 += s_t[k * 3 + 2]; }
+    const double g0 = gp[p * 3], g1 = gp[p * 3 + 1], g2 = gp[p * 3 + 2];
+    const double d0 = fmax_pos(D2p[p * 3]), d1 = fmax_pos(D2p[p * 3 + 1]), d2 = fmax_pos(D2p[p * 3 + 2]);
+    double v6[6], li[6];
+    v6[0] = V[p * 6] + lam * d0; v6[1] = V[p * 6 + 1]; v6[2] = V[p * 6 + 2];
+    v6[3] = V[p * 6 + 3] + lam * d1; v6[4] = V[p * 6 + 4]; v6[5] = V[p * 6 + 5] + lam * d2;
+    double e0 = 0, e1 = 0, e2 = 0;
+    if (chol3_inv<double>(v6, li)) {
+      const double b0 = -(g0 + t0), b1 = -(g1 + t1), b2 = -(g2 + t2);
+      const double y0 = li[0] * b0, y1 = li[1] * b0 + li[2] * b1, y2 = li[3] * b0 + li[4] * b1 + li[5] * b2;
+      e0 = li[0] * y0 + li[1] * y1 + li[3] * y2;     // L^-T y
+      e1 = li[2] * y1 + li[4] * y2;
+      e2 = li[5] * y2;
+    }
+    const double X0 = pts[p * 3], X1 = pts[p * 3 + 1], X2 = pts[p * 3 + 2];
+    const double n0 = X0 + e0, n1 = X1 + e1, n2 = X2 + e2;
+    pts_new[p * 3] = n0; pts_new[p * 3 + 1] = n1; pts_new[p * 3 + 2] = n2;
+    ptsT_new[p * 3] = (T)n0; ptsT_new[p * 3 + 1] = (T)n1; ptsT_new[p * 3 + 2] = (T)n2;
+    s_xn[q * 3] = n0; s_xn[q * 3 + 1] = n1; s_xn[q * 3 + 2] = n2;
+    pred += 0.5 * (e0 * (lam * d0 * e0 - g0) + e1 * (lam * d1 * e1 - g1) + e2 * (lam * d2 * e2 - g2));
+    dx2 += e0 * e0 + e1 * e1 + e2 * e2;
+    x2 += X0 * X0 + X1 * X1 + X2 * X2;
+  }
+  __syncthreads();
+  double sq = 0;
+  if (my_p >= 0) {
+    const int q = my_p - p_lo;
+    T u, v;
+    obs_project<T>(s_camn + my_c * CAMPRE, (T)s_xn[q * 3], (T)s_xn[q * 3 + 1], (T)s_xn[q * 3 + 2], u, v);
+    const T r0 = my_w * (u - my_uv.x), r1 = my_w * (v - my_uv.y);
+    sq = (double)r0 * r0 + (double)r1 * r1;
+  }
+  const double c_new = block_sum(sq, s_scr);
+  const double b_pred = block_sum(pred, s_scr);
+  const double b_dx2 = block_sum(dx2, s_scr);
+  const double b_x2 = block_sum(x2, s_scr);
+  if (threadIdx.x == 0) {
+    trial_part[blockIdx.x] = 0.5 * c_new;
+    trial_part[nblk + blockIdx.x] = b_pred;
+    trial_part[2 * nblk + blockIdx.x] = b_dx2;
+    trial_part[3 * nblk + blockIdx.x] = b_x2;
+  }
+}
+
+// one block: fold the per-block partials into this rank's 8 scalars
+__global__ void k_trial_scalars(const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
+                                int nblk, const LMState* __restrict__ st, double* __restrict__ scal) {
+  __shared__ double scr[4];
+  double a = 0, b = 0, c = 0, d = 0, g = 0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+    a += trial_part[i]; b += trial_part[nblk + i]; c += trial_part[2 * nblk + i]; d += trial_part[3 * nblk + i];
+    g = fmax(g, gmax_part[i]);
+  }
+  a = block_sum(a, scr); b = block_sum(b, scr); c = block_sum(c, scr); d = block_sum(d, scr); g = block_max(g, scr);
+  if (threadIdx.x == 0) {
+    scal[0] = a; scal[1] = b; scal[2] = c; scal[3] = d; scal[4] = g; scal[5] = (double)st->chol_fail;
+    scal[6] = 0; scal[7] = 0;
+  }
+}
+
+// ------------------------------------------------------------------ accept / reject / terminate (1 thread)
+__global__ void k_decide(LMState* __restrict__ st, const double* __restrict__ scal_all, int n_ranks) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
+  for (int r = 0; r < n_ranks; ++r) {
+    const double* s = scal_all + (size_t)r * NSCAL;
+    cost_new += s[0]; pred += s[1]; dx2 += s[2]; x2 += s[3];
+    gmax = fmax(gmax, s[4]); failv = fmax(failv, s[5]);
+  }
+  pred += st->pred_c; dx2 += st->dx2_c; x2 += st->x2_c; gmax = fmax(gmax, st->gmax_c);
+  st->gnorm = gmax;
+  st->step_norm = sqrt(dx2);
+  st->x_norm = sqrt(x2);
+  st->cost_new = cost_new;
+  st->pred = pred;
+  st->iter += 1;
+  if (gmax < st->gtol) {                      // scipy trf.py:452 tests this before taking a step
+    st->status = 1; st->accepted = 0; st->actual = 0; st->rho = 0;
+    return;
+  }
+  st->nfev += 1;
+  const bool ok = !(failv > 0) && isfinite(cost_new) && pred > 0;
+  const double actual = ok ? st->cost - cost_new : -1.0;
+  const double rho = ok ? actual / pred : -1.0;
+  st->actual = actual; st->rho = rho;
+  int status = -1;
+  if (ok) {                                    // scipy common.py:705-717
+    const bool f_ok = actual < st->ftol * st->cost && rho > 0.25;
+    const bool x_ok = sqrt(dx2) < st->xtol * (st->xtol + sqrt(x2));
+    status = (f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : -1;
+  }
+  if (actual > 0) {
+    const double t = 2.0 * rho - 1.0;
+    double l = st->lam * fmax(1.0 / 3.0, 1.0 - t * t * t);
+    st->lam = fmin(fmax(l, st->lam_min), st->lam_max);
+    st->nu = 2.0;
+    st->accepted = 1;
+    st->n_accepted += 1;
+    st->cost = cost_new;        // refreshed again from the exchange buffer after the next linearization
+    st->njev += 1;              // the accepted point gets a new Jacobian (scipy counts it the same way)
+    st->fresh = 1;
+  } else {
+    st->lam = fmin(st->lam * st->nu, st->lam_max);
+    st->nu *= 2.0;
+    st->accepted = 0;
+  }
+  if (status < 0 && st->nfev >= st->max_nfev) status = 0;
+  st->status = status;
+}
+
+}  // namespace sba

@@ -1,0 +1,177 @@
+// sba_model.hpp -- per-observation camera model and analytic Jacobian for gfx950 device code.
+//
+// Model being replaced: PySBA.rotate / PySBA.project / PySBA.fun
+// (/root/reference/lasercalib/pySBA.py:61-101): Rodrigues rotate -> + t -> pinhole divide ->
+// two-term radial distortion with ONE focal length -> + principal point; residual = w*(proj - uv).
+// The reference differentiates this numerically (scipy 3-point, 28 evaluations per Jacobian);
+// here the 2x11 camera block and 2x3 point block are closed-form.
+//
+// Per-camera quantities that do not depend on the observation (sin/cos, the Rodrigues series
+// coefficients and the rotation matrix) are computed once per parameter update into a "CamPre"
+// table that every workgroup stages in LDS, so the per-observation path has no transcendental.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sba {
+
+constexpr int NCP = 11;          // camera parameters per camera (pySBA.py:31-35)
+constexpr int CAMPRE = 25;       // CamPre row length (odd stride => LDS reads of different cameras spread over banks)
+// CamPre row layout
+constexpr int CP_RHO = 0;        // rho[3]
+constexpr int CP_T = 3;          // t[3]
+constexpr int CP_F = 6, CP_K1 = 7, CP_K2 = 8, CP_CX = 9, CP_CY = 10;
+constexpr int CP_R = 11;         // R[9] row-major
+constexpr int CP_A = 20, CP_B = 21, CP_A2 = 22, CP_B2 = 23;   // sin t/t, (1-cos t)/t^2, (cos t - a)/t^2, (a-2b)/t^2
+constexpr int CP_PAD = 24;
+
+// Build one CamPre row from the 11 raw parameters (always evaluated in double, then narrowed).
+template <typename T>
+__device__ inline void campre_build(const double* __restrict__ cam, T* __restrict__ out) {
+  const double r0 = cam[0], r1 = cam[1], r2 = cam[2];
+  const double th2 = r0 * r0 + r1 * r1 + r2 * r2;
+  double c, a, b, a2, b2;
+  if (th2 < 1e-4) {   // series: theta = 0 must behave as the identity (pySBA.py:66-68)
+    c = 1.0 - th2 * (0.5 - th2 * (1.0 / 24 - th2 * (1.0 / 720)));
+    a = 1.0 - th2 * (1.0 / 6 - th2 * (1.0 / 120 - th2 * (1.0 / 5040)));
+    b = 0.5 - th2 * (1.0 / 24 - th2 * (1.0 / 720 - th2 * (1.0 / 40320)));
+    a2 = -1.0 / 3 + th2 * (1.0 / 30 - th2 * (1.0 / 840 - th2 * (1.0 / 45360)));
+    b2 = -1.0 / 12 + th2 * (1.0 / 180 - th2 * (1.0 / 6720 - th2 * (1.0 / 453600)));
+  } else {
+    const double th = sqrt(th2);
+    double s;
+    sincos(th, &s, &c);
+    a = s / th;
+    b = (1.0 - c) / th2;
+    a2 = (c - a) / th2;
+    b2 = (a - 2.0 * b) / th2;
+  }
+#pragma unroll
+  for (int i = 0; i < NCP; ++i) out[i] = (T)cam[i];
+  // R = c I + a [rho]x + b rho rho^T
+  out[CP_R + 0] = (T)(c + b * r0 * r0);
+  out[CP_R + 1] = (T)(-a * r2 + b * r0 * r1);
+  out[CP_R + 2] = (T)(a * r1 + b * r0 * r2);
+  out[CP_R + 3] = (T)(a * r2 + b * r1 * r0);
+  out[CP_R + 4] = (T)(c + b * r1 * r1);
+  out[CP_R + 5] = (T)(-a * r0 + b * r1 * r2);
+  out[CP_R + 6] = (T)(-a * r1 + b * r2 * r0);
+  out[CP_R + 7] = (T)(a * r0 + b * r2 * r1);
+  out[CP_R + 8] = (T)(c + b * r2 * r2);
+  out[CP_A] = (T)a;
+  out[CP_B] = (T)b;
+  out[CP_A2] = (T)a2;
+  out[CP_B2] = (T)b2;
+  out[CP_PAD] = (T)0;
+}
+
+// Forward projection only.  cp points at a CamPre row (LDS or global).
+template <typename T>
+__device__ inline void obs_project(const T* __restrict__ cp, T X0, T X1, T X2, T& u, T& v) {
+  const T p0 = cp[CP_R + 0] * X0 + cp[CP_R + 1] * X1 + cp[CP_R + 2] * X2 + cp[CP_T + 0];
+  const T p1 = cp[CP_R + 3] * X0 + cp[CP_R + 4] * X1 + cp[CP_R + 5] * X2 + cp[CP_T + 1];
+  const T p2 = cp[CP_R + 6] * X0 + cp[CP_R + 7] * X1 + cp[CP_R + 8] * X2 + cp[CP_T + 2];
+  const T iz = (T)1 / p2;
+  const T x = p0 * iz, y = p1 * iz;
+  const T n = x * x + y * y;
+  const T d = (T)1 + n * (cp[CP_K1] + cp[CP_K2] * n);
+  const T fd = cp[CP_F] * d;
+  u = fd * x + cp[CP_CX];
+  v = fd * y + cp[CP_CY];
+}
+
+// Residual + Jacobian blocks of one observation.
+//   r[2]      = w * (project - uv)
+//   Jc[2][11] = d r / d(cam params),  Jp[2][3] = d r / d X
+template <typename T>
+__device__ inline void obs_resjac(const T* __restrict__ cp, T X0, T X1, T X2, T uo, T vo, T w,
+                                  T r[2], T Jc[2][NCP], T Jp[2][3]) {
+  const T R0 = cp[CP_R + 0], R1 = cp[CP_R + 1], R2 = cp[CP_R + 2];
+  const T R3 = cp[CP_R + 3], R4 = cp[CP_R + 4], R5 = cp[CP_R + 5];
+  const T R6 = cp[CP_R + 6], R7 = cp[CP_R + 7], R8 = cp[CP_R + 8];
+  const T p0 = R0 * X0 + R1 * X1 + R2 * X2 + cp[CP_T + 0];
+  const T p1 = R3 * X0 + R4 * X1 + R5 * X2 + cp[CP_T + 1];
+  const T p2 = R6 * X0 + R7 * X1 + R8 * X2 + cp[CP_T + 2];
+  const T iz = (T)1 / p2;
+  const T x = p0 * iz, y = p1 * iz;
+  const T n = x * x + y * y;
+  const T k1 = cp[CP_K1], k2 = cp[CP_K2], f = cp[CP_F];
+  const T d = (T)1 + n * (k1 + k2 * n);
+  const T dn = k1 + (T)2 * k2 * n;
+  r[0] = w * (f * d * x + cp[CP_CX] - uo);
+  r[1] = w * (f * d * y + cp[CP_CY] - vo);
+
+  // A = w * d(u,v)/dp
+  const T wf = w * f;
+  const T ux = wf * (d + (T)2 * x * x * dn);
+  const T uy = wf * ((T)2 * x * y * dn);
+  const T vy = wf * (d + (T)2 * y * y * dn);
+  const T A00 = ux * iz, A01 = uy * iz, A02 = -(ux * x + uy * y) * iz;
+  const T A10 = uy * iz, A11 = vy * iz, A12 = -(uy * x + vy * y) * iz;
+
+  // point block: A R
+  Jp[0][0] = A00 * R0 + A01 * R3 + A02 * R6;
+  Jp[0][1] = A00 * R1 + A01 * R4 + A02 * R7;
+  Jp[0][2] = A00 * R2 + A01 * R5 + A02 * R8;
+  Jp[1][0] = A10 * R0 + A11 * R3 + A12 * R6;
+  Jp[1][1] = A10 * R1 + A11 * R4 + A12 * R7;
+  Jp[1][2] = A10 * R2 + A11 * R5 + A12 * R8;
+
+  // rotation block: A * dP/drho,  dP/drho = q rho^T - a [X]x + b rho X^T + b (rho.X) I
+  const T h0 = cp[CP_RHO + 0], h1 = cp[CP_RHO + 1], h2 = cp[CP_RHO + 2];
+  const T a = cp[CP_A], b = cp[CP_B], a2 = cp[CP_A2], b2 = cp[CP_B2];
+  const T c0 = h1 * X2 - h2 * X1, c1 = h2 * X0 - h0 * X2, c2 = h0 * X1 - h1 * X0;   // rho x X
+  const T hd = h0 * X0 + h1 * X1 + h2 * X2;
+  const T q0 = -a * X0 + a2 * c0 + b2 * hd * h0;
+  const T q1 = -a * X1 + a2 * c1 + b2 * hd * h1;
+  const T q2 = -a * X2 + a2 * c2 + b2 * hd * h2;
+  const T bhd = b * hd;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const T a0 = rr ? A10 : A00, a1 = rr ? A11 : A01, a2r = rr ? A12 : A02;
+    const T Aq = a0 * q0 + a1 * q1 + a2r * q2;
+    const T Ah = b * (a0 * h0 + a1 * h1 + a2r * h2);
+    // row * [X]x  = (row x X) transposed sign: (row^T [X]x)_j = (X x row)_j ... use explicit form
+    // [X]x = [[0,-X2,X1],[X2,0,-X0],[-X1,X0,0]]  => row*[X]x = (a1*X2 - a2r*X1, a2r*X0 - a0*X2, a0*X1 - a1*X0)
+    const T x0 = a1 * X2 - a2r * X1, x1 = a2r * X0 - a0 * X2, x2 = a0 * X1 - a1 * X0;
+    Jc[rr][0] = Aq * h0 - a * x0 + Ah * X0 + bhd * a0;
+    Jc[rr][1] = Aq * h1 - a * x1 + Ah * X1 + bhd * a1;
+    Jc[rr][2] = Aq * h2 - a * x2 + Ah * X2 + bhd * a2r;
+    Jc[rr][3] = a0;
+    Jc[rr][4] = a1;
+    Jc[rr][5] = a2r;
+  }
+  const T wd = w * d, wfn = wf * n;
+  Jc[0][6] = wd * x;        Jc[1][6] = wd * y;
+  Jc[0][7] = wfn * x;       Jc[1][7] = wfn * y;
+  Jc[0][8] = wfn * n * x;   Jc[1][8] = wfn * n * y;
+  Jc[0][9] = w;             Jc[1][9] = (T)0;
+  Jc[0][10] = (T)0;         Jc[1][10] = w;
+}
+
+__device__ inline void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ inline void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
+
+// Plain Rodrigues rotation from a raw rotation vector (PySBA.rotate, pySBA.py:61-73), used by the
+// stateless sba_rotate / sba_project entry points where every row carries its own camera.
+template <typename T>
+__device__ inline void rotate_raw(T h0, T h1, T h2, T X0, T X1, T X2, T& P0, T& P1, T& P2) {
+  const T th2 = h0 * h0 + h1 * h1 + h2 * h2;
+  T c, a, b;
+  if (th2 < (T)1e-4) {
+    c = (T)1 - th2 * ((T)0.5 - th2 * ((T)(1.0 / 24) - th2 * (T)(1.0 / 720)));
+    a = (T)1 - th2 * ((T)(1.0 / 6) - th2 * ((T)(1.0 / 120) - th2 * (T)(1.0 / 5040)));
+    b = (T)0.5 - th2 * ((T)(1.0 / 24) - th2 * ((T)(1.0 / 720) - th2 * (T)(1.0 / 40320)));
+  } else {
+    const T th = sqrt(th2);
+    T s;
+    sincos_t(th, &s, &c);
+    a = s / th;
+    b = ((T)1 - c) / th2;
+  }
+  const T hd = b * (h0 * X0 + h1 * X1 + h2 * X2);
+  P0 = c * X0 + a * (h1 * X2 - h2 * X1) + hd * h0;
+  P1 = c * X1 + a * (h2 * X0 - h0 * X2) + hd * h1;
+  P2 = c * X2 + a * (h0 * X1 - h1 * X0) + hd * h2;
+}
+
+}  // namespace sba

@@ -1,0 +1,230 @@
+"""Multi-GPU bundle adjustment: one process per GPU, points sharded, cameras replicated.
+
+Every observation touches one camera block and one point block (pySBA.py:110-116), so the
+point list is cut into contiguous ranges (balanced by observation count, at point boundaries)
+and each rank owns its points, their observations, their 3x3 solves and back-substitution.
+The only data-path exchange per LM trial is an all-reduce (sum) of the reduced camera system
+``[S | rhs | diag U | g_c | cost]`` ((11C)^2 + 33C + 1 doubles) plus an all-gather of 8 scalars
+per rank; every rank then solves the same camera system redundantly, so no broadcast is needed
+and all ranks take bit-identical accept/reject decisions.
+
+The driver below is engine-agnostic: the product engine is :class:`HipEngine` (libsba_hip.so
+phase calls + RCCL through ``torch.distributed``); the CPU tests drive the same loop with a
+numpy model over gloo.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+NSCALARS = 8
+
+
+# ----------------------------------------------------------------------------- process group helpers
+def _td():
+    """torch.distributed if torch is already imported and a process group is up, else None."""
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return None
+    d = torch.distributed
+    if d.is_available() and d.is_initialized():
+        return d
+    return None
+
+
+def world_size():
+    d = _td()
+    return d.get_world_size() if d else 1
+
+
+def rank():
+    d = _td()
+    return d.get_rank() if d else 0
+
+
+# ----------------------------------------------------------------------------- sharding
+def shard_bounds(pt_start, n_ranks):
+    """Cut points [0,N) into n_ranks contiguous ranges with ~equal observation counts.
+
+    pt_start: (N+1,) CSR offsets of the point-major observation list.  Returns (n_ranks+1,) point
+    boundaries; cuts fall on point boundaries so no point straddles two ranks.
+    """
+    pt_start = np.asarray(pt_start, dtype=np.int64)
+    N = pt_start.shape[0] - 1
+    M = int(pt_start[-1])
+    targets = (np.arange(1, n_ranks, dtype=np.float64) * M / n_ranks)
+    cuts = np.searchsorted(pt_start, targets, side="left")
+    # choose the nearer of the two neighbouring point boundaries
+    lo = np.clip(cuts - 1, 0, N)
+    cuts = np.where(np.abs(pt_start[np.clip(cuts, 0, N)] - targets) <= np.abs(pt_start[lo] - targets), cuts, lo)
+    b = np.concatenate([[0], np.clip(cuts, 0, N), [N]]).astype(np.int64)
+    return np.maximum.accumulate(b)
+
+
+def make_shard(points3D, points2D, cam_idx, pt_idx, weights, n_ranks, r):
+    """Slice rank r's share out of the full problem.
+
+    Returns dict(pts, uv, ci, pi_local, w, p0, p1, obs_index) where obs_index are the positions of
+    the shard's observations in the caller's observation order.
+    """
+    pt_idx = np.asarray(pt_idx, dtype=np.int64)
+    N = points3D.shape[0]
+    order = np.argsort(pt_idx, kind="stable") if np.any(np.diff(pt_idx) < 0) else np.arange(pt_idx.size)
+    counts = np.bincount(pt_idx, minlength=N)
+    pt_start = np.concatenate([[0], np.cumsum(counts)])
+    b = shard_bounds(pt_start, n_ranks)
+    p0, p1 = int(b[r]), int(b[r + 1])
+    sel = order[pt_start[p0]:pt_start[p1]]
+    w = None if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1)[sel]
+    return dict(pts=np.ascontiguousarray(points3D[p0:p1], dtype=np.float64),
+                uv=np.ascontiguousarray(np.asarray(points2D)[sel], dtype=np.float64),
+                ci=np.ascontiguousarray(np.asarray(cam_idx)[sel], dtype=np.int64),
+                pi_local=pt_idx[sel] - p0, w=w, p0=p0, p1=p1, obs_index=sel, bounds=b)
+
+
+# ----------------------------------------------------------------------------- collectives
+class TorchComm:
+    """Sum-all-reduce and row all-gather over torch.distributed (nccl == RCCL on ROCm, or gloo)."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.d = torch.distributed
+        self.n = self.d.get_world_size()
+        self.r = self.d.get_rank()
+
+    def _t(self, x):
+        return x if isinstance(x, self.torch.Tensor) else self.torch.from_numpy(x)
+
+    def all_reduce_sum(self, x):
+        self.d.all_reduce(self._t(x), op=self.d.ReduceOp.SUM)
+        return x
+
+    def all_gather_rows(self, x):
+        t = self._t(x).reshape(-1)
+        out = self.torch.empty(self.n * t.numel(), dtype=t.dtype, device=t.device)
+        self.d.all_gather_into_tensor(out, t)
+        return out if isinstance(x, self.torch.Tensor) else out.numpy().reshape(self.n, -1)
+
+    def all_gather_var(self, a):
+        """All-gather numpy arrays whose leading dimension differs per rank (host side, small)."""
+        objs = [None] * self.n
+        self.d.all_gather_object(objs, a)
+        return objs
+
+
+class SoloComm:
+    n, r = 1, 0
+
+    def all_reduce_sum(self, x):
+        return x
+
+    def all_gather_rows(self, x):
+        return x if not isinstance(x, np.ndarray) else x.reshape(1, -1)
+
+    def all_gather_var(self, a):
+        return [a]
+
+
+# ----------------------------------------------------------------------------- the loop
+def run_lm(engine, comm, max_iter=0):
+    """Engine-agnostic sharded LM loop.  Returns (status, iterations)."""
+    status, it = None, 0
+    need_lin = True
+    while status is None:
+        if need_lin:
+            engine.linearize()
+        E = engine.form_reduced()
+        comm.all_reduce_sum(E)
+        sc = engine.solve_trial(E)
+        sc_all = comm.all_gather_rows(sc)
+        status, accepted = engine.decide(sc_all, comm.n)
+        need_lin = accepted or getattr(engine, "always_relinearize", False)
+        it += 1
+        if status is None and max_iter and it >= max_iter:
+            status = 0
+    return status, it
+
+
+# ----------------------------------------------------------------------------- product engine
+class HipEngine:
+    """libsba_hip.so phase calls on this rank's shard; exchange buffers are torch CUDA tensors."""
+
+    def __init__(self, cams, shard, dtype, device, opts_kwargs):
+        import torch
+        from . import _native
+        self.torch = torch
+        torch.cuda.set_device(device)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.prob = _native.Problem(cams, shard["pts"], shard["uv"], shard["ci"], shard["pi_local"],
+                                    weights=shard["w"], dtype=dtype, device=device, stream=stream)
+        self.opts = self.prob.make_opts(**opts_kwargs)
+        self.always_relinearize = bool(opts_kwargs.get("always_relinearize", False))
+        dev = torch.device("cuda", device)
+        self.E = torch.empty(self.prob.exchange_size(), dtype=torch.float64, device=dev)
+        self.sc = torch.empty(NSCALARS, dtype=torch.float64, device=dev)
+        self.log = []
+        self.prob.lm_begin(self.opts)
+
+    def linearize(self):
+        self.prob.lm_linearize()
+
+    def form_reduced(self):
+        self.prob.lm_form_reduced(self.E.data_ptr())
+        return self.E
+
+    def solve_trial(self, E):
+        self.prob.lm_solve_trial(E.data_ptr(), self.sc.data_ptr())
+        return self.sc
+
+    def decide(self, sc_all, n_ranks):
+        status, acc, row = self.prob.lm_decide(sc_all.data_ptr(), n_ranks)
+        self.log.append(row)
+        return (None if status < 0 else status), acc
+
+    def finish(self):
+        return self.prob.lm_finish()
+
+    def close(self):
+        self.prob.close()
+
+
+def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device, max_iter=0,
+                  always_relinearize=False):
+    """PySBA._solve for world_size > 1.  Every rank calls this with the same full problem and gets
+    the same full result back."""
+    comm = TorchComm()
+    cams = np.ascontiguousarray(sba.cameraArray, dtype=np.float64)
+    pts = np.ascontiguousarray(sba.points3D, dtype=np.float64)
+    w = sba._weights_or_none()
+    shard = make_shard(pts, sba.points2D, sba.cameraIndices, sba.point2DIndices, w, comm.n, comm.r)
+    eng = HipEngine(cams, shard, dtype, device, dict(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev or 0,
+                                                      mode=mode, verbose=0, max_iter=max_iter,
+                                                      always_relinearize=always_relinearize))
+    try:
+        status, _ = run_lm(eng, comm, max_iter=max_iter)
+        cams_opt, pts_loc, rep = eng.finish()
+        gc_loc, gp_loc = eng.prob.get_gradient()
+        fvec_loc, cost_loc = eng.prob.residual()
+    finally:
+        eng.close()
+    gp_max = float(np.max(np.abs(gp_loc))) if gp_loc.size else 0.0
+    parts = comm.all_gather_var((shard["p0"], pts_loc, shard["obs_index"], fvec_loc, cost_loc, gc_loc, gp_max,
+                                 rep.initial_cost))
+    pts_opt = np.empty_like(pts)
+    fvec = np.empty(2 * np.asarray(sba.point2DIndices).size)
+    cost, opt, cost0 = 0.0, 0.0, 0.0
+    gc = np.zeros_like(gc_loc)
+    for p0, pl, oi, fv, cl, gcl, gpm, c0 in parts:
+        pts_opt[p0:p0 + pl.shape[0]] = pl
+        fvec.reshape(-1, 2)[oi] = fv.reshape(-1, 2)
+        cost += cl
+        cost0 += c0
+        gc += gcl
+        opt = max(opt, gpm)
+    opt = max(opt, float(np.max(np.abs(gc))))
+    rep.cost, rep.optimality, rep.status, rep.initial_cost = cost, opt, status, cost0
+    res, c, p = sba._package(mode, cams_opt, pts_opt, rep, eng.log, fvec, verbose if comm.r == 0 else 0)
+    return res, c, p

@@ -1,0 +1,323 @@
+"""Drop-in mirror of the reference's ``lasercalib.pySBA.PySBA`` over the MI355X engine.
+
+Same class name, constructor, attributes, method names, positional order and defaults as
+/root/reference/lasercalib/pySBA.py:25-325, so ``scripts/calibrate_camera.py`` (which does
+``from lasercalib.pySBA import PySBA`` -> ``PySBA(...)`` -> ``sba.bundleAdjust(1e-4)`` ->
+reads ``sba.cameraArray`` -> pickles ``sba``) runs unchanged.  Only the arithmetic moved:
+projection, analytic Jacobian blocks and the whole Levenberg-Marquardt / Schur-complement
+loop execute in libsba_hip.so on the GPU (see include/sba_hip.h).  There is no CPU path in
+this module: without the shared library or without a gfx950 device the methods raise.
+
+Environment knobs (the script itself stays unchanged):
+  LASERCALIB_SBA_DTYPE   f64 (default) | f32   arithmetic type of the per-observation math
+  LASERCALIB_SBA_DEVICE  HIP device ordinal (default: LOCAL_RANK or 0)
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+from scipy.optimize import OptimizeResult
+from scipy.sparse import coo_matrix, csr_matrix, lil_matrix
+
+from . import _native
+
+N_CAM_PARAMS = 11
+
+TERMINATION_MESSAGES = {
+    -1: "Improper input parameters status returned from `leastsq`",
+    0: "The maximum number of function evaluations is exceeded.",
+    1: "`gtol` termination condition is satisfied.",
+    2: "`ftol` termination condition is satisfied.",
+    3: "`xtol` termination condition is satisfied.",
+    4: "Both `ftol` and `xtol` termination conditions are satisfied.",
+}
+
+
+def _env_dtype():
+    return _native.dtype_code(os.environ.get("LASERCALIB_SBA_DTYPE", "f64"))
+
+
+def _env_device():
+    return int(os.environ.get("LASERCALIB_SBA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+class SBAResult(OptimizeResult):
+    """scipy ``OptimizeResult`` whose ``jac`` / ``grad`` are computed on first access.
+
+    scipy returns the final Jacobian as a (2M x n) CSR matrix (least_squares.py:950-961); at
+    800k observations that is 22.4M non-zeros which the reference's caller never reads
+    (scripts/calibrate_camera.py:71 discards the result), so it is materialised lazily by the
+    device Jacobian kernel instead of on every solve.
+    """
+
+    def __missing__(self, key):
+        if key in ("jac", "grad"):
+            maker = dict.get(self, "_jac_maker")
+            if maker is None:
+                raise KeyError(key)
+            J = maker()
+            dict.__setitem__(self, "jac", J)
+            dict.__setitem__(self, "grad", J.T.dot(self["fun"]))
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError as e:
+            raise AttributeError(name) from e
+
+    def __reduce__(self):   # drop the closure when pickled
+        d = {k: v for k, v in self.items() if k != "_jac_maker"}
+        return (OptimizeResult, (d,))
+
+
+def _print_table(log, initial_cost, report, message, verbose):
+    """Iteration table in the format scipy prints for verbose=2 (scipy/optimize/_lsq/common.py:545-563)."""
+    if verbose >= 2:
+        print("{:^15}{:^15}{:^15}{:^15}{:^15}{:^15}".format(
+            "Iteration", "Total nfev", "Cost", "Cost reduction", "Step norm", "Optimality"))
+        first_opt = log[0].optimality if log else report.optimality
+        print("{:^15}{:^15}{:^15.4e}{:^15}{:^15}{:^15.2e}".format(0, 1, initial_cost, "", "", first_opt))
+        it = 0
+        for k, row in enumerate(log):
+            if not row.accepted:
+                continue
+            it += 1
+            nxt = log[k + 1].optimality if k + 1 < len(log) else report.optimality
+            print("{:^15}{:^15}{:^15.4e}{:^15.2e}{:^15.2e}{:^15.2e}".format(
+                it, row.nfev, row.cost, row.cost_reduction, row.step_norm, nxt))
+    if verbose >= 1:
+        print(message)
+        print("Function evaluations {0}, initial cost {1:.4e}, final cost {2:.4e}, "
+              "first-order optimality {3:.2e}.".format(report.nfev, initial_cost, report.cost, report.optimality))
+
+
+class PySBA:
+    """Python class for Simple Bundle Adjustment (surface of pySBA.py:25-325, GPU engine underneath)."""
+
+    def __init__(self, cameraArray, points3D, points2D, cameraIndices, point2DIndices, points3Dfixed=None,
+                 pointWeights=None):
+        # references are stored, not copies, like pySBA.py:50-59
+        self.cameraArray = cameraArray
+        self.points3D = points3D
+        self.points2D = points2D
+        self.cameraIndices = cameraIndices
+        self.point2DIndices = point2DIndices
+        self.points3Dfixed = points3Dfixed
+        if pointWeights is None:
+            pointWeights = np.full_like(point2DIndices, 1)     # integer ones (pySBA.py:57)
+        self.pointWeights = pointWeights.reshape((-1, 1))
+        self.points3Dfixed_labeled = None
+
+    # ------------------------------------------------------------------ model (GPU kernels, numpy in/out)
+    def rotate(self, points, rot_vecs):
+        """Rodrigues rotation of (M,3) points by (M,3) rotation vectors (pySBA.py:61-73)."""
+        return _native.rotate_rows(points, rot_vecs, dtype=_env_dtype(), device=_env_device())
+
+    def project(self, points, cameraArray):
+        """(M,3) points x (M,11) gathered camera rows -> (M,2) pixels (pySBA.py:76-89)."""
+        return _native.project_rows(points, cameraArray, dtype=_env_dtype(), device=_env_device())
+
+    def fun(self, params, n_cameras, n_points, camera_indices, point_indices, points_2d, pointWeights):
+        """Weighted residual vector, interleaved (u,v) per observation (pySBA.py:92-101)."""
+        nCamParams = N_CAM_PARAMS
+        camera_params = params[:n_cameras * nCamParams].reshape((n_cameras, nCamParams))
+        points_3d = params[n_cameras * nCamParams:].reshape((n_points, 3))
+        points_proj = self.project(points_3d[point_indices], camera_params[camera_indices])
+        return (pointWeights * (points_proj - points_2d)).ravel()
+
+    def bundle_adjustment_sparsity(self, numCameras, numPoints, cameraIndices, pointIndices):
+        """Jacobian pattern of `fun`: 28 ones per observation (pySBA.py:103-118), as a lil_matrix of int."""
+        m = cameraIndices.size * 2
+        n = numCameras * N_CAM_PARAMS + numPoints * 3
+        obs = np.arange(cameraIndices.size)
+        cols = np.concatenate([cameraIndices[:, None] * N_CAM_PARAMS + np.arange(N_CAM_PARAMS)[None, :],
+                               numCameras * N_CAM_PARAMS + pointIndices[:, None] * 3 + np.arange(3)[None, :]], axis=1)
+        rows = np.repeat(2 * obs, cols.shape[1])
+        cols = cols.ravel()
+        rows = np.concatenate([rows, rows + 1])
+        cols = np.concatenate([cols, cols])
+        A = coo_matrix((np.ones(rows.size, dtype=int), (rows, cols)), shape=(m, n))
+        A.sum_duplicates()
+        A.data[:] = 1
+        return lil_matrix(A)
+
+    def optimizedParams(self, params, n_cameras, n_points):
+        """Split x into (n_cameras,11) and (n_points,3) views (pySBA.py:121-129)."""
+        camera_params = params[:n_cameras * N_CAM_PARAMS].reshape((n_cameras, N_CAM_PARAMS))
+        points_3d = params[n_cameras * N_CAM_PARAMS:].reshape((n_points, 3))
+        return camera_params, points_3d
+
+    # ------------------------------------------------------------------ solvers
+    def _weights_or_none(self):
+        w = np.asarray(self.pointWeights).reshape(-1)
+        if w.size and np.all(w == 1):
+            return None          # unit weights: the kernels skip the multiply and the 8 B/obs read
+        return w.astype(np.float64)
+
+    def _solve(self, mode, ftol, verbose=2, xtol=1e-8, gtol=1e-8, max_nfev=None):
+        cams = np.ascontiguousarray(self.cameraArray, dtype=np.float64)
+        pts = np.ascontiguousarray(self.points3D, dtype=np.float64)
+        from . import dist
+        if dist.world_size() > 1:
+            return dist.solve_sharded(self, mode, ftol, xtol, gtol, max_nfev, verbose, _env_dtype(), _env_device())
+        with _native.Problem(cams, pts, self.points2D, self.cameraIndices, self.point2DIndices,
+                             weights=self._weights_or_none(), dtype=_env_dtype(), device=_env_device()) as prob:
+            opts = prob.make_opts(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev or 0, mode=mode, verbose=verbose)
+            cams_opt, pts_opt, rep, log = prob.solve_lm(opts)
+            fvec, _ = prob.residual()
+        return self._package(mode, cams_opt, pts_opt, rep, log, fvec, verbose)
+
+    def _package(self, mode, cams_opt, pts_opt, rep, log, fvec, verbose):
+        C_, N_ = cams_opt.shape[0], pts_opt.shape[0]
+        if mode == _native.MODE_POINTS_ONLY:
+            x = pts_opt.ravel().copy()
+        else:
+            x = np.hstack((cams_opt.ravel(), pts_opt.ravel()))
+        message = TERMINATION_MESSAGES[rep.status]
+        _print_table(log, rep.initial_cost, rep, message, verbose)
+        ci, pi = np.asarray(self.cameraIndices), np.asarray(self.point2DIndices)
+        uv, w = self.points2D, self._weights_or_none()
+        dt, dev = _env_dtype(), _env_device()
+
+        def make_jac():
+            with _native.Problem(cams_opt, pts_opt, uv, ci, pi, weights=w, dtype=dt, device=dev) as prob:
+                _, Jc, Jp = prob.residual_jacobian()
+            return assemble_jacobian(Jc, Jp, ci, pi, C_, N_, points_only=(mode == _native.MODE_POINTS_ONLY))
+
+        res = SBAResult(x=x, cost=rep.cost, fun=fvec, optimality=rep.optimality,
+                        active_mask=np.zeros_like(x), nfev=int(rep.nfev), njev=int(rep.njev),
+                        status=int(rep.status), message=message, success=rep.status > 0)
+        dict.__setitem__(res, "_jac_maker", make_jac)
+        return res, cams_opt, pts_opt
+
+    def bundleAdjust(self, ftol=1e-4):
+        """Bundle-adjust all cameras and all 3-D points (pySBA.py:132-147).
+
+        Rebinds self.cameraArray / self.points3D to new arrays and returns the result object.
+        """
+        res, cams, pts = self._solve(_native.MODE_FULL, ftol)
+        self.cameraArray = cams
+        self.points3D = pts
+        return res
+
+    def bundleAdjust_nocam(self, ftol=1e-7):
+        """Optimise the 3-D points with the cameras held fixed (pySBA.py:237-250)."""
+        res, _cams, pts = self._solve(_native.MODE_POINTS_ONLY, ftol)
+        self.points3D = pts
+        return res
+
+    def fun_nocam(self, params, camera_params, n_points, camera_indices, point_indices, points_2d, pointWeights):
+        """pySBA.py:228-235."""
+        points_3d = params.reshape((n_points, 3))
+        points_proj = self.project(points_3d[point_indices], camera_params[camera_indices])
+        return (pointWeights * (points_proj - points_2d)).ravel()
+
+    def bundle_adjustment_sparsity_nocam(self, numPoints, pointIndices):
+        """pySBA.py:216-226."""
+        m = pointIndices.size * 2
+        obs = np.arange(pointIndices.size)
+        cols = (pointIndices[:, None] * 3 + np.arange(3)[None, :])
+        rows = np.repeat(2 * obs, 3)
+        cols = cols.ravel()
+        A = coo_matrix((np.ones(2 * rows.size, dtype=int), (np.concatenate([rows, rows + 1]), np.concatenate([cols, cols]))),
+                       shape=(m, numPoints * 3))
+        A.sum_duplicates()
+        A.data[:] = 1
+        return lil_matrix(A)
+
+    def getResiduals(self):
+        """Residuals at the current parameters (pySBA.py:207-213).
+
+        Like the reference, the weight vector passed here has shape (M,), which numpy cannot
+        broadcast against the (M,2) residual unless M is 1 or 2 -- the same ValueError results.
+        """
+        numCameras = self.cameraArray.shape[0]
+        numPoints = self.points3D.shape[0]
+        x0 = np.hstack((self.cameraArray.ravel(), self.points3D.ravel()))
+        return self.fun(x0, numCameras, numPoints, self.cameraIndices, self.point2DIndices, self.points2D,
+                        np.full_like(self.point2DIndices, 1))
+
+    # -- variants whose residual is defined on other parameterisations --------------------------
+    def fun_camonly(self, params, n_cameras, n_points, camera_indices, point_indices, points_2d, pointWeights, points_3d):
+        """Cameras-only residual; squares the pixel error like the reference (pySBA.py:151-156)."""
+        camera_params = params.reshape(n_cameras, N_CAM_PARAMS)
+        points_proj = self.project(points_3d[point_indices], camera_params[camera_indices])
+        return (pointWeights * (points_proj - points_2d) ** 2).ravel()
+
+    def fun_transform_points_3d(self, params, numCameras, n_points, camera_params, camera_indices, point_indices,
+                                points_2d, pointWeights, points_3d):
+        """3x4 affine on the points, squared pixel error (pySBA.py:176-187)."""
+        T = np.vstack((params.reshape(3, 4), [0, 0, 0, 1]))
+        homog = np.vstack((points_3d.transpose(), np.ones(shape=(1, n_points))))
+        moved = np.dot(T, homog).transpose()[:, :3]
+        points_proj = self.project(moved[point_indices], camera_params[camera_indices])
+        return (pointWeights * (points_proj - points_2d) ** 2).ravel()
+
+    def fun_sharedcam(self, params, n_cameras, n_points, camera_indices, point_indices, points_2d, pointWeights):
+        """Shared (f,k1,k2) parameterisation (pySBA.py:277-295)."""
+        nI, nE, nC = 3, 6, 2
+        nCamParams = n_cameras * (nE + nC) + nI
+        shared = params[:nI]
+        extr = params[nI:nI + n_cameras * nE].reshape((n_cameras, nE))
+        centre = params[nI + n_cameras * nE:nCamParams].reshape((n_cameras, nC))
+        camera_params = np.concatenate((extr, np.tile(shared, (n_cameras, 1)), centre), axis=1)
+        points_3d = params[nCamParams:].reshape((n_points, 3))
+        points_proj = self.project(points_3d[point_indices], camera_params[camera_indices])
+        return (pointWeights * (points_proj - points_2d)).ravel()
+
+    def bundle_adjustment_sparsity_sharedcam(self, numCameras, numPoints, cameraIndices, pointIndices):
+        """pySBA.py:252-275."""
+        nI, nE, nC = 3, 6, 2
+        nCamParams = numCameras * (nE + nC) + nI
+        obs = np.arange(cameraIndices.size)
+        cols = np.concatenate([
+            np.tile(np.arange(nI), (obs.size, 1)),
+            nI + cameraIndices[:, None] * nE + np.arange(nE)[None, :],
+            nI + numCameras * nE + cameraIndices[:, None] * nC + np.arange(nC)[None, :],
+            nCamParams + pointIndices[:, None] * 3 + np.arange(3)[None, :]], axis=1)
+        rows = np.repeat(2 * obs, cols.shape[1])
+        cols = cols.ravel()
+        A = coo_matrix((np.ones(2 * rows.size, dtype=int), (np.concatenate([rows, rows + 1]), np.concatenate([cols, cols]))),
+                       shape=(cameraIndices.size * 2, nCamParams + numPoints * 3))
+        A.sum_duplicates()
+        A.data[:] = 1
+        return lil_matrix(A)
+
+    def bundle_adjustment_camonly(self, ftol=1e-4):
+        """pySBA.py:160-173 -- not on the device yet."""
+        raise NotImplementedError("bundle_adjustment_camonly is not implemented on the MI355X engine yet; "
+                                  "there is deliberately no CPU fallback")
+
+    def bundleAdjust_transform_points_3d(self, ftol=1e-3):
+        """pySBA.py:190-205 -- not on the device yet."""
+        raise NotImplementedError("bundleAdjust_transform_points_3d is not implemented on the MI355X engine yet; "
+                                  "there is deliberately no CPU fallback")
+
+    def bundleAdjust_sharedcam(self, ftol=1e-6):
+        """pySBA.py:297-325 -- not on the device yet."""
+        raise NotImplementedError("bundleAdjust_sharedcam is not implemented on the MI355X engine yet; "
+                                  "there is deliberately no CPU fallback")
+
+
+# pickles written by scripts/calibrate_camera.py:86-88 must load wherever `lasercalib.pySBA` resolves
+PySBA.__module__ = "lasercalib.pySBA"
+
+
+def assemble_jacobian(Jc, Jp, cam_idx, pt_idx, n_cams, n_pts, points_only=False):
+    """Blocks (M,2,11)/(M,2,3) -> the CSR matrix scipy would return as ``res.jac`` (pySBA.py:110-116 layout)."""
+    M = cam_idx.shape[0]
+    if points_only:
+        cols = (pt_idx[:, None] * 3 + np.arange(3)[None, :])
+        data = Jp.reshape(2 * M, 3)
+        width, ncol = 3, n_pts * 3
+    else:
+        cols = np.concatenate([cam_idx[:, None] * N_CAM_PARAMS + np.arange(N_CAM_PARAMS)[None, :],
+                               n_cams * N_CAM_PARAMS + pt_idx[:, None] * 3 + np.arange(3)[None, :]], axis=1)
+        data = np.concatenate([Jc, Jp], axis=2).reshape(2 * M, 14)
+        width, ncol = 14, n_cams * N_CAM_PARAMS + n_pts * 3
+    cols = np.repeat(cols[:, None, :], 2, axis=1).reshape(2 * M, width)
+    indptr = np.arange(0, 2 * M * width + 1, width)
+    return csr_matrix((data.ravel(), cols.ravel(), indptr), shape=(2 * M, ncol))

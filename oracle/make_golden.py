@@ -1,0 +1,174 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+Usage:  python oracle/make_golden.py            (needs /root/reference; never runs on the GPU box)
+
+The reference ships no tests or golden vectors, so the pins for this
+path are produced here by importing /root/reference/lasercalib/pySBA.py and recording its
+inputs and outputs.  Only data (arrays) is written -- no reference source travels.
+"tight" solves use ftol=1e-8 (scipy's own default): below that the reference's TRF/LSMR step crawls
+(cost reductions ~4e-7 per iteration on the 2x500 rig) and does not terminate in practical time.
+Fixture families follow SURVEY.md section 8(c): F1 project/rotate, F2 fun, F3 Jacobian +
+sparsity pattern, F4 converged solves, F5 variant solvers, F6 gauge-invariant summaries.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import scipy
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+from lasercalib.pySBA import PySBA  # noqa: E402  (the reference, NOT the repo's package)
+from scipy.optimize._numdiff import approx_derivative  # noqa: E402
+
+from lasercalib_amd.synth import make_rig  # noqa: E402
+from oracle import sba_oracle as orc  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+VERS = dict(scipy_version=scipy.__version__, numpy_version=np.__version__)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def ref_instance(rig, weights=None):
+    return PySBA(rig["cams0"].copy(), rig["pts0"].copy(), rig["points_2d"], rig["camera_ind"],
+                 rig["point_ind"], pointWeights=weights)
+
+
+def f1_project():
+    rng = np.random.default_rng(101)
+    M = 4096
+    rig = make_rig(8, 64, seed=5)
+    cams = rig["cams_true"][rng.integers(0, 8, M)].copy()
+    pts = rng.uniform(-700, 700, (M, 3))
+    pts[:, 2] = rng.uniform(-50, 150, M)
+    # special rotations: theta = 0, ~1e-9, ~1e-4, ~pi ; near-zero depth rows
+    cams[0:32, 0:3] = 0.0
+    cams[32:64, 0:3] = rng.normal(0, 1e-9, (32, 3))
+    cams[64:96, 0:3] = rng.normal(0, 1e-4, (32, 3))
+    ax = rng.normal(0, 1, (32, 3))
+    ax /= np.linalg.norm(ax, axis=1)[:, None]
+    cams[96:128, 0:3] = ax * (np.pi - rng.uniform(0, 1e-3, (32, 1)))
+    cams[128:160, 3:6] = rng.normal(0, 50, (32, 3))        # points close to the camera (small z)
+    sba = PySBA(cams, pts, None, None, np.zeros(1, dtype=np.int64))
+    rot = sba.rotate(pts, cams[:, :3])
+    uv = sba.project(pts, cams)
+    np.savez_compressed(os.path.join(OUT, "f1_project.npz"), points=pts, cam_rows=cams,
+                        rotated=rot, projected=uv, **VERS)
+
+
+def f2_fun():
+    out = {}
+    for tag, (C, N, vis) in dict(a=(2, 500, 1.0), b=(5, 200, 0.6)).items():
+        rig = make_rig(C, N, seed=11, visibility=vis)
+        M = rig["point_ind"].size
+        rng = np.random.default_rng(7)
+        w = rng.uniform(0.5, 2.0, M)
+        x0 = np.hstack((rig["cams0"].ravel(), rig["pts0"].ravel()))
+        for wtag, weights in (("unit", None), ("w", w)):
+            sba = ref_instance(rig, weights)
+            r = sba.fun(x0, C, N, sba.cameraIndices, sba.point2DIndices, sba.points2D, sba.pointWeights)
+            out[f"{tag}_{wtag}_res"] = r
+        out[f"{tag}_x0"] = x0
+        out[f"{tag}_uv"] = rig["points_2d"]
+        out[f"{tag}_ci"] = rig["camera_ind"]
+        out[f"{tag}_pi"] = rig["point_ind"]
+        out[f"{tag}_w"] = w
+        out[f"{tag}_shape"] = np.array([C, N])
+    np.savez_compressed(os.path.join(OUT, "f2_fun.npz"), **out, **VERS)
+
+
+def f3_jacobian():
+    out = {}
+    for tag, (C, N, vis) in dict(a=(3, 40, 0.8), b=(2, 500, 1.0)).items():
+        rig = make_rig(C, N, seed=21, visibility=vis)
+        sba = ref_instance(rig)
+        x0 = np.hstack((rig["cams0"].ravel(), rig["pts0"].ravel()))
+        A = sba.bundle_adjustment_sparsity(C, N, sba.cameraIndices, sba.point2DIndices)
+        J = approx_derivative(sba.fun, x0, method="3-point", sparsity=A,
+                              args=(C, N, sba.cameraIndices, sba.point2DIndices, sba.points2D,
+                                    sba.pointWeights)).tocsr()
+        J.sort_indices()
+        Ac = A.tocsr()
+        Ac.sort_indices()
+        out.update({f"{tag}_x0": x0, f"{tag}_uv": rig["points_2d"], f"{tag}_ci": rig["camera_ind"],
+                    f"{tag}_pi": rig["point_ind"], f"{tag}_shape": np.array([C, N]),
+                    f"{tag}_J_data": J.data, f"{tag}_J_indices": J.indices, f"{tag}_J_indptr": J.indptr,
+                    f"{tag}_A_indices": Ac.indices, f"{tag}_A_indptr": Ac.indptr})
+    np.savez_compressed(os.path.join(OUT, "f3_jacobian.npz"), **out, **VERS)
+
+
+def f4_f6_solves():
+    out = {}
+    for tag, (C, N, vis) in dict(cfg1=(2, 500, 1.0), mid=(8, 2000, 1.0), sparse=(6, 600, 0.6)).items():
+        rig = make_rig(C, N, seed=0, visibility=vis)
+        out.update({f"{tag}_cams0": rig["cams0"], f"{tag}_pts0": rig["pts0"], f"{tag}_uv": rig["points_2d"],
+                    f"{tag}_ci": rig["camera_ind"], f"{tag}_pi": rig["point_ind"]})
+        for ftag, ftol in (("loose", 1e-4), ("tight", 1e-8)):
+            sba = ref_instance(rig)
+            res = quiet(sba.bundleAdjust, ftol)
+            rms = orc.rms_reprojection(sba.cameraArray, sba.points3D, rig["points_2d"],
+                                       rig["camera_ind"], rig["point_ind"])
+            intr, ratios = orc.gauge_invariants(sba.cameraArray)
+            out.update({f"{tag}_{ftag}_x": res.x, f"{tag}_{ftag}_cost": res.cost,
+                        f"{tag}_{ftag}_nfev": res.nfev, f"{tag}_{ftag}_njev": res.njev,
+                        f"{tag}_{ftag}_status": res.status, f"{tag}_{ftag}_optimality": res.optimality,
+                        f"{tag}_{ftag}_rms": rms, f"{tag}_{ftag}_intr": intr,
+                        f"{tag}_{ftag}_centre_ratios": ratios})
+            print(tag, ftag, "cost", res.cost, "nfev", res.nfev, "status", res.status, "rms", rms, flush=True)
+    np.savez_compressed(os.path.join(OUT, "f4_solves.npz"), **out, **VERS)
+
+
+def f5_variants():
+    C, N = 4, 300
+    rig = make_rig(C, N, seed=3, visibility=0.9)
+    out = {"cams0": rig["cams0"], "pts0": rig["pts0"], "uv": rig["points_2d"],
+           "ci": rig["camera_ind"], "pi": rig["point_ind"]}
+
+    sba = ref_instance(rig)
+    res = quiet(sba.bundleAdjust_nocam)
+    out.update(nocam_x=res.x, nocam_cost=res.cost, nocam_status=res.status, nocam_pts=sba.points3D)
+
+    sba = ref_instance(rig)
+    res = quiet(sba.bundle_adjustment_camonly)
+    out.update(camonly_x=res.x, camonly_cost=res.cost, camonly_status=res.status,
+               camonly_cams=sba.cameraArray)
+
+    sba = ref_instance(rig)
+    res = quiet(sba.bundleAdjust_sharedcam)
+    out.update(sharedcam_x=res.x, sharedcam_cost=res.cost, sharedcam_status=res.status,
+               sharedcam_cams=sba.cameraArray, sharedcam_pts=sba.points3D)
+
+    sba = ref_instance(rig)
+    res = quiet(sba.bundleAdjust_transform_points_3d)
+    out.update(transform_x=res.x, transform_cost=res.cost, transform_status=res.status,
+               transform_pts=sba.points3D)
+
+    # quirk pins: getResiduals raises for M != 2 ; default weights are int ones (M,1)
+    sba = ref_instance(rig)
+    try:
+        sba.getResiduals()
+        raised = 0
+    except ValueError:
+        raised = 1
+    out.update(getResiduals_raises=raised, default_weight_dtype=str(sba.pointWeights.dtype),
+               default_weight_shape=np.array(sba.pointWeights.shape))
+    np.savez_compressed(os.path.join(OUT, "f5_variants.npz"), **out, **VERS)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    stages = dict(f1=f1_project, f2=f2_fun, f3=f3_jacobian, f4=f4_f6_solves, f5=f5_variants)
+    for name in (sys.argv[1:] or list(stages)):
+        stages[name]()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,331 @@
+"""GPU parity tests: every call goes through the C ABI (libsba_hip.so) and is checked against the
+oracle (oracle/sba_oracle.py = the reference's algorithm restated), the committed golden fixtures
+(produced by the reference itself) and, at full size, size-independent properties.
+
+Tolerances (stated once, used below):
+  fp64 device path   residual / projection  <= 1e-9 px absolute (values ~1e3 px => ~1e-12 relative)
+                     analytic Jacobian vs the reference's scipy 3-point FD Jacobian <= 1e-6 relative to max|J|
+                     converged cost vs reference at its own ftol: relative <= 1e-5, RMS reprojection <= 1e-4 px
+  fp32 device path   residual <= 2e-3 px, converged cost relative <= 1e-4, RMS <= 1e-3 px
+"""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from lasercalib_amd import _native  # noqa: E402
+from lasercalib_amd.pySBA import PySBA, assemble_jacobian  # noqa: E402
+from lasercalib_amd.synth import make_rig  # noqa: E402
+from oracle import lm_schur_model as model  # noqa: E402
+from oracle import sba_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert _native.device_count() > 0, "no HIP device visible: GPU tests must run on the MI355X box"
+
+
+def _problem(rig, dtype="f64", weights=None, cams=None, pts=None):
+    return _native.Problem(rig["cams0"] if cams is None else cams, rig["pts0"] if pts is None else pts,
+                           rig["points_2d"], rig["camera_ind"], rig["point_ind"], weights=weights, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------- F1: rotate / project
+@pytest.mark.parametrize("dtype,tol_rot,tol_uv", [("f64", 1e-9, 1e-7), ("f32", 2e-3, 0.5)])
+def test_project_rotate_golden(golden, dtype, tol_rot, tol_uv):
+    g = golden("f1_project.npz")
+    rot = _native.rotate_rows(g["points"], g["cam_rows"][:, :3], dtype=dtype)
+    uv = _native.project_rows(g["points"], g["cam_rows"], dtype=dtype)
+    assert np.max(np.abs(rot - g["rotated"])) <= tol_rot
+    # rows 128:160 put points a few cm from the camera (huge pixel values); compare relatively there
+    scale = np.maximum(1.0, np.abs(g["projected"]) / 1e3)
+    assert np.max(np.abs(uv - g["projected"]) / scale) <= tol_uv
+
+
+def test_project_theta_zero_is_identity():
+    pts = np.array([[1.0, 2.0, 3.0], [-4.0, 5.0, 6.0]])
+    rot = _native.rotate_rows(pts, np.zeros((2, 3)))
+    assert np.array_equal(rot, pts)          # pySBA.py:66-68: theta = 0 leaves the point unchanged
+
+
+def test_project_empty():
+    assert _native.project_rows(np.zeros((0, 3)), np.zeros((0, 11))).shape == (0, 2)
+
+
+def test_pysba_project_matches_oracle_like_sba_print_does():
+    # the call sba_print.py:17 makes: numpy fancy-indexed arguments
+    rig = make_rig(5, 300, seed=4, visibility=0.7)
+    sba = PySBA(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    got = sba.project(sba.points3D[sba.point2DIndices], sba.cameraArray[sba.cameraIndices]) - sba.points2D
+    ref = orc.project(rig["pts0"][rig["point_ind"]], rig["cams0"][rig["camera_ind"]]) - rig["points_2d"]
+    assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= 1e-9
+
+
+# ----------------------------------------------------------------------------- F2: fun
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("wtag", ["unit", "w"])
+def test_residual_golden_f64(golden, tag, wtag):
+    g = golden("f2_fun.npz")
+    C, N = g[f"{tag}_shape"]
+    x0 = g[f"{tag}_x0"]
+    w = g[f"{tag}_w"] if wtag == "w" else None
+    with _native.Problem(x0[:11 * C].reshape(C, 11), x0[11 * C:].reshape(N, 3), g[f"{tag}_uv"], g[f"{tag}_ci"],
+                         g[f"{tag}_pi"], weights=w) as prob:
+        r, cost = prob.residual()
+        r2, _ = prob.residual(x0)                  # explicit-x path
+    ref = g[f"{tag}_{wtag}_res"]
+    assert np.max(np.abs(r - ref)) <= 1e-9
+    assert np.array_equal(r, r2)
+    assert abs(cost - 0.5 * ref @ ref) <= 1e-9 * (0.5 * ref @ ref)
+
+
+def test_residual_f32(golden):
+    g = golden("f2_fun.npz")
+    C, N = g["a_shape"]
+    x0 = g["a_x0"]
+    with _native.Problem(x0[:11 * C].reshape(C, 11), x0[11 * C:].reshape(N, 3), g["a_uv"], g["a_ci"], g["a_pi"],
+                         dtype="f32") as prob:
+        r, cost = prob.residual()
+    ref = g["a_unit_res"]
+    assert np.max(np.abs(r - ref)) <= 5e-3
+    assert abs(cost - 0.5 * ref @ ref) <= 1e-4 * (0.5 * ref @ ref)
+
+
+def test_pysba_fun_and_getResiduals_quirk(golden):
+    g = golden("f2_fun.npz")
+    C, N = g["b_shape"]
+    x0 = g["b_x0"]
+    sba = PySBA(x0[:11 * C].reshape(C, 11).copy(), x0[11 * C:].reshape(N, 3).copy(), g["b_uv"], g["b_ci"], g["b_pi"],
+                pointWeights=g["b_w"])
+    r = sba.fun(x0, C, N, sba.cameraIndices, sba.point2DIndices, sba.points2D, sba.pointWeights)
+    assert np.max(np.abs(r - g["b_w_res"])) <= 1e-9
+    with pytest.raises(ValueError):                 # reference bug kept: pySBA.py:207-213 broadcasts (M,) against (M,2)
+        sba.getResiduals()
+
+
+def test_unsorted_observations_keep_caller_order():
+    rig = make_rig(4, 150, seed=9, visibility=0.8)
+    rng = np.random.default_rng(1)
+    shuf = rng.permutation(rig["point_ind"].size)
+    ref = orc.fun(np.hstack((rig["cams0"].ravel(), rig["pts0"].ravel())), 4, 150, rig["camera_ind"][shuf],
+                  rig["point_ind"][shuf], rig["points_2d"][shuf], 1.0)
+    with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"][shuf], rig["camera_ind"][shuf],
+                         rig["point_ind"][shuf]) as prob:
+        r, _ = prob.residual()
+        _, Jc, Jp = prob.residual_jacobian()
+    assert np.max(np.abs(r - ref)) <= 1e-9
+    _, Jc_m, Jp_m = model.residual_jacobian(rig["cams0"], rig["pts0"], rig["points_2d"][shuf], rig["camera_ind"][shuf],
+                                            rig["point_ind"][shuf], 1.0)
+    assert np.max(np.abs(Jc - Jc_m)) <= 1e-7 and np.max(np.abs(Jp - Jp_m)) <= 1e-7
+
+
+# ----------------------------------------------------------------------------- F3: Jacobian
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_jacobian_vs_reference_fd(golden, tag):
+    from scipy.sparse import csr_matrix
+    g = golden("f3_jacobian.npz")
+    C, N = g[f"{tag}_shape"]
+    x0 = g[f"{tag}_x0"]
+    with _native.Problem(x0[:11 * C].reshape(C, 11), x0[11 * C:].reshape(N, 3), g[f"{tag}_uv"], g[f"{tag}_ci"],
+                         g[f"{tag}_pi"]) as prob:
+        r, Jc, Jp = prob.residual_jacobian()
+    J = assemble_jacobian(Jc, Jp, g[f"{tag}_ci"], g[f"{tag}_pi"], C, N)
+    J.sort_indices()
+    Jref = csr_matrix((g[f"{tag}_J_data"], g[f"{tag}_J_indices"], g[f"{tag}_J_indptr"]), shape=J.shape)
+    assert np.array_equal(J.indices, g[f"{tag}_A_indices"]) and np.array_equal(J.indptr, g[f"{tag}_A_indptr"])
+    err = abs(J - Jref).max()
+    assert err <= 1e-6 * abs(Jref).max(), err        # FD truncation of the 3-point rule dominates
+
+
+def test_jacobian_theta_zero_camera():
+    rig = make_rig(3, 60, seed=2)
+    cams = rig["cams0"].copy()
+    cams[1, 0:3] = 0.0                                  # series branch of the Rodrigues derivative
+    cams[2, 0:3] = 1e-7
+    with _problem(rig, cams=cams) as prob:
+        r, Jc, Jp = prob.residual_jacobian()
+    res_m, Jc_m, Jp_m = model.residual_jacobian(cams, rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], 1.0)
+    assert np.all(np.isfinite(Jc)) and np.max(np.abs(Jc - Jc_m)) <= 1e-6 * np.max(np.abs(Jc_m))
+    # and against central differences of the oracle's residual in the rotation parameters
+    x = np.hstack((cams.ravel(), rig["pts0"].ravel()))
+    f = lambda xx: orc.fun(xx, 3, 60, rig["camera_ind"], rig["point_ind"], rig["points_2d"], 1.0)
+    for k in range(3):
+        h = 1e-6
+        e = np.zeros_like(x); e[11 + k] = h
+        fd = (f(x + e) - f(x - e)) / (2 * h)
+        sel = rig["camera_ind"] == 1
+        assert np.max(np.abs(Jc[sel, :, k].ravel() - fd.reshape(-1, 2)[sel].ravel())) <= 1e-4 * max(1.0, np.max(np.abs(fd)))
+
+
+# ----------------------------------------------------------------------------- F4: converged solves
+def _solve(rig_like, ftol, dtype="f64", mode=_native.MODE_FULL, weights=None, **kw):
+    with _native.Problem(rig_like["cams0"], rig_like["pts0"], rig_like["uv"], rig_like["ci"], rig_like["pi"],
+                         weights=weights, dtype=dtype) as prob:
+        opts = prob.make_opts(ftol=ftol, mode=mode, **kw)
+        return prob.solve_lm(opts)
+
+
+def _f4(g, tag):
+    return dict(cams0=g[f"{tag}_cams0"], pts0=g[f"{tag}_pts0"], uv=g[f"{tag}_uv"], ci=g[f"{tag}_ci"], pi=g[f"{tag}_pi"])
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "mid", "sparse"])
+@pytest.mark.parametrize("ftag,ftol", [("loose", 1e-4), ("tight", 1e-8)])
+def test_converged_solve_matches_reference_f64(golden, tag, ftag, ftol):
+    g = golden("f4_solves.npz")
+    p = _f4(g, tag)
+    cams, pts, rep, log = _solve(p, ftol)
+    ref_cost = float(g[f"{tag}_{ftag}_cost"])
+    assert rep.status in (2, 3, 4)
+    # the exact damped solve converges at least as far as the reference's TRF step does at the same ftol
+    assert rep.cost <= ref_cost * (1 + 1e-9)
+    assert abs(rep.cost - ref_cost) <= 1e-5 * ref_cost
+    rms = orc.rms_reprojection(cams, pts, p["uv"], p["ci"], p["pi"])
+    assert abs(rms - float(g[f"{tag}_{ftag}_rms"])) <= 1e-4
+    assert abs(0.5 * np.sum(orc.fun(np.hstack((cams.ravel(), pts.ravel())), cams.shape[0], pts.shape[0], p["ci"], p["pi"],
+                                    p["uv"], 1.0) ** 2) - rep.cost) <= 1e-9 * rep.cost
+    # gauge-free summaries at the tolerance the reference's own loose-vs-tight solves differ by
+    intr, ratios = orc.gauge_invariants(cams)
+    d_ref = np.abs(g[f"{tag}_loose_intr"] - g[f"{tag}_tight_intr"]).max(axis=0)
+    assert np.all(np.abs(intr - g[f"{tag}_tight_intr"]).max(axis=0) <= 20 * d_ref + np.array([0.5, 1e-4, 1e-4, 0.5, 0.5]))
+    assert np.max(np.abs(ratios - g[f"{tag}_tight_centre_ratios"])) <= 1e-3
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "mid"])
+def test_converged_solve_f32(golden, tag):
+    g = golden("f4_solves.npz")
+    p = _f4(g, tag)
+    cams, pts, rep, log = _solve(p, 1e-4, dtype="f32")
+    ref_cost = float(g[f"{tag}_loose_cost"])
+    cost64 = 0.5 * np.sum(orc.fun(np.hstack((cams.ravel(), pts.ravel())), cams.shape[0], pts.shape[0], p["ci"], p["pi"],
+                                  p["uv"], 1.0) ** 2)
+    assert abs(cost64 - ref_cost) <= 1e-4 * ref_cost
+    rms = orc.rms_reprojection(cams, pts, p["uv"], p["ci"], p["pi"])
+    assert abs(rms - float(g[f"{tag}_loose_rms"])) <= 1e-3
+
+
+def test_device_lm_follows_cpu_model_iteration_by_iteration(golden):
+    g = golden("f4_solves.npz")
+    p = _f4(g, "sparse")
+    cams, pts, rep, log = _solve(p, 1e-4)
+    eng = model.ModelEngine(p["cams0"], p["pts0"], p["uv"], p["ci"], p["pi"])
+    out = model.run_lm_single(eng, ftol=1e-4)
+    assert rep.iterations == out["iterations"] and rep.nfev == out["nfev"] and rep.status == out["status"]
+    assert abs(rep.cost - out["cost"]) <= 1e-9 * out["cost"]
+    assert np.max(np.abs(cams - out["cams"])) <= 1e-6 and np.max(np.abs(pts - out["pts"])) <= 1e-6
+
+
+def test_weighted_solve_matches_oracle():
+    rig = make_rig(4, 400, seed=12, visibility=0.8)
+    rng = np.random.default_rng(3)
+    w = rng.uniform(0.5, 2.0, rig["point_ind"].size)
+    res, c_ref, p_ref = orc.bundle_adjust(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"],
+                                          weights=w.reshape(-1, 1), ftol=1e-8)
+    cams, pts, rep, _ = _solve(dict(cams0=rig["cams0"], pts0=rig["pts0"], uv=rig["points_2d"], ci=rig["camera_ind"],
+                                    pi=rig["point_ind"]), 1e-8, weights=w)
+    assert rep.cost <= res.cost * (1 + 1e-9) and abs(rep.cost - res.cost) <= 1e-5 * res.cost
+
+
+# ----------------------------------------------------------------------------- class surface end to end
+def test_pysba_bundleAdjust_surface(golden, capsys):
+    g = golden("f4_solves.npz")
+    p = _f4(g, "cfg1")
+    cams_in, pts_in = p["cams0"].copy(), p["pts0"].copy()
+    sba = PySBA(cams_in, pts_in, p["uv"], p["ci"], p["pi"])
+    res = sba.bundleAdjust(1e-4)
+    out = capsys.readouterr().out
+    assert "Iteration" in out and "`ftol` termination condition is satisfied." in out
+    assert np.array_equal(cams_in, p["cams0"]) and np.array_equal(pts_in, p["pts0"])   # inputs never written (pySBA.py:145-146 rebinds)
+    assert sba.cameraArray is not cams_in and sba.cameraArray.shape == (2, 11) and sba.points3D.shape == (500, 3)
+    assert res.status == 2 and res.success and res.x.shape == (2 * 11 + 500 * 3,)
+    assert abs(res.cost - float(g["cfg1_loose_cost"])) <= 1e-5 * float(g["cfg1_loose_cost"])
+    assert res.fun.shape == (1000 * 2,) and abs(0.5 * res.fun @ res.fun - res.cost) <= 1e-9 * res.cost
+    assert res.jac.shape == (2000, 1522) and res.grad.shape == (1522,)
+    assert abs(np.max(np.abs(res.grad)) - res.optimality) <= 1e-6 * max(1.0, res.optimality)
+    blob = pickle.dumps(sba)                             # calibrate_camera.py:86-88
+    back = pickle.loads(blob)
+    assert type(back).__module__ == "lasercalib.pySBA" and np.array_equal(back.cameraArray, sba.cameraArray)
+    pickle.loads(pickle.dumps(res))
+
+
+def test_nocam_matches_reference(golden):
+    g = golden("f5_variants.npz")
+    sba = PySBA(g["cams0"].copy(), g["pts0"].copy(), g["uv"], g["ci"], g["pi"])
+    res = sba.bundleAdjust_nocam()
+    assert res.x.shape == (g["pts0"].size,)
+    assert res.cost <= float(g["nocam_cost"]) * (1 + 1e-9)
+    assert abs(res.cost - float(g["nocam_cost"])) <= 1e-6 * float(g["nocam_cost"])
+    assert np.max(np.abs(sba.points3D - g["nocam_pts"])) <= 1e-3       # mm; points-only BA has no gauge freedom
+    assert np.array_equal(sba.cameraArray, g["cams0"])
+
+
+def test_nonfinite_start_raises_value_error():
+    rig = make_rig(2, 50, seed=1)
+    cams = rig["cams0"].copy()
+    cams[0, 6] = np.nan
+    sba = PySBA(cams, rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    with pytest.raises(ValueError):                   # scipy: least_squares.py:844-845
+        sba.bundleAdjust(1e-4)
+
+
+def test_bad_indices_rejected():
+    rig = make_rig(2, 50, seed=1)
+    ci = rig["camera_ind"].copy()
+    ci[3] = 7
+    with pytest.raises(_native.SbaError):
+        _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], ci, rig["point_ind"])
+
+
+def test_point_with_single_observation_and_unseen_point():
+    # ragged input: a point seen once (rank-deficient 3x3 block, kept stable by the damping) and a point never seen
+    rig = make_rig(4, 120, seed=6, visibility=0.9)
+    keep = ~((rig["point_ind"] == 5) & (rig["camera_ind"] != 0)) & (rig["point_ind"] != 17)
+    p = dict(cams0=rig["cams0"], pts0=rig["pts0"], uv=rig["points_2d"][keep], ci=rig["camera_ind"][keep], pi=rig["point_ind"][keep])
+    cams, pts, rep, _ = _solve(p, 1e-6)
+    assert rep.status in (2, 3, 4) and np.all(np.isfinite(cams)) and np.all(np.isfinite(pts))
+    assert np.array_equal(pts[17], rig["pts0"][17])     # unseen point: zero gradient, never moves
+    eng = model.ModelEngine(p["cams0"], p["pts0"], p["uv"], p["ci"], p["pi"])
+    out = model.run_lm_single(eng, ftol=1e-6)
+    assert abs(rep.cost - out["cost"]) <= 1e-8 * out["cost"]
+
+
+def test_more_than_16_cameras_uses_camera_groups():
+    rig = make_rig(20, 200, seed=8, visibility=0.7)
+    p = dict(cams0=rig["cams0"], pts0=rig["pts0"], uv=rig["points_2d"], ci=rig["camera_ind"], pi=rig["point_ind"])
+    cams, pts, rep, _ = _solve(p, 1e-6)
+    eng = model.ModelEngine(p["cams0"], p["pts0"], p["uv"], p["ci"], p["pi"])
+    out = model.run_lm_single(eng, ftol=1e-6)
+    assert rep.iterations == out["iterations"]
+    assert abs(rep.cost - out["cost"]) <= 1e-8 * out["cost"]
+
+
+# ----------------------------------------------------------------------------- full size (BASELINE config 3) properties
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_full_size_16x50k_properties(dtype):
+    rig = make_rig(16, 50000, seed=0)
+    p = dict(cams0=rig["cams0"], pts0=rig["pts0"], uv=rig["points_2d"], ci=rig["camera_ind"], pi=rig["point_ind"])
+    with _native.Problem(p["cams0"], p["pts0"], p["uv"], p["ci"], p["pi"], dtype=dtype) as prob:
+        r0, c0 = prob.residual()
+        opts = prob.make_opts(ftol=1e-4)
+        cams, pts, rep, log = prob.solve_lm(opts)
+        r1, c1 = prob.residual(np.hstack((cams.ravel(), pts.ravel())))
+    M = p["ci"].size
+    # sampled check of the residual against the oracle at full size
+    idx = np.random.default_rng(0).choice(M, 5000, replace=False)
+    ref = orc.project(p["pts0"][p["pi"][idx]], p["cams0"][p["ci"][idx]]) - p["uv"][idx]
+    assert np.max(np.abs(r0.reshape(-1, 2)[idx] - ref)) <= (1e-8 if dtype == "f64" else 5e-3)
+    assert rep.status == 2 and rep.cost < 1e-3 * c0
+    costs = [row.cost for row in log if row.accepted]
+    assert all(b <= a for a, b in zip(costs, costs[1:]))        # accepted costs never increase
+    assert abs(c1 - rep.cost) <= (1e-9 if dtype == "f64" else 1e-4) * c1
+    # noise floor: 0.3 px Gaussian noise => RMS reprojection ~ 0.3*sqrt(2)*sqrt(dof ratio)
+    rms = np.sqrt(np.mean(np.sum(r1.reshape(-1, 2) ** 2, axis=1)))
+    assert 0.35 < rms < 0.45
+    # gauge-free recovery of the truth
+    intr, ratios = orc.gauge_invariants(cams)
+    intr_t, ratios_t = orc.gauge_invariants(rig["cams_true"])
+    assert np.max(np.abs(ratios - ratios_t)) <= 1e-3
+    assert np.max(np.abs(intr[:, 0] - intr_t[:, 0])) <= 3.0       # focal length, px
