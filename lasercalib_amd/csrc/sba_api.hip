@@ -285,7 +285,7 @@ struct Engine : EngineBase {
   }
   size_t schur_lds(bool diag) const {
     const size_t panels = (diag ? 1 : 2) * (size_t)SCHUR_K * GROUP_ROWS;
-    return (panels + 2 * GROUP_CAMS * CAMPRE + SCHUR_K) * sizeof(T);
+    return (panels + 2 * GROUP_CAMS * CAMPRE + SCHUR_K + SCHUR_PTS * 8) * sizeof(T);
   }
   void launch_schur() {
     // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(SchurCfg<DIAG>::THREADS) void k_schur(
   T* panelA = reinterpret_cast<T*>(smem);                       // [SCHUR_K][GROUP_ROWS]
   T* panelB = DIAG ? panelA : panelA + SCHUR_K * GROUP_ROWS;
   T* s_cam = panelA + (DIAG ? 1 : 2) * SCHUR_K * GROUP_ROWS;    // [32][CAMPRE] : group A then group B
-  T* s_z = s_cam + 2 * GROUP_CAMS * CAMPRE;                     // [SCHUR_K]
+  T* s_z = s_cam + 2 * GROUP_CAMS * CAMPRE;                     // [SCHUR_K]      z = L^-1 gp per point
+  T* s_li = s_z + SCHUR_K;                                      // [SCHUR_PTS][8] L^-1 (6 values) + valid flag
   for (int i = threadIdx.x; i < nA * CAMPRE; i += THREADS) s_cam[i] = campre[(size_t)camA0 * CAMPRE + i];
   if (!DIAG)
     for (int i = threadIdx.x; i < nB * CAMPRE; i += THREADS)
@@ -435,7 +436,32 @@ __global__ __launch_bounds__(SchurCfg<DIAG>::THREADS) void k_schur(
     const int p1 = min(pend, p0 + SCHUR_PTS);
     __syncthreads();   // previous chunk's MFMA reads are done
     for (int i = threadIdx.x; i < (DIAG ? 1 : 2) * SCHUR_K * GROUP_ROWS; i += THREADS) panelA[i] = (T)0;
-    if (threadIdx.x < SCHUR_K) s_z[threadIdx.x] = (T)0;
+    if (threadIdx.x < SCHUR_PTS) {
+      // one lane per point of the chunk: (V + lam D)^-1 factor, shared by all its observations
+      const int q = threadIdx.x, p = p0 + q;
+      T li[6] = {0, 0, 0, 0, 0, 0};
+      T z0 = 0, z1 = 0, z2 = 0, ok = 0;
+      if (p < p1) {
+        T v6[6];
+        v6[0] = (T)(V[(size_t)p * 6 + 0] + lam * fmax_pos(D2p[(size_t)p * 3 + 0]));
+        v6[1] = (T)V[(size_t)p * 6 + 1];
+        v6[2] = (T)V[(size_t)p * 6 + 2];
+        v6[3] = (T)(V[(size_t)p * 6 + 3] + lam * fmax_pos(D2p[(size_t)p * 3 + 1]));
+        v6[4] = (T)V[(size_t)p * 6 + 4];
+        v6[5] = (T)(V[(size_t)p * 6 + 5] + lam * fmax_pos(D2p[(size_t)p * 3 + 2]));
+        if (chol3_inv<T>(v6, li)) {   // degenerate point: contributes nothing (its step is zeroed in back-substitution too)
+          ok = (T)1;
+          const T g0 = (T)gp[(size_t)p * 3], g1 = (T)gp[(size_t)p * 3 + 1], g2 = (T)gp[(size_t)p * 3 + 2];
+          z0 = li[0] * g0;
+          z1 = li[1] * g0 + li[2] * g1;
+          z2 = li[3] * g0 + li[4] * g1 + li[5] * g2;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s_li[q * 8 + k] = li[k];
+      s_li[q * 8 + 6] = ok;
+      s_z[3 * q + 0] = z0; s_z[3 * q + 1] = z1; s_z[3 * q + 2] = z2;
+    }
     __syncthreads();
     const int o_lo = pt_start[p0], o_hi = pt_start[p1];
     for (int o = o_lo + threadIdx.x; o < o_hi; o += THREADS) {
@@ -446,14 +472,10 @@ __global__ __launch_bounds__(SchurCfg<DIAG>::THREADS) void k_schur(
       int lo = p0, hi = p1;
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pt_start[mid] <= o) lo = mid; else hi = mid; }
       const int p = lo, q = p - p0;
-      T v6[6], li[6];
-      v6[0] = (T)(V[(size_t)p * 6 + 0] + lam * fmax_pos(D2p[(size_t)p * 3 + 0]));
-      v6[1] = (T)V[(size_t)p * 6 + 1];
-      v6[2] = (T)V[(size_t)p * 6 + 2];
-      v6[3] = (T)(V[(size_t)p * 6 + 3] + lam * fmax_pos(D2p[(size_t)p * 3 + 1]));
-      v6[4] = (T)V[(size_t)p * 6 + 4];
-      v6[5] = (T)(V[(size_t)p * 6 + 5] + lam * fmax_pos(D2p[(size_t)p * 3 + 2]));
-      if (!chol3_inv<T>(v6, li)) continue;   // degenerate point: contributes nothing (its step is zeroed in back-substitution too)
+      if (s_li[q * 8 + 6] == (T)0) continue;
+      T li[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) li[k] = s_li[q * 8 + k];
       const auto m = uv[o];
       const T ww = w ? w[o] : (T)1;
       const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
@@ -474,12 +496,6 @@ __global__ __launch_bounds__(SchurCfg<DIAG>::THREADS) void k_schur(
 #pragma unroll
         for (int d = 0; d < 3; ++d)
           pan[(3 * q + d) * GROUP_ROWS + col0 + e] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
-      }
-      if (DIAG && o == pt_start[p]) {   // first observation of the point publishes z = L^-1 gp
-        const T g0 = (T)gp[(size_t)p * 3], g1 = (T)gp[(size_t)p * 3 + 1], g2 = (T)gp[(size_t)p * 3 + 2];
-        s_z[3 * q + 0] = li[0] * g0;
-        s_z[3 * q + 1] = li[1] * g0 + li[2] * g1;
-        s_z[3 * q + 2] = li[3] * g0 + li[4] * g1 + li[5] * g2;
       }
     }
     __syncthreads();
