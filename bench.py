@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- LM-iteration throughput of the MI355X bundle-adjustment engine.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N = 1:  one process, one GPU.   N > 1: launched by torchrun, one rank per GPU, RCCL over xGMI.
+One "step" = one full Levenberg-Marquardt iteration of the hot path on synthetic data already resident
+in HBM: linearize (analytic residual + Jacobian blocks -> normal-equation blocks), Schur complement,
+reduced camera solve, back-substitution, trial residual, accept/reject.  Nothing is skipped: steps
+run with always_relinearize so a rejected step costs the same as an accepted one.
+
+Workload (BASELINE.json configs[2], the config its metric is quoted on): 16 cameras x 50,000 points,
+full visibility => 800,000 observations PER GPU (weak scaling: N GPUs solve one 16 x 50,000*N problem,
+points sharded, cameras replicated, all-reduce of the reduced camera system every step).
+
+Prints ONE JSON line (rank 0).  `value` = observations x LM-iterations per second over the whole job
+(M_total * K / t / 1e6, "Mobs/s"); `lm_iters_per_s` = K / t is reported beside it, as are the
+residual+Jacobian kernel rates.  `roofline` is for the kernel with the largest share of a step;
+`cpu_baseline` times the reference's algorithm (oracle/sba_oracle.py: numpy model + scipy
+least_squares with the reference's exact arguments) on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # f32-in MFMA = vector rate 157.3 TF; f64 MFMA is half that on CDNA4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--cams", type=int, default=16)
+    ap.add_argument("--points", type=int, default=50000, help="points PER GPU")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--cpu-points", type=int, default=5000, help="points of the bounded CPU sample")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_obs(kernel, s, C, N, M):
+    """SURVEY.md section 8(d).  s = sizeof(real); indices are int32 on the device."""
+    if kernel == "resjac":            # materialising: read ci,pi,uv,point ; write r + 28 J values
+        return 8 + 35 * s
+    if kernel == "linearize_points":  # fused: read ci(4) + uv(2s) + point(3s) ; write V(6)+gp(3) doubles per point
+        return 4 + 5 * s + 9 * 8 * N / M
+    if kernel == "linearize_cams":    # camera-major pass: read pi(4) + uv(2s) + point(3s) per observation
+        return 4 + 5 * s
+    if kernel == "backsub":           # read ci(4)+uv(2s)+point(3s) ; per point read V,gp,D2p (12 doubles) + X (3 doubles), write X (3 doubles + 3 s)
+        return 4 + 5 * s + (15 * 8 + 3 * 8 + 3 * s) * N / M
+    if kernel == "residual":
+        return 8 + 5 * s
+    raise KeyError(kernel)
+
+
+def cpu_baseline(C, n_points_sample, ftol=1e-4):
+    """Reference algorithm on the host: scipy TRF + 3-point FD Jacobian through oracle.bundle_adjust.
+
+    Bounded sample: same rig recipe, fewer points (16 x 5,000 = 80k observations takes ~10-20 s here; the
+    full 16 x 50,000 solve takes ~2 min).  LM iterations/s of scipy are nearly
+    inversely proportional to the observation count, so the observation throughput (obs x iters / s) is
+    the size-independent figure to put beside `value`.
+    """
+    from lasercalib_amd.synth import make_rig
+    from oracle import sba_oracle as orc
+    rig = make_rig(C, n_points_sample, seed=0)
+    M = rig["camera_ind"].size
+    t0 = time.perf_counter()
+    res, _, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], ftol=ftol)
+    dt = time.perf_counter() - t0
+    iters = max(1, res.nfev - 1)
+    threads = 1
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([1] + [p.get("num_threads", 1) for p in threadpool_info()])
+    except Exception:
+        pass
+    return {"value": M * iters / dt / 1e6, "unit": "Mobs/s", "cores": 1, "kind": "port",
+            "sample": f"{C} cams x {n_points_sample} points ({M} obs), oracle.bundle_adjust = scipy least_squares(trf, 3-point FD, "
+                      f"x_scale=jac, ftol={ftol}) to convergence: {iters} LM iterations in {dt:.2f} s",
+            "lm_iters_per_s": iters / dt, "seconds": dt, "nfev": int(res.nfev), "njev": int(res.njev),
+            "final_cost": float(res.cost), "host_cpus": os.cpu_count(), "blas_threads": threads,
+            "note": "numpy elementwise + scipy sparse FD/LSMR: effectively one core"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    import torch
+    import torch.distributed as dist
+    from lasercalib_amd import _native
+    from lasercalib_amd import dist as sdist
+    from lasercalib_amd.synth import make_rig
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    C, Np = a.cams, a.points
+    N_total = Np * world
+    rig = make_rig(C, N_total, seed=0)                 # every rank builds the same job, then takes its slice
+    M_total = rig["camera_ind"].size
+    shard = sdist.make_shard(rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], None, world, rank)
+    M_local = shard["ci"].size
+    s = 4 if a.dtype == "f32" else 8
+    stream = torch.cuda.current_stream().cuda_stream
+    prob = _native.Problem(rig["cams0"], shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], dtype=a.dtype,
+                           device=local, stream=stream)
+    x0 = np.hstack((rig["cams0"].ravel(), shard["pts"].ravel()))
+    comm = sdist.TorchComm() if world > 1 else sdist.SoloComm()
+    E = torch.empty(prob.exchange_size(), dtype=torch.float64, device="cuda")
+    sc = torch.empty(sdist.NSCALARS, dtype=torch.float64, device="cuda")
+
+    def run(iters):
+        """`iters` LM iterations from the initial guess; returns (seconds, last log row)."""
+        prob.set_params(x0)
+        opts = prob.make_opts(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=iters, always_relinearize=True, profile=True)
+        barrier()
+        t0 = time.perf_counter()
+        if world == 1:
+            cams, pts, rep, log = prob.solve_lm(opts)
+            costs = [r.cost for r in log]
+        else:
+            prob.lm_begin(opts)
+            costs = []
+            for _ in range(iters):
+                prob.lm_linearize()
+                prob.lm_form_reduced(E.data_ptr())
+                dist.all_reduce(E)
+                prob.lm_solve_trial(E.data_ptr(), sc.data_ptr())
+                sc_all = comm.all_gather_rows(sc)
+                status, acc, row = prob.lm_decide(sc_all.data_ptr(), world)
+                costs.append(row.cost)
+            prob.lm_finish()
+        barrier()
+        return time.perf_counter() - t0, costs
+
+    if a.warmup > 0:
+        run(a.warmup)
+    dt, costs = run(a.steps)
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # kernel durations: LIVE over the timed region (one HIP event pair per kernel class per step on the
+    # engine's stream); residual / resjac are not part of a step and are timed back-to-back afterwards.
+    kt = prob.kernel_profile()
+    kt.update({k: prob.time_kernel(k, 20) for k in ("residual", "resjac")})
+    step_us = dt / a.steps * 1e6
+    out = None
+    if rank == 0:
+        n = 11 * C
+        dominant = max(("schur", "linearize_cams", "linearize_points", "backsub", "cholesky_solve", "schur_reduce"), key=lambda k: kt[k])
+        if dominant in ("cholesky_solve", "schur_reduce"):
+            # latency-bound single-workgroup / reduction stages have no meaningful bandwidth roofline; report the
+            # heaviest streaming or MFMA kernel instead and list these in kernel_us
+            dominant = max(("schur", "linearize_cams", "linearize_points", "backsub"), key=lambda k: kt[k])
+        if dominant == "schur":
+            flops = (n * (n + 1) / 2) * 3 * shard["pts"].shape[0] * 2          # symmetric S: n(n+1)/2 entries x K=3N x 2
+            ach = flops / (kt["schur"] * 1e-6) / 1e12
+            roof = {"kernel": "k_schur", "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[a.dtype],
+                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype], "traffic": None,
+                    "algorithmic_flops_per_launch": flops, "launch_us": kt["schur"]}
+        else:
+            by = algorithmic_bytes_per_obs(dominant, s, C, shard["pts"].shape[0], M_local) * M_local
+            ach = by / (kt[dominant] * 1e-6) / 1e9
+            roof = {"kernel": "k_" + dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": by, "launch_us": kt[dominant]}
+        rj_bytes = algorithmic_bytes_per_obs("resjac", s, C, shard["pts"].shape[0], M_local) * M_local
+        rj = {"kernel": "k_resjac", "bound": "hbm", "achieved": rj_bytes / (kt["resjac"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": rj_bytes / (kt["resjac"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "launch_us": kt["resjac"],
+              "algorithmic_bytes_per_launch": rj_bytes, "mobs_per_s": M_local / kt["resjac"]}
+        out = {
+            "metric": "LM iters/sec and residual+Jacobian Mobs/s at 16 cams x 50k points",
+            "value": M_total * a.steps / dt / 1e6,
+            "unit": "Mobs/s (observations x LM iterations per second, whole job)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{C} cams x {Np} points per GPU, full visibility ({M_local} obs per GPU, {M_total} total), "
+                                   "full on-device Schur-complement LM iteration", "cams": C, "points_per_gpu": Np,
+                       "observations_total": int(M_total), "parallelism": f"points sharded x{world}, cameras replicated"},
+            "lm_iters_per_s": a.steps / dt,
+            "resjac_mobs_per_s": M_local / kt["resjac"],
+            "fused_linearize_mobs_per_s": M_local / (kt["linearize_points"] + kt["linearize_cams"]),
+            "kernel_us": kt, "step_us": step_us,
+            "cost_first_last": [costs[0], costs[-1]] if costs else None,
+            "roofline": roof, "roofline_resjac": rj,
+        }
+        if a.cpu_baseline != "off" and world == 1:
+            cb = cpu_baseline(C, a.cpu_points)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_obs_throughput"] = out["value"] / cb["value"]
+        print(json.dumps(out))
+    prob.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

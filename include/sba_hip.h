@@ -69,7 +69,8 @@ typedef struct {
   int32_t max_iter;           /* <=0: unlimited; bench uses it to run exactly K LM iterations     */
   int32_t always_relinearize; /* bench only: rebuild the normal equations even after a rejection  */
   double  lambda0;            /* <=0: library default                                             */
-  int32_t reserved[4];
+  int32_t reserved[4];        /* reserved[0] != 0: time each kernel class of every iteration with HIP
+                                 events on the solve stream (read back with sba_get_kernel_profile)   */
 } sba_lm_opts;
 
 typedef struct {
@@ -168,6 +169,12 @@ int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_re
  * names: "residual", "resjac" (materialising), "linearize_points", "linearize_cams", "schur",
  *        "backsub".  */
 int sba_time_kernel(sba_handle* h, const char* name, int32_t reps, double* mean_us_out);
+
+/* In-loop timing collected while opts.reserved[0] != 0: total microseconds and launch counts per kernel
+ * class, slots: 0 linearize_points, 1 linearize_cams (+its reduce), 2 schur, 3 schur_reduce+pack,
+ * 4 cholesky_solve, 5 backsub_trial.  Arrays of SBA_PROFILE_SLOTS entries. */
+#define SBA_PROFILE_SLOTS 6
+int sba_get_kernel_profile(sba_handle* h, double* total_us_out, int64_t* count_out);
 
 #ifdef __cplusplus
 }

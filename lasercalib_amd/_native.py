@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "sba_create", "sba_upload", "sba_set_params", "sba_get_params", "sba_destroy",
     "sba_get_gradient", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
-    "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_finish", "sba_time_kernel",
+    "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_finish", "sba_time_kernel", "sba_get_kernel_profile",
 )
 
 
@@ -99,6 +99,7 @@ def load():
                                     C.POINTER(C.c_int32), C.POINTER(LmIterLog)]),
         "sba_lm_finish": (C.c_int, [H, dp, dp, C.POINTER(LmReport)]),
         "sba_time_kernel": (C.c_int, [H, C.c_char_p, C.c_int32, dp]),
+        "sba_get_kernel_profile": (C.c_int, [H, dp, ip]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -257,9 +258,9 @@ class Problem:
     # -- solver
     @staticmethod
     def make_opts(ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=0, mode=MODE_FULL, verbose=0, max_iter=0,
-                  always_relinearize=False, lambda0=0.0):
+                  always_relinearize=False, lambda0=0.0, profile=False):
         return LmOpts(ftol, xtol, gtol, int(max_nfev or 0), mode, verbose, int(max_iter or 0),
-                      1 if always_relinearize else 0, float(lambda0), (C.c_int32 * 4)())
+                      1 if always_relinearize else 0, float(lambda0), (C.c_int32 * 4)(1 if profile else 0, 0, 0, 0))
 
     def solve_lm(self, opts, log_capacity=4096):
         cams = np.empty((self.C, 11))
@@ -302,6 +303,15 @@ class Problem:
         return cams, pts, rep
 
     # -- measurement
+    PROFILE_SLOTS = ("linearize_points", "linearize_cams", "schur", "schur_reduce", "cholesky_solve", "backsub")
+
+    def kernel_profile(self):
+        """Mean in-loop duration (us) per kernel class of the last solve run with profile=True."""
+        tot = np.zeros(len(self.PROFILE_SLOTS))
+        cnt = np.zeros(len(self.PROFILE_SLOTS), dtype=np.int64)
+        _check(self._lib.sba_get_kernel_profile(self._h, _dptr(tot), _iptr(cnt)), self._h)
+        return {k: (tot[i] / cnt[i] if cnt[i] else 0.0) for i, k in enumerate(self.PROFILE_SLOTS)}
+
     def time_kernel(self, name, reps=20):
         us = C.c_double()
         _check(self._lib.sba_time_kernel(self._h, name.encode(), reps, C.byref(us)), self._h)

@@ -92,8 +92,27 @@ struct Engine : EngineBase {
   double initial_cost = 0;
   std::vector<sba_lm_iter_log> log;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // in-loop kernel timing (opts.reserved[0] != 0): one HIP event pair per kernel class per LM iteration
+  enum { KP_LINP = 0, KP_LINC, KP_SCHUR, KP_REDUCE, KP_CHOL, KP_BACKSUB, KP_N };
+  hipEvent_t pev[KP_N][2] = {};
+  bool pev_used[KP_N] = {};
+  bool prof_on = false;
+  double prof_us[KP_N] = {};
+  long long prof_cnt[KP_N] = {};
+  void prof_begin(int k) { if (prof_on) HIPCHK(hipEventRecord(pev[k][0], stream)); }
+  void prof_end(int k) { if (prof_on) { HIPCHK(hipEventRecord(pev[k][1], stream)); pev_used[k] = true; } }
+  void prof_collect() {   // call after a stream sync
+    if (!prof_on) return;
+    for (int k = 0; k < KP_N; ++k)
+      if (pev_used[k]) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pev[k][0], pev[k][1]) == hipSuccess) { prof_us[k] += (double)ms * 1e3; prof_cnt[k]++; }
+        pev_used[k] = false;
+      }
+  }
 
   ~Engine() override {
+    for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) if (pev[k][j]) (void)hipEventDestroy(pev[k][j]);
     if (h_state) (void)hipHostFree(h_state);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -108,6 +127,7 @@ struct Engine : EngineBase {
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(LMState), hipHostMallocDefault));
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
+    for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) HIPCHK(hipEventCreate(&pev[k][j]));
     d_state.alloc(1);
     // kernels whose dynamic LDS can exceed the 64 KB default
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -360,6 +380,8 @@ struct Engine : EngineBase {
     if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
     HIPCHK(hipSetDevice(device));
     opts = *o;
+    prof_on = opts.reserved[0] != 0;
+    for (int k = 0; k < KP_N; ++k) { prof_us[k] = 0; prof_cnt[k] = 0; pev_used[k] = false; }
     if (opts.mode != SBA_MODE_FULL && opts.mode != SBA_MODE_POINTS_ONLY) { err = "unsupported mode"; return SBA_ERR_UNSUPPORTED; }
     // initial cost; scipy raises ValueError when it is not finite (least_squares.py:844-845)
     double c0 = 0;
@@ -393,8 +415,10 @@ struct Engine : EngineBase {
 
   int lm_linearize() {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    prof_begin(KP_LINP);
     launch_linearize_points();
-    if (h_state->free_cams) launch_linearize_cams();
+    prof_end(KP_LINP);
+    if (h_state->free_cams) { prof_begin(KP_LINC); launch_linearize_cams(); prof_end(KP_LINC); }
     need_linearize = false;
     return SBA_OK;
   }
@@ -402,18 +426,23 @@ struct Engine : EngineBase {
   int lm_form_reduced(double* E) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     if (h_state->free_cams) {
+      prof_begin(KP_SCHUR);
       launch_schur();
+      prof_end(KP_SCHUR);
+      prof_begin(KP_REDUCE);
       hipLaunchKernelGGL(k_schur_reduce<T>, dim3(GROUP_TILES * GROUP_TILES, npairs), dim3(256), 0, stream, slabs.p, ksplit,
                          pair_ga.p, pair_gb.p, U.p, C, E);
     }
     hipLaunchKernelGGL(k_pack_exchange, dim3(1), dim3(256), 0, stream, U.p, gc.p, bpart.p, ksplit, cost_part.p, nblk, C,
                        (int)h_state->free_cams, E);
+    if (h_state->free_cams) prof_end(KP_REDUCE);
     return SBA_OK;
   }
 
   int lm_solve_trial(double* E, double* scal) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     if (h_state->free_cams) {
+      prof_begin(KP_CHOL);
       if (n <= CHOL_LDS_MAX_N) {
         const size_t lds = (size_t)n * (n + 1) / 2 * sizeof(double);
         hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, E, C, d_state.p, D2c.p,
@@ -422,10 +451,13 @@ struct Engine : EngineBase {
         hipLaunchKernelGGL((k_cholesky_solve<false, T>), dim3(1), dim3(CHOL_THREADS), 0, stream, E, C, d_state.p, D2c.p,
                            cams[cur].p, delta_c.p, cams[1 - cur].p, campre[1 - cur].p);
       }
+      prof_end(KP_CHOL);
     } else {
       hipLaunchKernelGGL(k_nocam_step, dim3(1), dim3(64), 0, stream, d_state.p, E, n);
     }
+    prof_begin(KP_BACKSUB);
     launch_backsub_trial();
+    prof_end(KP_BACKSUB);
     hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, nblk, d_state.p, scal);
     return SBA_OK;
   }
@@ -436,6 +468,7 @@ struct Engine : EngineBase {
     HIPCHK(hipMemcpyAsync(h_state, d_state.p, sizeof(LMState), hipMemcpyDeviceToHost, stream));
     sync();
     HIPCHK(hipGetLastError());
+    prof_collect();
     const LMState& s = *h_state;
     if (s.accepted) { cur = 1 - cur; need_linearize = true; }
     if (opts.always_relinearize) need_linearize = true;
@@ -765,6 +798,15 @@ int sba_lm_decide(sba_handle* h, const double* scalars_all_dev, int32_t n_ranks,
 int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report) {
   if (!h) return SBA_ERR_INVALID;
   return guarded(h, [&] { return DISPATCH(h, lm_finish(cams_out, points_out, report)); });
+}
+
+int sba_get_kernel_profile(sba_handle* h, double* total_us_out, int64_t* count_out) {
+  if (!h || !total_us_out || !count_out) return SBA_ERR_INVALID;
+  auto get = [&](auto* e) {
+    for (int k = 0; k < SBA_PROFILE_SLOTS; ++k) { total_us_out[k] = e->prof_us[k]; count_out[k] = e->prof_cnt[k]; }
+    return (int)SBA_OK;
+  };
+  return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
 }
 
 int sba_time_kernel(sba_handle* h, const char* name, int32_t reps, double* mean_us_out) {

@@ -1,0 +1,126 @@
+"""CPU: host-side mirror of the reference interface -- constructor semantics, sparsity patterns, parameter
+splitting, pickling under the reference's module path, sharding, Jacobian assembly."""
+import inspect
+import pickle
+
+import numpy as np
+import pytest
+
+from lasercalib_amd import dist as sdist
+from lasercalib_amd.pySBA import PySBA, assemble_jacobian
+from lasercalib_amd.synth import make_rig
+from oracle import lm_schur_model as model
+from oracle import sba_oracle as orc
+
+
+def _sba(rig, **kw):
+    return PySBA(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], **kw)
+
+
+def test_constructor_semantics():
+    rig = make_rig(3, 40, seed=1)
+    sba = _sba(rig)
+    assert sba.cameraArray is rig["cams0"] and sba.points3D is rig["pts0"] and sba.points2D is rig["points_2d"]
+    assert sba.pointWeights.shape == (rig["point_ind"].size, 1) and sba.pointWeights.dtype == rig["point_ind"].dtype
+    assert sba.points3Dfixed is None and sba.points3Dfixed_labeled is None
+    w = np.linspace(0.5, 2, rig["point_ind"].size)
+    assert _sba(rig, pointWeights=w).pointWeights.shape == (w.size, 1)
+
+
+def test_method_surface_matches_reference_signatures():
+    expect = {
+        "__init__": ["self", "cameraArray", "points3D", "points2D", "cameraIndices", "point2DIndices", "points3Dfixed", "pointWeights"],
+        "rotate": ["self", "points", "rot_vecs"],
+        "project": ["self", "points", "cameraArray"],
+        "fun": ["self", "params", "n_cameras", "n_points", "camera_indices", "point_indices", "points_2d", "pointWeights"],
+        "bundle_adjustment_sparsity": ["self", "numCameras", "numPoints", "cameraIndices", "pointIndices"],
+        "optimizedParams": ["self", "params", "n_cameras", "n_points"],
+        "bundleAdjust": ["self", "ftol"],
+        "fun_camonly": ["self", "params", "n_cameras", "n_points", "camera_indices", "point_indices", "points_2d", "pointWeights", "points_3d"],
+        "bundle_adjustment_camonly": ["self", "ftol"],
+        "fun_transform_points_3d": ["self", "params", "numCameras", "n_points", "camera_params", "camera_indices", "point_indices", "points_2d", "pointWeights", "points_3d"],
+        "bundleAdjust_transform_points_3d": ["self", "ftol"],
+        "getResiduals": ["self"],
+        "bundle_adjustment_sparsity_nocam": ["self", "numPoints", "pointIndices"],
+        "fun_nocam": ["self", "params", "camera_params", "n_points", "camera_indices", "point_indices", "points_2d", "pointWeights"],
+        "bundleAdjust_nocam": ["self", "ftol"],
+        "bundle_adjustment_sparsity_sharedcam": ["self", "numCameras", "numPoints", "cameraIndices", "pointIndices"],
+        "fun_sharedcam": ["self", "params", "n_cameras", "n_points", "camera_indices", "point_indices", "points_2d", "pointWeights"],
+        "bundleAdjust_sharedcam": ["self", "ftol"],
+    }
+    defaults = {"bundleAdjust": 1e-4, "bundle_adjustment_camonly": 1e-4, "bundleAdjust_transform_points_3d": 1e-3,
+                "bundleAdjust_nocam": 1e-7, "bundleAdjust_sharedcam": 1e-6}
+    for name, params in expect.items():
+        sig = inspect.signature(getattr(PySBA, name))
+        assert list(sig.parameters) == params, name
+        if name in defaults:
+            assert sig.parameters["ftol"].default == defaults[name]
+
+
+def test_sparsity_patterns_match_oracle():
+    rig = make_rig(3, 50, seed=2, visibility=0.7)
+    sba = _sba(rig)
+    ci, pi = rig["camera_ind"], rig["point_ind"]
+    for mine, ref in ((sba.bundle_adjustment_sparsity(3, 50, ci, pi), orc.sparsity(3, 50, ci, pi)),
+                      (sba.bundle_adjustment_sparsity_nocam(50, pi), orc.sparsity_nocam(50, pi)),
+                      (sba.bundle_adjustment_sparsity_sharedcam(3, 50, ci, pi), orc.sparsity_sharedcam(3, 50, ci, pi))):
+        assert type(mine).__name__ == "lil_matrix" and mine.dtype == ref.dtype and mine.shape == ref.shape
+        assert (mine.tocsr() != ref.tocsr()).nnz == 0
+
+
+def test_optimized_params_views():
+    rig = make_rig(2, 10)
+    x = np.arange(2 * 11 + 30, dtype=float)
+    c, p = _sba(rig).optimizedParams(x, 2, 10)
+    assert c.shape == (2, 11) and p.shape == (10, 3) and c.base is x and p.base is x
+
+
+def test_pickle_under_reference_module_path():
+    import lasercalib.pySBA as shim
+    assert shim.PySBA is PySBA and PySBA.__module__ == "lasercalib.pySBA"
+    rig = make_rig(2, 10)
+    back = pickle.loads(pickle.dumps(_sba(rig)))
+    assert isinstance(back, PySBA) and np.array_equal(back.points2D, rig["points_2d"])
+    assert set(vars(back)) == {"cameraArray", "points3D", "points2D", "cameraIndices", "point2DIndices", "points3Dfixed",
+                               "pointWeights", "points3Dfixed_labeled"}
+
+
+def test_assemble_jacobian_layout():
+    rig = make_rig(3, 30, seed=3, visibility=0.8)
+    res, Jc, Jp = model.residual_jacobian(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], 1.0)
+    J = assemble_jacobian(Jc, Jp, rig["camera_ind"], rig["point_ind"], 3, 30)
+    Jm = model.jacobian_csr(Jc, Jp, rig["camera_ind"], rig["point_ind"], 3, 30)
+    assert abs(J - Jm).max() == 0
+    Jpo = assemble_jacobian(Jc, Jp, rig["camera_ind"], rig["point_ind"], 3, 30, points_only=True)
+    assert abs(Jpo - Jm[:, 33:]).max() == 0
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
+def test_shard_bounds_balance_and_cover(n_ranks):
+    rig = make_rig(6, 500, seed=4, visibility=0.5)
+    pi = rig["point_ind"]
+    counts = np.bincount(pi, minlength=500)
+    pt_start = np.concatenate([[0], np.cumsum(counts)])
+    b = sdist.shard_bounds(pt_start, n_ranks)
+    assert b[0] == 0 and b[-1] == 500 and np.all(np.diff(b) >= 0)
+    per = np.diff(pt_start[b])
+    assert per.sum() == pi.size and per.max() - per.min() <= 2 * counts.max()
+    seen = np.zeros(pi.size, dtype=int)
+    for r in range(n_ranks):
+        sh = sdist.make_shard(rig["pts0"], rig["points_2d"], rig["camera_ind"], pi, None, n_ranks, r)
+        seen[sh["obs_index"]] += 1
+        assert np.array_equal(sh["pi_local"] + sh["p0"], pi[sh["obs_index"]])
+        assert sh["pi_local"].min(initial=0) >= 0 and (sh["pi_local"].max(initial=-1) < sh["pts"].shape[0])
+    assert np.all(seen == 1)
+
+
+def test_shard_handles_unsorted_observations():
+    rig = make_rig(4, 100, seed=5)
+    perm = np.random.default_rng(0).permutation(rig["point_ind"].size)
+    pi, ci, uv = rig["point_ind"][perm], rig["camera_ind"][perm], rig["points_2d"][perm]
+    got = np.zeros(pi.size, dtype=int)
+    for r in range(2):
+        sh = sdist.make_shard(rig["pts0"], uv, ci, pi, None, 2, r)
+        got[sh["obs_index"]] += 1
+        assert np.array_equal(sh["uv"], uv[sh["obs_index"]])
+    assert np.all(got == 1)
