@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "sba_lm_kernels.hpp"
+#include "sba_chol_blocked.hpp"
 
 using namespace sba;
 
@@ -88,6 +89,9 @@ struct Engine : EngineBase {
   LMState* h_state = nullptr;         // pinned
   sba_lm_opts opts{};
   bool lm_active = false;
+  bool chol_old = false;
+  bool chol_debug = false;
+  DevBuf<long long> chol_dbg;
   bool need_linearize = true;
   double initial_cost = 0;
   std::vector<sba_lm_iter_log> log;
@@ -134,6 +138,9 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    if (const char* e = getenv("SBA_CHOL")) chol_old = (std::string(e) == "old");
+    if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residual<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -245,7 +252,7 @@ struct Engine : EngineBase {
       ptsT[b].alloc((size_t)N * 3); campre[b].alloc((size_t)C * CAMPRE);
     }
     V.alloc((size_t)N * 6); gp.alloc((size_t)N * 3); D2p.alloc((size_t)N * 3); D2c.alloc(n);
-    U.alloc((size_t)C * 121); gc.alloc(n); Upart.alloc((size_t)std::max(1, nchunk) * 4 * 256);
+    U.alloc((size_t)C * 121); gc.alloc(n); Upart.alloc((size_t)std::max(1, nchunk) * 256);
     bpart.alloc((size_t)ngroups * ksplit * GROUP_ROWS);
     slabs.alloc((size_t)npairs * ksplit * GROUP_TILES * GROUP_TILES * 256);
     E_own.alloc((size_t)n * n + 3 * n + 1); scal_own.alloc(NSCAL); delta_c.alloc(n);
@@ -301,7 +308,7 @@ struct Engine : EngineBase {
     if (nchunk == 0) return;
     hipLaunchKernelGGL(k_linearize_cams<T>, dim3(nchunk), dim3(256), 0, stream, campre[cur].p, ptsT[cur].p, uv_cm.p,
                        has_w ? w_cm.p : nullptr, pi_cm.p, chunk_cam.p, chunk_begin.p, chunk_end.p, Upart.p);
-    hipLaunchKernelGGL(k_reduce_cams, dim3(C), dim3(256), 0, stream, Upart.p, cam_chunk_start.p, U.p, gc.p);
+    hipLaunchKernelGGL(k_reduce_cams, dim3(C), dim3(1024), 0, stream, Upart.p, cam_chunk_start.p, U.p, gc.p);
   }
   size_t schur_lds(bool diag) const {
     const size_t panels = (diag ? 1 : 2) * (size_t)SCHUR_K * GROUP_ROWS;
@@ -429,13 +436,15 @@ struct Engine : EngineBase {
       prof_begin(KP_SCHUR);
       launch_schur();
       prof_end(KP_SCHUR);
-      prof_begin(KP_REDUCE);
-      hipLaunchKernelGGL(k_schur_reduce<T>, dim3(GROUP_TILES * GROUP_TILES, npairs), dim3(256), 0, stream, slabs.p, ksplit,
-                         pair_ga.p, pair_gb.p, U.p, C, E);
     }
-    hipLaunchKernelGGL(k_pack_exchange, dim3(1), dim3(256), 0, stream, U.p, gc.p, bpart.p, ksplit, cost_part.p, nblk, C,
-                       (int)h_state->free_cams, E);
-    if (h_state->free_cams) prof_end(KP_REDUCE);
+    prof_begin(KP_REDUCE);
+    {
+      const int fc = (int)h_state->free_cams;
+      const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 63) / 64 : 0) + 1;
+      hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(256), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
+                         pair_gb.p, npairs, U.p, gc.p, cost_part.p, nblk, C, fc, E);
+    }
+    prof_end(KP_REDUCE);
     return SBA_OK;
   }
 
@@ -443,7 +452,23 @@ struct Engine : EngineBase {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     if (h_state->free_cams) {
       prof_begin(KP_CHOL);
-      if (n <= CHOL_LDS_MAX_N) {
+      if (n <= CHOL_LDS_MAX_N && !chol_old) {
+        const int nb = (n + CB - 1) / CB;
+        const size_t lds = ((size_t)(nb * (nb + 1) / 2 + 2) * CBS + 3 * (size_t)nb * CB) * sizeof(double);
+        if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }
+        hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_THREADS), lds, stream, E, C, d_state.p, D2c.p,
+                           cams[cur].p, delta_c.p, cams[1 - cur].p, campre[1 - cur].p, chol_debug ? chol_dbg.p : nullptr);
+        if (chol_debug) {
+          std::vector<long long> st(64);
+          HIPCHK(hipMemcpyAsync(st.data(), chol_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+          sync();
+          const int nb = (n + CB - 1) / CB;
+          fprintf(stderr, "[chol stamps, cycles] load %lld  chol0 %lld |", st[1] - st[0], st[2] - st[1]);
+          for (int j = 0; j < nb; ++j) fprintf(stderr, " B%d %lld C%d %lld |", j, st[3 + 2 * j] - st[2 + 2 * j], j, st[4 + 2 * j] - st[3 + 2 * j]);
+          fprintf(stderr, " backsub %lld  epilogue %lld  total %lld\n", st[3 + 2 * nb] - st[2 + 2 * nb], st[4 + 2 * nb] - st[3 + 2 * nb], st[4 + 2 * nb] - st[0]);
+          chol_debug = false;
+        }
+      } else if (n <= CHOL_LDS_MAX_N) {
         const size_t lds = (size_t)n * (n + 1) / 2 * sizeof(double);
         hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, E, C, d_state.p, D2c.p,
                            cams[cur].p, delta_c.p, cams[1 - cur].p, campre[1 - cur].p);

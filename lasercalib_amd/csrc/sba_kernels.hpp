@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_linearize_cams(
     const typename Vec2<T>::type* __restrict__ uv_cm, const T* __restrict__ w_cm,
     const int32_t* __restrict__ pi_cm, const int32_t* __restrict__ chunk_cam,
     const int32_t* __restrict__ chunk_begin, const int32_t* __restrict__ chunk_end,
-    double* __restrict__ Upart /* [n_chunks*4][256] */) {
+    double* __restrict__ Upart /* [n_chunks][256] */) {
   constexpr int LD = 130;                       // [16 params][128 rows + 2]: conflict-free lane writes and MFMA reads
   __shared__ T s_tile[4][16 * LD];
   __shared__ T s_cam[CAMPRE];
@@ -352,22 +352,37 @@ __global__ __launch_bounds__(256) void k_linearize_cams(
     }
     __builtin_amdgcn_wave_barrier();
   }
-  double* dst = Upart + ((size_t)chunk * 4 + wid) * 256;
+  // fold the four waves' 16x16 partials through LDS (fixed order => deterministic), one partial per chunk
+  __syncthreads();
+  double* s_acc = reinterpret_cast<double*>(&s_tile[0][0]);      // reuse the tile storage: [4][256] doubles
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) dst[M_::row_of(lane, rg) * 16 + (lane & 15)] = (double)acc[rg];
+  for (int rg = 0; rg < 4; ++rg) s_acc[wid * 256 + M_::row_of(lane, rg) * 16 + (lane & 15)] = (double)acc[rg];
+  __syncthreads();
+  Upart[(size_t)chunk * 256 + threadIdx.x] =
+      (s_acc[threadIdx.x] + s_acc[256 + threadIdx.x]) + (s_acc[512 + threadIdx.x] + s_acc[768 + threadIdx.x]);
 }
 
-// Sum the per-wave 16x16 partials of each camera: U (C x 121), gc (C x 11).  grid = C, block = 256.
-__global__ void k_reduce_cams(const double* __restrict__ Upart, const int32_t* __restrict__ cam_chunk_start /*C+1*/,
-                              double* __restrict__ U, double* __restrict__ gc) {
+// Sum the per-chunk 16x16 partials of each camera: U (C x 121), gc (C x 11).  grid = C, block = 1024
+// (4 groups x 256 entries; group g takes chunks g, g+4, ... ; groups are folded through LDS in a fixed order).
+__global__ __launch_bounds__(1024) void k_reduce_cams(const double* __restrict__ Upart,
+                                                      const int32_t* __restrict__ cam_chunk_start /*C+1*/,
+                                                      double* __restrict__ U, double* __restrict__ gc) {
+  __shared__ double s_p[4][256];
   const int c = blockIdx.x;
-  const int e = threadIdx.x;              // entry of the 16x16
-  const int a = cam_chunk_start[c] * 4, b = cam_chunk_start[c + 1] * 4;
-  double s = 0;
-  for (int k = a; k < b; ++k) s += Upart[(size_t)k * 256 + e];
-  const int i = e >> 4, j = e & 15;
-  if (i < NCP && j < NCP) U[(size_t)c * 121 + i * NCP + j] = s;
-  if (i < NCP && j == NCP) gc[(size_t)c * NCP + i] = s;
+  const int e = threadIdx.x & 255, g = threadIdx.x >> 8;
+  const int a = cam_chunk_start[c], b = cam_chunk_start[c + 1];
+  double s0 = 0, s1 = 0;
+  int k = a + g;
+  for (; k + 4 < b; k += 8) { s0 += Upart[(size_t)k * 256 + e]; s1 += Upart[(size_t)(k + 4) * 256 + e]; }
+  if (k < b) s0 += Upart[(size_t)k * 256 + e];
+  s_p[g][e] = s0 + s1;
+  __syncthreads();
+  if (g == 0) {
+    const double s = (s_p[0][e] + s_p[1][e]) + (s_p[2][e] + s_p[3][e]);
+    const int i = e >> 4, j = e & 15;
+    if (i < NCP && j < NCP) U[(size_t)c * 121 + i * NCP + j] = s;
+    if (i < NCP && j == NCP) gc[(size_t)c * NCP + i] = s;
+  }
 }
 
 // ------------------------------------------------------------------ K4: Schur complement partials (MFMA)

@@ -29,55 +29,89 @@ constexpr int CHOL_THREADS = 1024;
 constexpr int CHOL_LDS_MAX_N = 176;    // packed lower triangle of 176x176 doubles = 124.6 KB of the 160 KB LDS
 
 // ------------------------------------------------------------------ reduced system assembly
-// S(i,j) = [same camera] U(i,j) - sum_ks slab ; written symmetric into E.  grid = (ntile_max, n_pairs), block 256.
+// One launch builds the whole exchange buffer E = [S | rhs | diagU | gc | cost]:
+//   blocks [0, 4*NT*npairs):   S(i,j) = [same camera] U(i,j) - sum_ks slab      (NT = 121 tile slots per pair)
+//       block = (pair, tile, quarter of the tile's 256 entries); 256 threads = 4 k-split groups x 64 entries,
+//       group g sums slabs g, g+4, ...; the groups are folded through LDS in a fixed order (deterministic).
+//   blocks [.., +nrow_blocks): rhs = -gc + sum_ks bpart ; diagU ; gc           (64 rows x 4 k-split groups)
+//   last block:                cost = sum cost_part
 template <typename T>
-__global__ void k_schur_reduce(const T* __restrict__ slabs, int ksplit, const int32_t* __restrict__ pair_ga,
-                               const int32_t* __restrict__ pair_gb, const double* __restrict__ U, int C,
-                               double* __restrict__ E) {
+__global__ __launch_bounds__(256) void k_build_exchange(
+    const T* __restrict__ slabs, const double* __restrict__ bpart, int ksplit, const int32_t* __restrict__ pair_ga,
+    const int32_t* __restrict__ pair_gb, int npairs, const double* __restrict__ U, const double* __restrict__ gc,
+    const double* __restrict__ cost_part, int n_cost_part, int C, int free_cams, double* __restrict__ E) {
   using M_ = Mfma<T>;
-  const int ga = pair_ga[blockIdx.y], gb = pair_gb[blockIdx.y];
-  const bool diag = (ga == gb);
-  const int ntile = diag ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : GROUP_TILES * GROUP_TILES;
-  const int t = blockIdx.x;
-  if (t >= ntile) return;
-  int R = 0, Tc = 0;
-  if (diag) { int rem = t; while (rem >= GROUP_TILES - R) { rem -= GROUP_TILES - R; ++R; } Tc = R + rem; }
-  else { R = t / GROUP_TILES; Tc = t - R * GROUP_TILES; }
-  const int rg = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t stride = (size_t)(GROUP_TILES * GROUP_TILES) * 256;
-  const T* src = slabs + (size_t)blockIdx.y * ksplit * stride + (size_t)t * 256 + threadIdx.x;
-  double s = 0;
-  for (int k = 0; k < ksplit; ++k) s += (double)src[(size_t)k * stride];
-  const int n = C * NCP;
-  const int i = ga * GROUP_ROWS + 16 * R + M_::row_of(lane, rg);
-  const int j = gb * GROUP_ROWS + 16 * Tc + (lane & 15);
-  if (i >= n || j >= n) return;
-  const int ci_ = i / NCP, cj_ = j / NCP;
-  double v = -s;
-  if (ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
-  E[(size_t)i * n + j] = v;
-  if (!(diag && R == Tc)) E[(size_t)j * n + i] = v;
-}
-
-// rhs = -gc + sum_ks bpart ; diagU ; gc ; cost = sum cost_part.   one block of 256 threads.
-__global__ void k_pack_exchange(const double* __restrict__ U, const double* __restrict__ gc,
-                                const double* __restrict__ bpart, int ksplit, const double* __restrict__ cost_part,
-                                int n_cost_part, int C, int free_cams, double* __restrict__ E) {
+  __shared__ double s_p[4][64];
   __shared__ double scr[4];
+  constexpr int NT = GROUP_TILES * GROUP_TILES;
   const int n = C * NCP;
+  const int tile_blocks = free_cams ? 4 * NT * npairs : 0;
+  const int row_blocks = free_cams ? (n + 63) / 64 : 0;
+  const int g = threadIdx.x >> 6, l64 = threadIdx.x & 63;
+  int bid = blockIdx.x;
+  if (bid < tile_blocks) {
+    const int pair = bid / (4 * NT);
+    const int rem = bid - pair * 4 * NT;
+    const int t = rem >> 2, quarter = rem & 3;
+    const int ga = pair_ga[pair], gb = pair_gb[pair];
+    const bool diag = (ga == gb);
+    const int ntile = diag ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : NT;
+    if (t >= ntile) return;
+    int R, Tc;
+    schur_tile_rc(diag, t, R, Tc);
+    const int e = quarter * 64 + l64;                 // entry of the tile's register dump: reg = e>>6, lane = e&63
+    const int rg = e >> 6, lane = e & 63;
+    const int i = ga * GROUP_ROWS + 16 * R + M_::row_of(lane, rg);
+    const int j = gb * GROUP_ROWS + 16 * Tc + (lane & 15);
+    const size_t stride = (size_t)NT * 256;
+    const T* src = slabs + (size_t)pair * ksplit * stride + (size_t)t * 256 + e;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int k = g;
+    for (; k + 12 < ksplit; k += 16) {
+      s0 += (double)src[(size_t)k * stride];
+      s1 += (double)src[(size_t)(k + 4) * stride];
+      s2 += (double)src[(size_t)(k + 8) * stride];
+      s3 += (double)src[(size_t)(k + 12) * stride];
+    }
+    for (; k < ksplit; k += 4) s0 += (double)src[(size_t)k * stride];
+    s_p[g][l64] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < n && j < n) {
+      const double s = (s_p[0][l64] + s_p[1][l64]) + (s_p[2][l64] + s_p[3][l64]);
+      const int ci_ = i / NCP, cj_ = j / NCP;
+      double v = -s;
+      if (ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
+      E[(size_t)i * n + j] = v;
+      if (!(diag && R == Tc)) E[(size_t)j * n + i] = v;
+    }
+    return;
+  }
+  bid -= tile_blocks;
   double* rhs = E + (size_t)n * n;
   double* dU = rhs + n;
-  double* g = dU + n;
-  if (free_cams) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  double* gv = dU + n;
+  if (bid < row_blocks) {
+    const int i = bid * 64 + l64;
+    double b = 0;
+    if (i < n) {
       const int grp = i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;
-      double b = 0;
-      for (int k = 0; k < ksplit; ++k) b += bpart[((size_t)grp * ksplit + k) * GROUP_ROWS + rho];
-      const int c = i / NCP, e = i - c * NCP;
-      rhs[i] = -gc[i] + b;
-      dU[i] = U[(size_t)c * 121 + e * NCP + e];
-      g[i] = gc[i];
+      const double* src = bpart + (size_t)grp * ksplit * GROUP_ROWS + rho;
+      double b0 = 0, b1 = 0;
+      int k = g;
+      for (; k + 4 < ksplit; k += 8) { b0 += src[(size_t)k * GROUP_ROWS]; b1 += src[(size_t)(k + 4) * GROUP_ROWS]; }
+      if (k < ksplit) b0 += src[(size_t)k * GROUP_ROWS];
+      b = b0 + b1;
     }
+    s_p[g][l64] = b;
+    __syncthreads();
+    if (g == 0 && i < n) {
+      const double bs = (s_p[0][l64] + s_p[1][l64]) + (s_p[2][l64] + s_p[3][l64]);
+      const int c = i / NCP, e = i - c * NCP;
+      rhs[i] = -gc[i] + bs;
+      dU[i] = U[(size_t)c * 121 + e * NCP + e];
+      gv[i] = gc[i];
+    }
+    return;
   }
   double s = 0;
   for (int i = threadIdx.x; i < n_cost_part; i += blockDim.x) s += cost_part[i];
