@@ -67,6 +67,7 @@ struct Engine : EngineBase {
   bool uploaded = false;
   bool has_w = false;
   bool identity_perm = true;
+  bool dense = false;                // every point is observed by every camera exactly once
   std::vector<int64_t> perm;          // pm position -> caller's observation index
   int nblk = 0, nchunk = 0, ngroups = 0, npairs = 0, ksplit = 1;
   int n = 0;                          // 11*C
@@ -82,7 +83,7 @@ struct Engine : EngineBase {
   int cur = 0;
   // linearization + LM work space
   DevBuf<double> V, gp, D2p, D2c, U, gc, Upart, bpart, E_own, scal_own, delta_c, cost_part, gmax_part, trial_part;
-  DevBuf<T> slabs;
+  DevBuf<T> slabs, pfac;
   DevBuf<T2> r_pm;
   DevBuf<T> Jc_pm, Jp_pm;
   DevBuf<LMState> d_state;
@@ -91,6 +92,8 @@ struct Engine : EngineBase {
   bool lm_active = false;
   bool chol_old = false;
   bool chol_debug = false;
+  bool schur_debug = false;
+  DevBuf<long long> schur_dbg;
   DevBuf<long long> chol_dbg;
   bool need_linearize = true;
   double initial_cost = 0;
@@ -134,13 +137,14 @@ struct Engine : EngineBase {
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) HIPCHK(hipEventCreate(&pev[k][j]));
     d_state.alloc(1);
     // kernels whose dynamic LDS can exceed the 64 KB default
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     if (const char* e = getenv("SBA_CHOL")) chol_old = (std::string(e) == "old");
     if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
+    if (getenv("SBA_SCHUR_DEBUG")) { schur_debug = true; schur_dbg.alloc(64); schur_dbg.zero(stream); }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residual<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -168,6 +172,7 @@ struct Engine : EngineBase {
     for (int64_t i = 0; i < M; ++i) ptstart[pi_h[i] + 1]++;
     int maxdeg = 0;
     for (int p = 0; p < N; ++p) { maxdeg = std::max(maxdeg, ptstart[p + 1]); ptstart[p + 1] += ptstart[p]; }
+    dense = (M == (int64_t)N * C);
     if (maxdeg > PM_BLOCK) { err = "a point has more than 256 observations"; return SBA_ERR_UNSUPPORTED; }
     perm.resize(M);
     identity_perm = sorted;
@@ -251,6 +256,7 @@ struct Engine : EngineBase {
       cams[b].alloc((size_t)C * NCP); pts[b].alloc((size_t)N * 3);
       ptsT[b].alloc((size_t)N * 3); campre[b].alloc((size_t)C * CAMPRE);
     }
+    pfac.alloc((size_t)std::max(N, 1) * PF);
     V.alloc((size_t)N * 6); gp.alloc((size_t)N * 3); D2p.alloc((size_t)N * 3); D2c.alloc(n);
     U.alloc((size_t)C * 121); gc.alloc(n); Upart.alloc((size_t)std::max(1, nchunk) * 256);
     bpart.alloc((size_t)ngroups * ksplit * GROUP_ROWS);
@@ -301,7 +307,7 @@ struct Engine : EngineBase {
     if (nblk == 0) return;
     const size_t lds = (size_t)PM_BLOCK * 9 * sizeof(double) + lds_cams();
     hipLaunchKernelGGL(k_linearize_points<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, campre[cur].p, C, ptsT[cur].p,
-                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pt_start.p, blk_pt.p, V.p, gp.p, D2p.p,
+                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_pt.p, V.p, gp.p, D2p.p,
                        cost_part.p, gmax_part.p);
   }
   void launch_linearize_cams() {
@@ -310,26 +316,36 @@ struct Engine : EngineBase {
                        has_w ? w_cm.p : nullptr, pi_cm.p, chunk_cam.p, chunk_begin.p, chunk_end.p, Upart.p);
     hipLaunchKernelGGL(k_reduce_cams, dim3(C), dim3(1024), 0, stream, Upart.p, cam_chunk_start.p, U.p, gc.p);
   }
-  size_t schur_lds(bool diag) const {
-    const size_t panels = (diag ? 1 : 2) * (size_t)SCHUR_K * GROUP_ROWS;
-    return (panels + 2 * GROUP_CAMS * CAMPRE + SCHUR_K + SCHUR_PTS * 8) * sizeof(T);
-  }
   void launch_schur() {
+    if (N > 0)
+      hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, &d_state.p->lam, N, pfac.p);
     // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
-    hipLaunchKernelGGL((k_schur<T, true>), dim3(ksplit, ngroups), dim3(SchurCfg<true>::THREADS), schur_lds(true), stream,
-                       campre[cur].p, C, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pt_start.p, N, V.p, gp.p,
-                       D2p.p, &d_state.p->lam, pair_ga.p, pair_gb.p, 0, ksplit, slabs.p, bpart.p);
+    using CfgD = SchurCfg<T, true>;
+    using CfgO = SchurCfg<T, false>;
+    hipLaunchKernelGGL((k_schur<T, true>), dim3(ksplit, ngroups), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
+                       stream, campre[cur].p, C, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
+                       pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,
+                       schur_debug ? schur_dbg.p : nullptr);
+    if (schur_debug) {
+      std::vector<long long> st(64);
+      HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+      sync();
+      fprintf(stderr, "[schur stamps, cycles since first barrier; per chunk: producer-done consumer-done barrier-out]\n");
+      for (int i = 0; i < 14; ++i)
+        fprintf(stderr, "  it %2d: P %7lld  C %7lld  out %7lld\n", i, st[3 * i] - st[2], st[3 * i + 1] - st[2], st[3 * i + 2] - st[2]);
+      schur_debug = false;
+    }
     if (npairs > ngroups)
-      hipLaunchKernelGGL((k_schur<T, false>), dim3(ksplit, npairs - ngroups), dim3(SchurCfg<false>::THREADS),
-                         schur_lds(false), stream, campre[cur].p, C, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr,
-                         ci_pm.p, pt_start.p, N, V.p, gp.p, D2p.p, &d_state.p->lam, pair_ga.p, pair_gb.p, ngroups, ksplit,
-                         slabs.p, bpart.p);
+      hipLaunchKernelGGL((k_schur<T, false>), dim3(ksplit, npairs - ngroups), dim3(CfgO::THREADS),
+                         CfgO::LDS_BYTES, stream, campre[cur].p, C, ptsT[cur].p, uv_pm.p,
+                         has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
+                         pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
   }
   void launch_backsub_trial() {
     if (nblk == 0) return;
     const size_t lds = (size_t)PM_BLOCK * 6 * sizeof(double) + (2 * (size_t)C * CAMPRE + (size_t)C * NCP) * sizeof(T);
     hipLaunchKernelGGL(k_backsub_trial<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, campre[cur].p, campre[1 - cur].p, C,
-                       pts[cur].p, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pt_start.p, blk_pt.p,
+                       pts[cur].p, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_pt.p,
                        V.p, gp.p, D2p.p, delta_c.p, d_state.p, pts[1 - cur].p, ptsT[1 - cur].p, trial_part.p, nblk);
   }
 

@@ -22,7 +22,6 @@ namespace sba {
 constexpr int PM_BLOCK = 256;      // threads (= max observations) of a point-major workgroup
 constexpr int CM_WAVE_OBS = 64;    // observations a wave turns into one 128-row MFMA tile
 constexpr int CM_CHUNK = 1024;     // observations per camera-major workgroup (256 threads x 4)
-constexpr int SCHUR_THREADS = 512; // 8 waves
 constexpr int SCHUR_PTS = 16;      // points per panel chunk  (K = 48 panel rows)
 constexpr int SCHUR_K = 3 * SCHUR_PTS;
 constexpr int GROUP_CAMS = 16;     // cameras per Schur camera group: 16*11 = 176 = 11 MFMA tiles exactly
@@ -219,7 +218,7 @@ template <typename T>
 __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points(
     const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
-    const int32_t* __restrict__ ci, const int32_t* __restrict__ pt_start,
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start,
     const int32_t* __restrict__ blk_pt, double* __restrict__ V, double* __restrict__ gp,
     double* __restrict__ D2p, double* __restrict__ cost_part, double* __restrict__ gmax_part) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -235,10 +234,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points(
   double sq = 0;
   if ((int)threadIdx.x < nobs) {
     const int o = o_lo + threadIdx.x;
-    // binary search of the owning point inside [p_lo, p_hi)
-    int lo = p_lo, hi = p_hi;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pt_start[mid] <= o) lo = mid; else hi = mid; }
-    const int p = lo;
+    const int p = pi[o];
     const int c = ci[o];
     const auto m = uv[o];
     const T ww = w ? w[o] : (T)1;
@@ -385,21 +381,63 @@ __global__ __launch_bounds__(1024) void k_reduce_cams(const double* __restrict__
   }
 }
 
+// ------------------------------------------------------------------ per-point damped factor (once per LM trial)
+// pf[p] = { L^-1 (6: l00 l10 l11 l20 l21 l22) of V_p + lam*D_p, z = L^-1 g_p (3), ok, 0, 0 }  in T, 12 values per point.
+// Evaluated in double, stored narrowed: the Schur producers (one lane per observation) then read 12 T per lane
+// instead of 12 doubles and run no sqrt/divide of their own.
+constexpr int PF = 12;
+template <typename T>
+__global__ void k_point_factor(const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
+                               const double* __restrict__ lam_ptr, int N, T* __restrict__ pf) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const double lam = *lam_ptr;
+  double v6[6], li[6];
+  v6[0] = V[(size_t)p * 6 + 0] + lam * fmax_pos(D2p[(size_t)p * 3 + 0]);
+  v6[1] = V[(size_t)p * 6 + 1];
+  v6[2] = V[(size_t)p * 6 + 2];
+  v6[3] = V[(size_t)p * 6 + 3] + lam * fmax_pos(D2p[(size_t)p * 3 + 1]);
+  v6[4] = V[(size_t)p * 6 + 4];
+  v6[5] = V[(size_t)p * 6 + 5] + lam * fmax_pos(D2p[(size_t)p * 3 + 2]);
+  T* o = pf + (size_t)p * PF;
+  if (!chol3_inv<double>(v6, li)) {      // degenerate point: contributes nothing (its step is zeroed in back-substitution too)
+#pragma unroll
+    for (int k = 0; k < PF; ++k) o[k] = (T)0;
+    return;
+  }
+  const double g0 = gp[(size_t)p * 3], g1 = gp[(size_t)p * 3 + 1], g2 = gp[(size_t)p * 3 + 2];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o[k] = (T)li[k];
+  o[6] = (T)(li[0] * g0);
+  o[7] = (T)(li[1] * g0 + li[2] * g1);
+  o[8] = (T)(li[3] * g0 + li[4] * g1 + li[5] * g2);
+  o[9] = (T)1; o[10] = (T)0; o[11] = (T)0;
+}
+
 // ------------------------------------------------------------------ K4: Schur complement partials (MFMA)
-// Pair (ga, gb), ga <= gb, of camera groups (16 cameras = 176 rows each).  Each workgroup walks its
-// slice of the point list in chunks of SCHUR_PTS points: lanes (one per observation) write
-// Ytilde_i = W_i L^-T (11x3) into the [K=48][176] LDS panel(s) of their camera group, then the waves
-// accumulate panel products into their 16x16 output tiles with 16x16x4 MFMAs.  Partials go to slabs;
-// k_schur_reduce sums them in a fixed order (deterministic, no atomics).
-//   DIAG  (ga == gb): one panel, 66 upper-triangular tiles over 8 waves  (grid = (ksplit, ngroups))
-//   !DIAG (ga <  gb): two panels, 121 tiles over 16 waves                (grid = (ksplit, npairs - ngroups))
+// Pair (ga, gb), ga <= gb, of camera groups (16 cameras = 176 rows each).  Each workgroup walks its slice of
+// the point list in chunks of PTS points and is split into two roles that overlap through a double-buffered
+// LDS panel (one workgroup barrier per chunk):
+//   producer waves (lane = observation): residual/Jacobian blocks -> Ytilde_i = W_i L^-T (11x3) written into
+//       the [K = 3*PTS][176] panel of the camera group(s), plus z = L^-1 g_p for the right-hand side;
+//   consumer waves: rhs += panel^T z, then 16x16x4 MFMAs accumulate panel products into their output tiles.
+// Partials go to slabs; k_build_exchange sums them in a fixed order (deterministic, no atomics).
+//   DIAG  (ga == gb): one panel, 66 upper-triangular tiles over 4 consumer waves  (grid = (ksplit, ngroups))
+//   !DIAG (ga <  gb): two panels, 121 tiles over 8 consumer waves                (grid = (ksplit, npairs - ngroups))
 //   slab layout: [pair][ks][tile (121 slots)][reg 4][lane 64]   (acc type T)
 //   bpart layout: [ga][ks][176] doubles (only diagonal pairs contribute)
-template <bool DIAG> struct SchurCfg {
-  static constexpr int THREADS = DIAG ? 512 : 1024;
-  static constexpr int NW = THREADS / 64;
+template <bool DIAG> struct SchurThreads { static constexpr int value = DIAG ? 512 : 1024; };
+template <typename T, bool DIAG> struct SchurCfg {
+  static constexpr int THREADS = SchurThreads<DIAG>::value;
+  static constexpr int NPROD = THREADS / 2;                  // producer threads (first half of the workgroup)
+  static constexpr int NCW = THREADS / 128;                  // consumer waves
   static constexpr int NTILE = DIAG ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : GROUP_TILES * GROUP_TILES;
-  static constexpr int MAXSLOT = (NTILE + NW - 1) / NW;     // 9 or 8
+  static constexpr int MAXSLOT = (NTILE + NCW - 1) / NCW;    // 17 or 16
+  static constexpr int PTS = (!DIAG && sizeof(T) == 8) ? 8 : 16;   // points per chunk (LDS budget: 2 buffers x panels)
+  static constexpr int K = 3 * PTS;
+  static constexpr int NPANEL = DIAG ? 1 : 2;
+  static constexpr int BUF = NPANEL * K * GROUP_ROWS + K;    // one buffer: panel(s) + z   (in T)
+  static constexpr size_t LDS_BYTES = (size_t)(2 * BUF + 2 * GROUP_CAMS * CAMPRE) * sizeof(T);
 };
 
 __device__ inline void schur_tile_rc(bool diag, int t, int& R, int& Tc) {
@@ -410,144 +448,279 @@ __device__ inline void schur_tile_rc(bool diag, int t, int& R, int& Tc) {
   } else { R = t / GROUP_TILES; Tc = t - R * GROUP_TILES; }
 }
 
+// Static tile ownership of the 4 consumer waves of a diagonal pair: whole block-rows of the upper triangle, paired so
+// that every wave owns 15-17 tiles.  With the rows known at compile time one k-step needs only the (<= 11) distinct
+// 16-row fragments of the panel (A and B operands of a diagonal pair are the same fragments), all MFMAs of a k-step
+// are independent, and the next k-step's fragments are fetched while they issue.
+__host__ __device__ constexpr int diag_row_of(int cw, int k) {
+  constexpr int rows[4][5] = {{0, 5, -1, -1, -1}, {1, 4, -1, -1, -1}, {2, 3, -1, -1, -1}, {6, 7, 8, 9, 10}};
+  return rows[cw][k];
+}
+__host__ __device__ constexpr int diag_min_row(int cw) { return cw == 3 ? 6 : cw; }
+__host__ __device__ constexpr int diag_tile_index(int R, int Tc) { return R * GROUP_TILES - (R * (R - 1)) / 2 + (Tc - R); }
+
+template <typename T, int CW, int K>
+__device__ inline void schur_consume_diag(const T* __restrict__ pl /* panel + lane offset */,
+                                          typename Mfma<T>::acc_t (&acc)[17]) {
+  using M_ = Mfma<T>;
+  constexpr int RMIN = diag_min_row(CW);
+  T f[2][GROUP_TILES];
+#pragma unroll
+  for (int b = RMIN; b < GROUP_TILES; ++b) f[0][b] = pl[16 * b];
+#pragma unroll
+  for (int ks = 0; ks < K / 4; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < K / 4) {
+#pragma unroll
+      for (int b = RMIN; b < GROUP_TILES; ++b) f[cur ^ 1][b] = pl[(ks + 1) * 4 * GROUP_ROWS + 16 * b];
+    }
+    int slot = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int R = diag_row_of(CW, k);
+      if (R >= 0) {
+#pragma unroll
+        for (int Tc = R; Tc < GROUP_TILES; ++Tc) { acc[slot] = M_::mma(f[cur][R], f[cur][Tc], acc[slot]); ++slot; }
+      }
+    }
+  }
+}
+
+template <typename T, int CW>
+__device__ inline void schur_store_diag(T* __restrict__ slab, int lane, const typename Mfma<T>::acc_t (&acc)[17]) {
+  int slot = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int R = diag_row_of(CW, k);
+    if (R >= 0) {
+#pragma unroll
+      for (int Tc = R; Tc < GROUP_TILES; ++Tc) {
+        const int t = diag_tile_index(R, Tc);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) slab[(size_t)t * 256 + rg * 64 + lane] = acc[slot][rg];
+        ++slot;
+      }
+    }
+  }
+}
+
 template <typename T, bool DIAG>
-__global__ __launch_bounds__(SchurCfg<DIAG>::THREADS) void k_schur(
+__global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
     const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
-    const int32_t* __restrict__ ci, const int32_t* __restrict__ pt_start, int N,
-    const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
-    const double* __restrict__ lam_ptr, const int32_t* __restrict__ pair_ga, const int32_t* __restrict__ pair_gb,
-    int pair0, int ksplit, T* __restrict__ slabs, double* __restrict__ bpart) {
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start, int N,
+    const T* __restrict__ pf, const int32_t* __restrict__ pair_ga, const int32_t* __restrict__ pair_gb,
+    int pair0, int ksplit, int dense, T* __restrict__ slabs, double* __restrict__ bpart,
+    long long* __restrict__ dbg /* optional cycle stamps of workgroup (0,0): [it][producer done, consumer done, barrier out] */) {
   extern __shared__ __align__(16) unsigned char smem[];
   using M_ = Mfma<T>;
-  using Cfg = SchurCfg<DIAG>;
-  constexpr int THREADS = Cfg::THREADS, NW = Cfg::NW, MAXSLOT = Cfg::MAXSLOT, NTILE = Cfg::NTILE;
+  using Cfg = SchurCfg<T, DIAG>;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, NCW = Cfg::NCW, MAXSLOT = Cfg::MAXSLOT, NTILE = Cfg::NTILE;
+  constexpr int PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF;
   const int pair = pair0 + blockIdx.y;
   const int ga = pair_ga[pair], gb = pair_gb[pair];
   const int camA0 = ga * GROUP_CAMS, camB0 = gb * GROUP_CAMS;
   const int nA = min(GROUP_CAMS, C - camA0), nB = min(GROUP_CAMS, C - camB0);
-  T* panelA = reinterpret_cast<T*>(smem);                       // [SCHUR_K][GROUP_ROWS]
-  T* panelB = DIAG ? panelA : panelA + SCHUR_K * GROUP_ROWS;
-  T* s_cam = panelA + (DIAG ? 1 : 2) * SCHUR_K * GROUP_ROWS;    // [32][CAMPRE] : group A then group B
-  T* s_z = s_cam + 2 * GROUP_CAMS * CAMPRE;                     // [SCHUR_K]      z = L^-1 gp per point
-  T* s_li = s_z + SCHUR_K;                                      // [SCHUR_PTS][8] L^-1 (6 values) + valid flag
+  T* s_buf = reinterpret_cast<T*>(smem);                          // [2][BUF]: panelA [K][176], (panelB), z [K]
+  T* s_cam = s_buf + 2 * BUF;                                     // [32][CAMPRE] : group A then group B
+  for (int i = threadIdx.x; i < 2 * BUF; i += THREADS) s_buf[i] = (T)0;
   for (int i = threadIdx.x; i < nA * CAMPRE; i += THREADS) s_cam[i] = campre[(size_t)camA0 * CAMPRE + i];
   if (!DIAG)
     for (int i = threadIdx.x; i < nB * CAMPRE; i += THREADS)
       s_cam[GROUP_CAMS * CAMPRE + i] = campre[(size_t)camB0 * CAMPRE + i];
-  const double lam = *lam_ptr;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool producer = threadIdx.x < NPROD;
+  const int cw = wid - NPROD / 64;                                // consumer wave index (valid when !producer)
+  const int ct = threadIdx.x - NPROD;                             // consumer thread index
   typename M_::acc_t acc[MAXSLOT];
 #pragma unroll
   for (int s = 0; s < MAXSLOT; ++s) acc[s] = typename M_::acc_t{0, 0, 0, 0};
-  double bacc = 0;   // thread rho < 176 accumulates the rhs contribution of row rho (diag pairs only)
+  double bacc = 0;   // consumer thread rho < 176 accumulates the rhs contribution of row rho (diag pairs only)
   const int lane_off = (lane >> 4) * GROUP_ROWS + (lane & 15);
 
-  // slice of points for this k-split (multiple of SCHUR_PTS)
+  // slice of points for this k-split (multiple of PTS)
   int per = (N + ksplit - 1) / ksplit;
-  per = ((per + SCHUR_PTS - 1) / SCHUR_PTS) * SCHUR_PTS;
+  per = ((per + PTS - 1) / PTS) * PTS;
   const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
-  for (int p0 = pbeg; p0 < pend; p0 += SCHUR_PTS) {
-    const int p1 = min(pend, p0 + SCHUR_PTS);
-    __syncthreads();   // previous chunk's MFMA reads are done
-    for (int i = threadIdx.x; i < (DIAG ? 1 : 2) * SCHUR_K * GROUP_ROWS; i += THREADS) panelA[i] = (T)0;
-    if (threadIdx.x < SCHUR_PTS) {
-      // one lane per point of the chunk: (V + lam D)^-1 factor, shared by all its observations
-      const int q = threadIdx.x, p = p0 + q;
-      T li[6] = {0, 0, 0, 0, 0, 0};
-      T z0 = 0, z1 = 0, z2 = 0, ok = 0;
-      if (p < p1) {
-        T v6[6];
-        v6[0] = (T)(V[(size_t)p * 6 + 0] + lam * fmax_pos(D2p[(size_t)p * 3 + 0]));
-        v6[1] = (T)V[(size_t)p * 6 + 1];
-        v6[2] = (T)V[(size_t)p * 6 + 2];
-        v6[3] = (T)(V[(size_t)p * 6 + 3] + lam * fmax_pos(D2p[(size_t)p * 3 + 1]));
-        v6[4] = (T)V[(size_t)p * 6 + 4];
-        v6[5] = (T)(V[(size_t)p * 6 + 5] + lam * fmax_pos(D2p[(size_t)p * 3 + 2]));
-        if (chol3_inv<T>(v6, li)) {   // degenerate point: contributes nothing (its step is zeroed in back-substitution too)
-          ok = (T)1;
-          const T g0 = (T)gp[(size_t)p * 3], g1 = (T)gp[(size_t)p * 3 + 1], g2 = (T)gp[(size_t)p * 3 + 2];
-          z0 = li[0] * g0;
-          z1 = li[1] * g0 + li[2] * g1;
-          z2 = li[3] * g0 + li[4] * g1 + li[5] * g2;
+  const int nchunk = (pend - pbeg + PTS - 1) / PTS;
+  // producer software pipeline (diagonal pairs): per-lane operands of the current chunk and indices of the next
+  using T2 = typename Vec2<T>::type;
+  bool cur_valid = false, n1_valid = false;
+  int cur_c = 0, cur_p = 0, n1_c = 0, n1_p = 0;
+  T2 cur_uv, n1_uv; cur_uv.x = cur_uv.y = n1_uv.x = n1_uv.y = (T)0;
+  T cur_w = (T)1, n1_w = (T)1;
+  T cur_X[3] = {0, 0, 0};
+  T cur_f[PF];
+#pragma unroll
+  for (int k = 0; k < PF; ++k) cur_f[k] = (T)0;
+  auto load_idx = [&](int chunk, bool& valid, int& c, int& pp, T2& m, T& ww) {
+    valid = false;
+    if (chunk < nchunk) {
+      const int q0 = pbeg + chunk * PTS, q1 = min(pend, q0 + PTS);
+      const int o = pt_start[q0] + (int)threadIdx.x;
+      if (o < pt_start[q1]) { valid = true; c = ci[o]; pp = pi[o]; m = uv[o]; ww = w ? w[o] : (T)1; }
+    }
+  };
+  // a chunk holds at most PTS*C observations: one per producer lane only when all cameras are in this one group
+  const bool piped = DIAG && (C <= GROUP_CAMS) && sizeof(T) == 4;   // f64 has no registers to spare for the pipeline state
+  if (piped && producer) {
+    load_idx(0, cur_valid, cur_c, cur_p, cur_uv, cur_w);
+    if (cur_valid) {
+      cur_X[0] = ptsT[3 * (size_t)cur_p]; cur_X[1] = ptsT[3 * (size_t)cur_p + 1]; cur_X[2] = ptsT[3 * (size_t)cur_p + 2];
+#pragma unroll
+      for (int k = 0; k < PF; ++k) cur_f[k] = pf[(size_t)cur_p * PF + k];
+    }
+    load_idx(1, n1_valid, n1_c, n1_p, n1_uv, n1_w);
+  }
+  __syncthreads();
+  for (int it = 0; it <= nchunk; ++it) {
+    if (producer) {
+      if (it < nchunk) {
+        T* buf = s_buf + (it & 1) * BUF;
+        T* panelA = buf;
+        T* panelB = DIAG ? panelA : panelA + K * GROUP_ROWS;
+        T* s_z = buf + Cfg::NPANEL * K * GROUP_ROWS;
+        const int p0 = pbeg + it * PTS, p1 = min(pend, p0 + PTS);
+        if (dense && p1 - p0 < PTS)      // partial last chunk of a dense problem: clear the rows no observation will write
+          for (int i = (p1 - p0) * 3 * GROUP_ROWS + threadIdx.x; i < Cfg::NPANEL * K * GROUP_ROWS; i += NPROD) {
+            const int rowi = (i % (K * GROUP_ROWS)) / GROUP_ROWS;
+            if (rowi >= 3 * (p1 - p0)) buf[i] = (T)0;
+          }
+        // one observation -> its 11x3 block of Ytilde in the panel (+ z of its point)
+        auto emit = [&](int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f) {
+          const bool inA = (c >= camA0 && c < camA0 + nA);
+          const bool inB = !DIAG && (c >= camB0 && c < camB0 + nB);
+          if (!inA && !inB) return;
+          T* pan = inA ? panelA : panelB;
+          const int col0 = (inA ? (c - camA0) : (c - camB0)) * NCP;
+          if (f[9] == (T)0) {              // degenerate point
+            if (dense) {
+#pragma unroll
+              for (int e = 0; e < NCP; ++e)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) pan[(3 * q + d) * GROUP_ROWS + col0 + e] = (T)0;
+            }
+            return;
+          }
+          const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
+          T r[2], Jc[2][NCP], Jp[2][3];
+          obs_resjac<T>(cp, X0, X1, X2, ux, uy, ww, r, Jc, Jp);
+          // Jp~ = Jp * L^-T  (2x3):  (L^-T)[k][d] = Linv[d][k]
+          T Jt[2][3];
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            Jt[rr][0] = Jp[rr][0] * f[0];
+            Jt[rr][1] = Jp[rr][0] * f[1] + Jp[rr][1] * f[2];
+            Jt[rr][2] = Jp[rr][0] * f[3] + Jp[rr][1] * f[4] + Jp[rr][2] * f[5];
+          }
+#pragma unroll
+          for (int e = 0; e < NCP; ++e) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+              pan[(3 * q + d) * GROUP_ROWS + col0 + e] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
+          }
+          if (DIAG) { s_z[3 * q + 0] = f[6]; s_z[3 * q + 1] = f[7]; s_z[3 * q + 2] = f[8]; }   // same 3 values from every observation of the point
+        };
+        if (piped) {
+          // <= 16 points x 16 cameras = 256 observations = one per producer lane; operands of the NEXT chunk were
+          // requested one iteration ago (software pipeline: indices two chunks ahead, point data one chunk ahead)
+          if (cur_valid) emit(cur_c, cur_p - p0, cur_uv.x, cur_uv.y, cur_w, cur_X[0], cur_X[1], cur_X[2], cur_f);
+        } else {
+          const int o_lo = pt_start[p0], o_hi = pt_start[p1];
+          for (int o = o_lo + threadIdx.x; o < o_hi; o += NPROD) {
+            const int c = ci[o];
+            const int pp = pi[o];
+            T f[PF];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) f[k] = pf[(size_t)pp * PF + k];
+            const auto m = uv[o];
+            emit(c, pp - p0, m.x, m.y, w ? w[o] : (T)1, ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f);
+          }
         }
       }
+      if (piped) {
+        // advance the pipeline: data for chunk it+1 (its indices are already here), indices for chunk it+2
+        cur_valid = n1_valid; cur_c = n1_c; cur_p = n1_p; cur_uv = n1_uv; cur_w = n1_w;
+        if (cur_valid) {
+          cur_X[0] = ptsT[3 * (size_t)cur_p]; cur_X[1] = ptsT[3 * (size_t)cur_p + 1]; cur_X[2] = ptsT[3 * (size_t)cur_p + 2];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) s_li[q * 8 + k] = li[k];
-      s_li[q * 8 + 6] = ok;
-      s_z[3 * q + 0] = z0; s_z[3 * q + 1] = z1; s_z[3 * q + 2] = z2;
-    }
-    __syncthreads();
-    const int o_lo = pt_start[p0], o_hi = pt_start[p1];
-    for (int o = o_lo + threadIdx.x; o < o_hi; o += THREADS) {
-      const int c = ci[o];
-      const bool inA = (c >= camA0 && c < camA0 + nA);
-      const bool inB = !DIAG && (c >= camB0 && c < camB0 + nB);
-      if (!inA && !inB) continue;
-      int lo = p0, hi = p1;
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pt_start[mid] <= o) lo = mid; else hi = mid; }
-      const int p = lo, q = p - p0;
-      if (s_li[q * 8 + 6] == (T)0) continue;
-      T li[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) li[k] = s_li[q * 8 + k];
-      const auto m = uv[o];
-      const T ww = w ? w[o] : (T)1;
-      const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
-      T r[2], Jc[2][NCP], Jp[2][3];
-      obs_resjac<T>(cp, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2], m.x, m.y, ww, r, Jc, Jp);
-      // Jp~ = Jp * L^-T  (2x3):  (L^-T)[k][d] = Linv[d][k]
-      T Jt[2][3];
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        Jt[rr][0] = Jp[rr][0] * li[0];
-        Jt[rr][1] = Jp[rr][0] * li[1] + Jp[rr][1] * li[2];
-        Jt[rr][2] = Jp[rr][0] * li[3] + Jp[rr][1] * li[4] + Jp[rr][2] * li[5];
+          for (int k = 0; k < PF; ++k) cur_f[k] = pf[(size_t)cur_p * PF + k];
+        }
+        load_idx(it + 2, n1_valid, n1_c, n1_p, n1_uv, n1_w);
       }
-      T* pan = inA ? panelA : panelB;
-      const int col0 = (inA ? (c - camA0) : (c - camB0)) * NCP;
-#pragma unroll
-      for (int e = 0; e < NCP; ++e) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-          pan[(3 * q + d) * GROUP_ROWS + col0 + e] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
-      }
-    }
-    __syncthreads();
-    // rhs: b[rho] += sum_k panel[k][rho] * z[k]
-    if (DIAG && threadIdx.x < GROUP_ROWS) {
-      T s = 0;
+    } else if (it >= 1) {
+      T* buf = s_buf + ((it - 1) & 1) * BUF;
+      const T* panelA = buf;
+      const T* panelB = DIAG ? panelA : panelA + K * GROUP_ROWS;
+      const T* s_z = buf + Cfg::NPANEL * K * GROUP_ROWS;
+      // rhs: b[rho] += sum_k panel[k][rho] * z[k]
+      if (DIAG && ct < GROUP_ROWS) {
+        T s0 = 0, s1 = 0;
 #pragma unroll 8
-      for (int k = 0; k < SCHUR_K; ++k) s += panelA[k * GROUP_ROWS + threadIdx.x] * s_z[k];
-      bacc += (double)s;
-    }
-    // tiles
-#pragma unroll
-    for (int s = 0; s < MAXSLOT; ++s) {
-      const int t = wid + NW * s;
-      if (t < NTILE) {
-        int R, Tc;
-        schur_tile_rc(DIAG, t, R, Tc);
-        const T* pa = panelA + lane_off + 16 * R;
-        const T* pb = panelB + lane_off + 16 * Tc;
-#pragma unroll
-        for (int ks = 0; ks < SCHUR_K / 4; ++ks)
-          acc[s] = M_::mma(pa[ks * 4 * GROUP_ROWS], pb[ks * 4 * GROUP_ROWS], acc[s]);
+        for (int k = 0; k < K; k += 2) { s0 += panelA[k * GROUP_ROWS + ct] * s_z[k]; s1 += panelA[(k + 1) * GROUP_ROWS + ct] * s_z[k + 1]; }
+        bacc += (double)(s0 + s1);
       }
+      if constexpr (DIAG) {
+        static_assert(MAXSLOT == 17, "diagonal pairs: 4 consumer waves x <= 17 tiles");
+        const T* pl = panelA + lane_off;
+        switch (cw) {
+          case 0: schur_consume_diag<T, 0, K>(pl, acc); break;
+          case 1: schur_consume_diag<T, 1, K>(pl, acc); break;
+          case 2: schur_consume_diag<T, 2, K>(pl, acc); break;
+          default: schur_consume_diag<T, 3, K>(pl, acc); break;
+        }
+      } else {
+        // generic (off-diagonal pairs): k-step outer so that consecutive MFMAs are independent
+#pragma unroll
+        for (int ks = 0; ks < K / 4; ++ks) {
+#pragma unroll
+          for (int s = 0; s < MAXSLOT; ++s) {
+            const int t = cw + NCW * s;
+            if (t < NTILE) {
+              const int R = t / GROUP_TILES, Tc = t - R * GROUP_TILES;
+              acc[s] = M_::mma(panelA[lane_off + 16 * R + ks * 4 * GROUP_ROWS], panelB[lane_off + 16 * Tc + ks * 4 * GROUP_ROWS], acc[s]);
+            }
+          }
+        }
+      }
+    }
+    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && it < 20) {
+      if (threadIdx.x == 0) dbg[3 * it + 0] = clock64();
+      if (threadIdx.x == NPROD) dbg[3 * it + 1] = clock64();
+    }
+    __syncthreads();
+    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && it < 20 && threadIdx.x == 0) dbg[3 * it + 2] = clock64();
+    if (!dense && it >= 1) {
+      // sparse visibility: not every panel entry is rewritten by the next chunk, so the buffer that was just
+      // consumed is cleared by the whole workgroup before the producers get it back
+      T* done = s_buf + ((it - 1) & 1) * BUF;
+      for (int i = threadIdx.x; i < Cfg::NPANEL * K * GROUP_ROWS; i += THREADS) done[i] = (T)0;
+      __syncthreads();
     }
   }
   // write partial tiles
-  T* slab = slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
+  if (!producer) {
+    T* slab = slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
+    if constexpr (DIAG) {
+      switch (cw) {
+        case 0: schur_store_diag<T, 0>(slab, lane, acc); break;
+        case 1: schur_store_diag<T, 1>(slab, lane, acc); break;
+        case 2: schur_store_diag<T, 2>(slab, lane, acc); break;
+        default: schur_store_diag<T, 3>(slab, lane, acc); break;
+      }
+    } else {
 #pragma unroll
-  for (int s = 0; s < MAXSLOT; ++s) {
-    const int t = wid + NW * s;
-    if (t < NTILE) {
+      for (int s = 0; s < MAXSLOT; ++s) {
+        const int t = cw + NCW * s;
+        if (t < NTILE) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) slab[(size_t)t * 256 + rg * 64 + lane] = acc[s][rg];
+          for (int rg = 0; rg < 4; ++rg) slab[(size_t)t * 256 + rg * 64 + lane] = acc[s][rg];
+        }
+      }
     }
+    if (DIAG && ct < GROUP_ROWS)
+      bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + ct] = bacc;
   }
-  if (DIAG && threadIdx.x < GROUP_ROWS)
-    bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + threadIdx.x] = bacc;
 }
 
 }  // namespace sba

@@ -248,7 +248,8 @@ template <typename T>
 __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
     const T* __restrict__ campre, const T* __restrict__ campre_new, int C, const double* __restrict__ pts,
     const T* __restrict__ ptsT, const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
-    const int32_t* __restrict__ ci, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ blk_pt,
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start,
+    const int32_t* __restrict__ blk_pt,
     const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
     const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ pts_new,
     T* __restrict__ ptsT_new, double* __restrict__ trial_part, int nblk) {
@@ -273,9 +274,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
   T my_w = (T)1;
   if ((int)threadIdx.x < nobs) {
     const int o = o_lo + threadIdx.x;
-    int lo = p_lo, hi = p_hi;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pt_start[mid] <= o) lo = mid; else hi = mid; }
-    my_p = lo;
+    my_p = pi[o];
     my_c = ci[o];
     my_uv = uv[o];
     my_w = w ? w[o] : (T)1;
