@@ -98,6 +98,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SBA_BENCH_BACKEND", "nccl") != "nccl":
+        local = 0      # rehearsal on a one-GPU box: every rank uses device 0
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
@@ -112,7 +114,11 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("SBA_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse N>1 on a one-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
