@@ -99,6 +99,9 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   const double* gct = dU + n;
   const double lam = st->lam;
   const bool fresh = st->fresh != 0;
+  // operands of the epilogue, requested now so that their latency is hidden behind the factorisation
+  const double my_cam = (tid < n) ? cams[tid] : 0.0;
+  const double my_g = (tid < n) ? gct[tid] : 0.0;
 
   // camera scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
   for (int i = tid; i < n16; i += CHOLB_THREADS) {
@@ -119,27 +122,30 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   }
   if (tid == 0) { s_fail = 0; st->cost = E[(size_t)n * n + 3 * n]; }
   __syncthreads();
-  // load the lower block triangle (+ damping), 8 independent loads in flight per thread; the padded tail is the identity
+  // load the lower block triangle (+ damping): every thread issues all of its (<= 33) loads before using any of
+  // them, so the fabric latency of reading E (written by other CUs) is paid once; the padded tail is the identity
   {
+    constexpr int MAXU = (CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2 + 1) / 2;     // 33
     const int e = tid & 255, ii = e >> 4, jj = e & 15, half = tid >> 8;
-    for (int b0 = 0; b0 < nblk; b0 += 16) {
-      double v[8];
+    double v[MAXU];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int b = b0 + 2 * u + half;
-        v[u] = 0;
-        if (b < nblk) {
-          const int rc = s_rc[b];
-          const int I = (rc >> 8) * CB + ii, J = (rc & 255) * CB + jj;
-          if (I < n && J < n) v[u] = E[(size_t)I * n + J];
-          else v[u] = (I == J) ? 1.0 : 0.0;
-          if (I == J && I < n) v[u] += s_d[I];
-        }
+    for (int u = 0; u < MAXU; ++u) {
+      const int b = 2 * u + half;
+      v[u] = 0;
+      if (b < nblk) {
+        const int rc = s_rc[b];
+        const int I = (rc >> 8) * CB + ii, J = (rc & 255) * CB + jj;
+        if (I < n && J < n) v[u] = E[(size_t)I * n + J];
+        else v[u] = (I == J) ? 1.0 : 0.0;
       }
+    }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int b = b0 + 2 * u + half;
-        if (b < nblk) Lb[b * CBS + ii * CLD + jj] = v[u];
+    for (int u = 0; u < MAXU; ++u) {
+      const int b = 2 * u + half;
+      if (b < nblk) {
+        const int rc = s_rc[b];
+        const int I = (rc >> 8) * CB + ii, J = (rc & 255) * CB + jj;
+        Lb[b * CBS + ii * CLD + jj] = v[u] + ((I == J && I < n) ? s_d[I] : 0.0);
       }
     }
   }
@@ -157,11 +163,21 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
     const double* inv = s_inv + jb * CB;
     // ---- B': L21 = A21 L11^-T row by row, right-looking: x_k = a_k / L_kk ; a_j -= x_k L11[j][k] (j > k).
     //      One more thread does the same with the rhs block, which is the forward solve.
-    if (tid <= m) {
+    if (tid <= m + CB) {
       double a[CB];
-      double* row = (tid < m) ? Lb + cb_off(jb + 1 + (tid >> 4), jb) + (tid & 15) * CLD : s_y + jb * CB;
+      // tid < m: panel row ; tid == m: rhs block ; tid in (m, m+16]: row e_j of the identity, whose solution
+      // e_j L11^-T is row j of Linv^T -- stored over the diagonal block itself (B' reads L11 only through its
+      // transposed copy, and nothing but the back substitution needs the diagonal block afterwards)
+      const int jrow = tid - m - 1;
+      double* row = (tid < m) ? Lb + cb_off(jb + 1 + (tid >> 4), jb) + (tid & 15) * CLD
+                  : (tid == m) ? s_y + jb * CB : Lb + cb_off(jb, jb) + jrow * CLD;
+      if (tid <= m) {
 #pragma unroll
-      for (int k = 0; k < CB; ++k) a[k] = row[k];
+        for (int k = 0; k < CB; ++k) a[k] = row[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < CB; ++k) a[k] = (k == jrow) ? 1.0 : 0.0;
+      }
 #pragma unroll
       for (int k = 0; k < CB; ++k) {
         const double xk = a[k] * inv[k];
@@ -223,50 +239,43 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
     CHOL_STAMP();
   }
   const bool fail = s_fail != 0;
-  // ---- back substitution  L11_b^T x_b = y_b - sum_{r>b} L[r][b]^T x_r   (wave 0, 16 lanes x 4 partial sums)
-  if (!fail && wid == 0) {
-    const int j = lane & 15, part = lane >> 4;
+  // ---- back substitution, right-looking:  x_b = Linv_b^T y_b  (wave 0), then every earlier row t < 16 b takes
+  //      y_t -= sum_i L[16b+i][t] x_b[i]  (all waves).  The diagonal blocks hold Linv^T.
+  if (!fail) {
     for (int b = nb - 1; b >= 0; --b) {
-      const double* L11 = Lb + cb_off(b, b);
-      double col[CB];                                 // column j of L11: L11[k][j] (zero above the diagonal)
+      if (wid == 0) {
+        const int j = lane & 15, part = lane >> 4;
+        const double* LiT = Lb + cb_off(b, b) + j * CLD;    // row j of Linv^T
+        double x = 0;
 #pragma unroll
-      for (int k = 0; k < CB; ++k) col[k] = L11[k * CLD + j];
-      double v0 = 0, v1 = 0;
-      int I = (b + 1) * CB + part;
-      for (; I + 4 < n16; I += 8) {
-        v0 += Lb[cb_off(I >> 4, b) + (I & 15) * CLD + j] * s_y[I];
-        v1 += Lb[cb_off((I + 4) >> 4, b) + ((I + 4) & 15) * CLD + j] * s_y[I + 4];
+        for (int ii = 0; ii < 4; ++ii) { const int i = part + 4 * ii; x += LiT[i] * s_y[b * CB + i]; }
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (part == 0) s_y[b * CB + j] = x;
       }
-      if (I < n16) v0 += Lb[cb_off(I >> 4, b) + (I & 15) * CLD + j] * s_y[I];
-      double v = v0 + v1;
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      v = s_y[b * CB + j] - v;                        // every 16-lane group now holds v_j
-      const double myinv = s_inv[b * CB + j];
-      double x = 0;
+      __syncthreads();
+      if (tid < b * CB) {
+        const double* col = Lb + cb_off(b, tid >> 4) + (tid & 15);
+        double s0 = 0, s1 = 0;
 #pragma unroll
-      for (int k = CB - 1; k >= 0; --k) {
-        const double xk = readlane_f64(v * myinv, k); // x_k = v_k / L[k][k]
-        if (j == k) x = xk;
-        v -= col[k] * xk;                             // rows j < k: v_j -= L[k][j] x_k   (col[k] = 0 for j > k)
+        for (int i = 0; i < CB; i += 2) { s0 += col[i * CLD] * s_y[b * CB + i]; s1 += col[(i + 1) * CLD] * s_y[b * CB + i + 1]; }
+        s_y[tid] -= s0 + s1;
       }
-      __builtin_amdgcn_wave_barrier();
-      if (part == 0) s_y[b * CB + j] = x;
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();
     }
   }
   __syncthreads();
   CHOL_STAMP();
   double pred = 0, dx2 = 0, x2 = 0, gm = 0;
-  for (int i = tid; i < n; i += CHOLB_THREADS) {
-    const double d = fail ? 0.0 : s_y[i];
-    delta_c[i] = d;
-    const double x = cams[i];
-    cams_new[i] = x + d;
-    pred += 0.5 * d * (s_d[i] * d - gct[i]);
-    dx2 += d * d;
-    x2 += x * x;
-    gm = fmax(gm, fabs(gct[i]));
+  if (tid < n) {                                     // n <= 176 < CHOLB_THREADS: one entry per thread
+    const double d = fail ? 0.0 : s_y[tid];
+    delta_c[tid] = d;
+    cams_new[tid] = my_cam + d;
+    pred = 0.5 * d * (s_d[tid] * d - my_g);
+    dx2 = d * d;
+    x2 = my_cam * my_cam;
+    gm = fabs(my_g);
   }
   pred = wave_sum(pred); dx2 = wave_sum(dx2); x2 = wave_sum(x2); gm = wave_max(gm);
   if (lane == 0) { s_scr[0][wid] = pred; s_scr[1][wid] = dx2; s_scr[2][wid] = x2; s_scr[3][wid] = gm; }
