@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "sba_create", "sba_upload", "sba_set_params", "sba_get_params", "sba_destroy",
     "sba_get_gradient", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
-    "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_finish", "sba_time_kernel", "sba_get_kernel_profile",
+    "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_finish", "sba_time_kernel", "sba_get_kernel_profile",
 )
 
 
@@ -97,6 +97,8 @@ def load():
         "sba_lm_solve_trial": (C.c_int, [H, C.c_void_p, C.c_void_p]),
         "sba_lm_decide": (C.c_int, [H, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int32), C.POINTER(LmIterLog)]),
+        "sba_lm_decide_async": (C.c_int, [H, C.c_void_p, C.c_int32]),
+        "sba_lm_poll": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "sba_lm_finish": (C.c_int, [H, dp, dp, C.POINTER(LmReport)]),
         "sba_time_kernel": (C.c_int, [H, C.c_char_p, C.c_int32, dp]),
         "sba_get_kernel_profile": (C.c_int, [H, dp, ip]),
@@ -294,6 +296,14 @@ class Problem:
         _check(self._lib.sba_lm_decide(self._h, C.c_void_p(scalars_all_ptr), n_ranks, C.byref(status),
                                        C.byref(acc), C.byref(row)), self._h)
         return status.value, bool(acc.value), row
+
+    def lm_decide_async(self, scalars_all_ptr, n_ranks):
+        _check(self._lib.sba_lm_decide_async(self._h, C.c_void_p(scalars_all_ptr), n_ranks), self._h)
+
+    def lm_poll(self):
+        status, iters = C.c_int32(), C.c_int32()
+        _check(self._lib.sba_lm_poll(self._h, C.byref(status), C.byref(iters)), self._h)
+        return status.value, iters.value
 
     def lm_finish(self):
         cams = np.empty((self.C, 11))

@@ -87,6 +87,11 @@ struct Engine : EngineBase {
   DevBuf<T2> r_pm;
   DevBuf<T> Jc_pm, Jp_pm;
   DevBuf<LMState> d_state;
+  DevBuf<ParamPtrs<T>> d_pp;
+  ParamPtrs<T>* h_pp = nullptr;        // pinned
+  DevBuf<sba_lm_iter_log> d_log;
+  int log_read = 0;
+  int cur_at_begin = 0;
   LMState* h_state = nullptr;         // pinned
   sba_lm_opts opts{};
   bool lm_active = false;
@@ -95,7 +100,6 @@ struct Engine : EngineBase {
   bool schur_debug = false;
   DevBuf<long long> schur_dbg;
   DevBuf<long long> chol_dbg;
-  bool need_linearize = true;
   double initial_cost = 0;
   std::vector<sba_lm_iter_log> log;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -106,6 +110,8 @@ struct Engine : EngineBase {
   bool prof_on = false;
   double prof_us[KP_N] = {};
   long long prof_cnt[KP_N] = {};
+  int pslot = 0;
+  void pslot_advance() {}
   void prof_begin(int k) { if (prof_on) HIPCHK(hipEventRecord(pev[k][0], stream)); }
   void prof_end(int k) { if (prof_on) { HIPCHK(hipEventRecord(pev[k][1], stream)); pev_used[k] = true; } }
   void prof_collect() {   // call after a stream sync
@@ -121,6 +127,7 @@ struct Engine : EngineBase {
   ~Engine() override {
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) if (pev[k][j]) (void)hipEventDestroy(pev[k][j]);
     if (h_state) (void)hipHostFree(h_state);
+    if (h_pp) (void)hipHostFree(h_pp);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -132,6 +139,8 @@ struct Engine : EngineBase {
     if (d.stream) { stream = reinterpret_cast<hipStream_t>(d.stream); own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(LMState), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_pp), sizeof(ParamPtrs<T>), hipHostMallocDefault));
+    d_pp.alloc(1);
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) HIPCHK(hipEventCreate(&pev[k][j]));
@@ -280,7 +289,6 @@ struct Engine : EngineBase {
     HIPCHK(hipMemcpyAsync(ptsT[cur].p, pt.data(), sizeof(T) * pt.size(), hipMemcpyHostToDevice, stream));
     cam_prep(cur);
     sync();
-    need_linearize = true;
   }
 
   void cam_prep(int b) {
@@ -290,6 +298,15 @@ struct Engine : EngineBase {
   size_t lds_cams() const { return (size_t)C * CAMPRE * sizeof(T); }
 
   // ------------------------------------------------------------------ kernel launchers
+  // The LM kernels read the current / trial buffers through a device-resident pointer table that k_decide swaps on
+  // acceptance; the host mirror `cur` is refreshed from LMState::cur whenever the state is read back.
+  void push_ptrs() {
+    ParamPtrs<T> t;
+    t.cams = cams[cur].p; t.pts = pts[cur].p; t.ptsT = ptsT[cur].p; t.campre = campre[cur].p;
+    t.cams_new = cams[1 - cur].p; t.pts_new = pts[1 - cur].p; t.ptsT_new = ptsT[1 - cur].p; t.campre_new = campre[1 - cur].p;
+    *h_pp = t;
+    HIPCHK(hipMemcpyAsync(d_pp.p, h_pp, sizeof(ParamPtrs<T>), hipMemcpyHostToDevice, stream));
+  }
   void launch_residual(T2* r_out) {
     const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
     if (g == 0) return;
@@ -303,27 +320,29 @@ struct Engine : EngineBase {
     hipLaunchKernelGGL(k_resjac<T>, dim3(g), dim3(PM_BLOCK), lds, stream, campre[cur].p, C, ptsT[cur].p, uv_pm.p,
                        has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, r_out, Jc_pm.p, Jp_pm.p);
   }
-  void launch_linearize_points() {
+  // st == nullptr: unconditional (used outside the LM loop); otherwise the launch is a no-op once the solve has
+  // terminated or when the last step was rejected and nothing has to be re-linearized
+  void launch_linearize_points(const LMState* st) {
     if (nblk == 0) return;
     const size_t lds = (size_t)PM_BLOCK * 9 * sizeof(double) + lds_cams();
-    hipLaunchKernelGGL(k_linearize_points<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, campre[cur].p, C, ptsT[cur].p,
+    hipLaunchKernelGGL(k_linearize_points<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, d_pp.p, st, C,
                        uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_pt.p, V.p, gp.p, D2p.p,
                        cost_part.p, gmax_part.p);
   }
-  void launch_linearize_cams() {
+  void launch_linearize_cams(const LMState* st) {
     if (nchunk == 0) return;
-    hipLaunchKernelGGL(k_linearize_cams<T>, dim3(nchunk), dim3(256), 0, stream, campre[cur].p, ptsT[cur].p, uv_cm.p,
+    hipLaunchKernelGGL(k_linearize_cams<T>, dim3(nchunk), dim3(256), 0, stream, d_pp.p, st, uv_cm.p,
                        has_w ? w_cm.p : nullptr, pi_cm.p, chunk_cam.p, chunk_begin.p, chunk_end.p, Upart.p);
-    hipLaunchKernelGGL(k_reduce_cams, dim3(C), dim3(1024), 0, stream, Upart.p, cam_chunk_start.p, U.p, gc.p);
+    hipLaunchKernelGGL(k_reduce_cams, dim3(C), dim3(1024), 0, stream, Upart.p, cam_chunk_start.p, U.p, gc.p, st);
   }
   void launch_schur() {
     if (N > 0)
-      hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, &d_state.p->lam, N, pfac.p);
+      hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
     // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
     using CfgD = SchurCfg<T, true>;
     using CfgO = SchurCfg<T, false>;
     hipLaunchKernelGGL((k_schur<T, true>), dim3(ksplit, ngroups), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
-                       stream, campre[cur].p, C, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
+                       stream, d_pp.p, d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
                        pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,
                        schur_debug ? schur_dbg.p : nullptr);
     if (schur_debug) {
@@ -337,16 +356,16 @@ struct Engine : EngineBase {
     }
     if (npairs > ngroups)
       hipLaunchKernelGGL((k_schur<T, false>), dim3(ksplit, npairs - ngroups), dim3(CfgO::THREADS),
-                         CfgO::LDS_BYTES, stream, campre[cur].p, C, ptsT[cur].p, uv_pm.p,
+                         CfgO::LDS_BYTES, stream, d_pp.p, d_state.p, C, uv_pm.p,
                          has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
                          pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
   }
   void launch_backsub_trial() {
     if (nblk == 0) return;
     const size_t lds = (size_t)PM_BLOCK * 6 * sizeof(double) + (2 * (size_t)C * CAMPRE + (size_t)C * NCP) * sizeof(T);
-    hipLaunchKernelGGL(k_backsub_trial<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, campre[cur].p, campre[1 - cur].p, C,
-                       pts[cur].p, ptsT[cur].p, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_pt.p,
-                       V.p, gp.p, D2p.p, delta_c.p, d_state.p, pts[1 - cur].p, ptsT[1 - cur].p, trial_part.p, nblk);
+    hipLaunchKernelGGL(k_backsub_trial<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, d_pp.p, C,
+                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_pt.p,
+                       V.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nblk);
   }
 
   // ------------------------------------------------------------------ model evaluation entry points
@@ -398,13 +417,17 @@ struct Engine : EngineBase {
 
   // ------------------------------------------------------------------ LM phases
   int64_t exchange_size() const { return (int64_t)n * n + 3 * (int64_t)n + 1; }
+  static constexpr int LOG_CAP = 4096;
+  static constexpr int BATCH = 4;      // LM iterations enqueued between two host polls of the state
 
   int lm_begin(const sba_lm_opts* o) {
     if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
     HIPCHK(hipSetDevice(device));
     opts = *o;
     prof_on = opts.reserved[0] != 0;
-    for (int k = 0; k < KP_N; ++k) { prof_us[k] = 0; prof_cnt[k] = 0; pev_used[k] = false; }
+    for (int k = 0; k < KP_N; ++k) { prof_us[k] = 0; prof_cnt[k] = 0; }
+    pslot = 0;
+    for (auto& u : pev_used) u = false;
     if (opts.mode != SBA_MODE_FULL && opts.mode != SBA_MODE_POINTS_ONLY) { err = "unsupported mode"; return SBA_ERR_UNSUPPORTED; }
     // initial cost; scipy raises ValueError when it is not finite (least_squares.py:844-845)
     double c0 = 0;
@@ -420,7 +443,10 @@ struct Engine : EngineBase {
     s.nfev = 1; s.njev = 1;
     const long long nparam = (opts.mode == SBA_MODE_FULL ? (long long)n : 0) + 3LL * N;
     s.max_nfev = opts.max_nfev > 0 ? opts.max_nfev : 100 * nparam;
-    s.status = -1; s.fresh = 1;
+    s.status = -1; s.fresh = 1; s.need_lin = 1;
+    s.always_relin = opts.always_relinearize ? 1 : 0;
+    s.max_iter = opts.max_iter > 0 ? opts.max_iter : 0;
+    s.cur = 0;
     s.free_cams = (opts.mode == SBA_MODE_FULL) ? 1 : 0;
     *h_state = s;
     HIPCHK(hipMemcpyAsync(d_state.p, h_state, sizeof(LMState), hipMemcpyHostToDevice, stream));
@@ -428,10 +454,13 @@ struct Engine : EngineBase {
     // trial buffers start as copies so that points-only mode has valid trial cameras
     HIPCHK(hipMemcpyAsync(cams[1 - cur].p, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(campre[1 - cur].p, campre[cur].p, sizeof(T) * C * CAMPRE, hipMemcpyDeviceToDevice, stream));
+    push_ptrs();
+    cur_at_begin = cur;
+    if (d_log.n == 0) d_log.alloc(LOG_CAP);
     sync();
     log.clear();
+    log_read = 0;
     lm_active = true;
-    need_linearize = true;
     if (!std::isfinite(c0)) { err = "Residuals are not finite in the initial point."; return SBA_ERR_NONFINITE; }
     return SBA_OK;
   }
@@ -439,10 +468,9 @@ struct Engine : EngineBase {
   int lm_linearize() {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     prof_begin(KP_LINP);
-    launch_linearize_points();
+    launch_linearize_points(d_state.p);
     prof_end(KP_LINP);
-    if (h_state->free_cams) { prof_begin(KP_LINC); launch_linearize_cams(); prof_end(KP_LINC); }
-    need_linearize = false;
+    if (h_state->free_cams) { prof_begin(KP_LINC); launch_linearize_cams(d_state.p); prof_end(KP_LINC); }
     return SBA_OK;
   }
 
@@ -458,12 +486,13 @@ struct Engine : EngineBase {
       const int fc = (int)h_state->free_cams;
       const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 63) / 64 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(256), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
-                         pair_gb.p, npairs, U.p, gc.p, cost_part.p, nblk, C, fc, E);
+                         pair_gb.p, npairs, U.p, gc.p, cost_part.p, nblk, C, fc, E, d_state.p);
     }
     prof_end(KP_REDUCE);
     return SBA_OK;
   }
 
+  // scal == nullptr: single rank, the partials are folded inside k_decide and no scalar exchange is needed
   int lm_solve_trial(double* E, double* scal) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     if (h_state->free_cams) {
@@ -473,12 +502,11 @@ struct Engine : EngineBase {
         const size_t lds = ((size_t)(nb * (nb + 1) / 2 + 2) * CBS + 3 * (size_t)nb * CB) * sizeof(double);
         if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }
         hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_THREADS), lds, stream, E, C, d_state.p, D2c.p,
-                           cams[cur].p, delta_c.p, cams[1 - cur].p, campre[1 - cur].p, chol_debug ? chol_dbg.p : nullptr);
+                           d_pp.p, delta_c.p, chol_debug ? chol_dbg.p : nullptr);
         if (chol_debug) {
           std::vector<long long> st(64);
           HIPCHK(hipMemcpyAsync(st.data(), chol_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
           sync();
-          const int nb = (n + CB - 1) / CB;
           fprintf(stderr, "[chol stamps, cycles] load %lld  chol0 %lld |", st[1] - st[0], st[2] - st[1]);
           for (int j = 0; j < nb; ++j) fprintf(stderr, " B%d %lld C%d %lld |", j, st[3 + 2 * j] - st[2 + 2 * j], j, st[4 + 2 * j] - st[3 + 2 * j]);
           fprintf(stderr, " backsub %lld  epilogue %lld  total %lld\n", st[3 + 2 * nb] - st[2 + 2 * nb], st[4 + 2 * nb] - st[3 + 2 * nb], st[4 + 2 * nb] - st[0]);
@@ -487,10 +515,10 @@ struct Engine : EngineBase {
       } else if (n <= CHOL_LDS_MAX_N) {
         const size_t lds = (size_t)n * (n + 1) / 2 * sizeof(double);
         hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, E, C, d_state.p, D2c.p,
-                           cams[cur].p, delta_c.p, cams[1 - cur].p, campre[1 - cur].p);
+                           d_pp.p, delta_c.p);
       } else {
         hipLaunchKernelGGL((k_cholesky_solve<false, T>), dim3(1), dim3(CHOL_THREADS), 0, stream, E, C, d_state.p, D2c.p,
-                           cams[cur].p, delta_c.p, cams[1 - cur].p, campre[1 - cur].p);
+                           d_pp.p, delta_c.p);
       }
       prof_end(KP_CHOL);
     } else {
@@ -499,37 +527,60 @@ struct Engine : EngineBase {
     prof_begin(KP_BACKSUB);
     launch_backsub_trial();
     prof_end(KP_BACKSUB);
-    hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, nblk, d_state.p, scal);
+    if (scal)
+      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, nblk, d_state.p, scal);
     return SBA_OK;
   }
 
-  int lm_decide(const double* scal_all, int n_ranks, int32_t* status_out, int32_t* accepted_out, sba_lm_iter_log* row) {
+  // enqueue the accept / reject / terminate kernel; nothing is read back
+  int lm_decide_async(const double* scal_all, int n_ranks) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, stream, d_state.p, scal_all, n_ranks);
+    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(256), 0, stream, d_state.p, d_pp.p, scal_all, n_ranks, trial_part.p,
+                       gmax_part.p, nblk, reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
+    pslot_advance();
+    return SBA_OK;
+  }
+
+  // read the state back (one sync); returns the scipy status or -1 while the solve is still running
+  int lm_poll(int32_t* status_out, int32_t* iterations_out) {
+    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     HIPCHK(hipMemcpyAsync(h_state, d_state.p, sizeof(LMState), hipMemcpyDeviceToHost, stream));
     sync();
     HIPCHK(hipGetLastError());
     prof_collect();
     const LMState& s = *h_state;
-    if (s.accepted) { cur = 1 - cur; need_linearize = true; }
-    if (opts.always_relinearize) need_linearize = true;
-    sba_lm_iter_log r{};
-    r.iteration = s.iter; r.accepted = s.accepted; r.nfev = s.nfev;
-    r.cost = s.cost;
-    r.cost_reduction = s.actual; r.step_norm = s.step_norm; r.optimality = s.gnorm; r.lambda = s.lam; r.rho = s.rho;
-    log.push_back(r);
-    if (row) *row = r;
-    int status = s.status;
-    if (status < 0 && opts.max_iter > 0 && s.iter >= opts.max_iter) status = 0;
-    if (status_out) *status_out = status;
-    if (accepted_out) *accepted_out = s.accepted;
+    cur = cur_at_begin ^ (s.cur & 1);
+    const int have = std::min(s.iter, LOG_CAP);
+    if (have > log_read) {
+      log.resize(have);
+      HIPCHK(hipMemcpy(log.data() + log_read, d_log.p + log_read, sizeof(sba_lm_iter_log) * (have - log_read), hipMemcpyDeviceToHost));
+      log_read = have;
+    }
+    if (status_out) *status_out = s.status;
+    if (iterations_out) *iterations_out = s.iter;
+    return SBA_OK;
+  }
+
+  int lm_decide(const double* scal_all, int n_ranks, int32_t* status_out, int32_t* accepted_out, sba_lm_iter_log* row) {
+    int rc = lm_decide_async(scal_all, n_ranks);
+    if (rc) return rc;
+    int32_t st = -1, it = 0;
+    rc = lm_poll(&st, &it);
+    if (rc) return rc;
+    if (row && !log.empty()) *row = log.back();
+    if (status_out) *status_out = st;
+    if (accepted_out) *accepted_out = h_state->accepted;
     return SBA_OK;
   }
 
   int lm_finish(double* cams_out, double* pts_out, sba_lm_report* rep) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    int32_t st = -1, it = 0;
+    int rc = lm_poll(&st, &it);          // refreshes `cur` and the log
+    if (rc) return rc;
+    push_ptrs();                         // table consistent with `cur` for the unconditional launches below
     // gradient norm at the returned point (scipy reports optimality there, trf.py:546-551)
-    launch_linearize_points();
+    launch_linearize_points(nullptr);
     double gmax = 0;
     std::vector<double> gm(nblk), cp(nblk);
     if (nblk) {
@@ -538,7 +589,7 @@ struct Engine : EngineBase {
     }
     std::vector<double> gch(n, 0.0);
     if (h_state->free_cams) {
-      launch_linearize_cams();
+      launch_linearize_cams(nullptr);
       HIPCHK(hipMemcpyAsync(gch.data(), gc.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
     } else {
       gc.zero(stream);
@@ -557,7 +608,6 @@ struct Engine : EngineBase {
       rep->status = s.status < 0 ? 0 : s.status;
     }
     lm_active = false;
-    need_linearize = true;
     return SBA_OK;
   }
 
@@ -567,19 +617,25 @@ struct Engine : EngineBase {
     int rc = lm_begin(o);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev0, stream));
-    int32_t status = -1, acc = 0;
+    int32_t status = -1, iters = 0;
     while (status < 0) {
-      if (need_linearize) lm_linearize();
-      lm_form_reduced(E_own.p);
-      lm_solve_trial(E_own.p, scal_own.p);
-      rc = lm_decide(scal_own.p, 1, &status, &acc, nullptr);
+      // a batch of iterations is enqueued back to back; the kernels turn into no-ops once the device-side state says the
+      // solve has terminated, and a rejected step skips its re-linearization on the device, not on the host
+      int batch = prof_on ? 1 : BATCH;
+      if (o->max_iter > 0) batch = prof_on ? 1 : std::min(std::max(1, o->max_iter - iters), 64);
+      for (int b = 0; b < batch; ++b) {
+        lm_linearize();
+        lm_form_reduced(E_own.p);
+        lm_solve_trial(E_own.p, nullptr);
+        lm_decide_async(nullptr, 1);
+      }
+      rc = lm_poll(&status, &iters);
       if (rc) return rc;
     }
     HIPCHK(hipEventRecord(ev1, stream));
     HIPCHK(hipEventSynchronize(ev1));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-    h_state->status = status;
     rc = lm_finish(cams_out, pts_out, rep);
     if (rc) return rc;
     if (rep) {
@@ -605,12 +661,14 @@ struct Engine : EngineBase {
       sba_lm_opts o{}; o.ftol = o.xtol = o.gtol = 0; o.mode = SBA_MODE_FULL;
       if (!lm_active) { int rc = lm_begin(&o); if (rc) return rc; }
       lm_linearize(); lm_form_reduced(E_own.p); lm_solve_trial(E_own.p, scal_own.p);
+    } else {
+      push_ptrs();
     }
     auto once = [&]() {
       if (k == "residual") launch_residual(nullptr);
       else if (k == "resjac") launch_resjac(r_pm.p);
-      else if (k == "linearize_points") launch_linearize_points();
-      else if (k == "linearize_cams") launch_linearize_cams();
+      else if (k == "linearize_points") launch_linearize_points(nullptr);
+      else if (k == "linearize_cams") launch_linearize_cams(nullptr);
       else if (k == "schur") launch_schur();
       else if (k == "backsub") launch_backsub_trial();
       else return false;
@@ -835,6 +893,14 @@ int sba_lm_decide(sba_handle* h, const double* scalars_all_dev, int32_t n_ranks,
                   int32_t* accepted_out, sba_lm_iter_log* row_out) {
   if (!h || !scalars_all_dev || n_ranks < 1) return SBA_ERR_INVALID;
   return guarded(h, [&] { return DISPATCH(h, lm_decide(scalars_all_dev, n_ranks, status_out, accepted_out, row_out)); });
+}
+int sba_lm_decide_async(sba_handle* h, const double* scalars_all_dev, int32_t n_ranks) {
+  if (!h || n_ranks < 1 || (n_ranks > 1 && !scalars_all_dev)) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, lm_decide_async(scalars_all_dev, n_ranks)); });
+}
+int sba_lm_poll(sba_handle* h, int32_t* status_out, int32_t* iterations_out) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return DISPATCH(h, lm_poll(status_out, iterations_out)); });
 }
 int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report) {
   if (!h) return SBA_ERR_INVALID;

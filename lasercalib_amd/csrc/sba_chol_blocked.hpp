@@ -42,7 +42,7 @@ __device__ inline double rsqrt_nr(double x) {
 // v_readlane (SGPRs), so a step costs ~150 cycles instead of two LDS round trips.  Writes L (lower, upper zeroed)
 // back into the block, L^T into `blkT` and 1/L[k][k] into inv[0..15].  Returns false (wave-uniform) when the block
 // is not positive definite.
-__device__ inline bool chol16_wave(double* __restrict__ blk, double* __restrict__ blkT, double* __restrict__ inv) {
+__device__ __forceinline__ bool chol16_wave(double* __restrict__ blk, double* __restrict__ blkT, double* __restrict__ inv) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15;
   double a[CB];
@@ -74,10 +74,13 @@ __device__ inline bool chol16_wave(double* __restrict__ blk, double* __restrict_
 template <typename T>
 __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
     const double* __restrict__ E /* summed exchange buffer [S | rhs | diagU | gc | cost] */, int C,
-    LMState* __restrict__ st, double* __restrict__ D2c, const double* __restrict__ cams,
-    double* __restrict__ delta_c, double* __restrict__ cams_new, T* __restrict__ campre_new,
-    long long* __restrict__ dbg /* optional cycle stamps (diagnostic runs only) */) {
+    LMState* __restrict__ st, double* __restrict__ D2c, const ParamPtrs<T>* __restrict__ pp,
+    double* __restrict__ delta_c, long long* __restrict__ dbg /* optional cycle stamps (diagnostic runs only) */) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (st->status >= 0) return;
+  const double* __restrict__ cams = pp->cams;
+  double* __restrict__ cams_new = pp->cams_new;
+  T* __restrict__ campre_new = pp->campre_new;
   int nstamp = 0;
 #define CHOL_STAMP() do { if (dbg && threadIdx.x == 0) dbg[nstamp] = clock64(); ++nstamp; } while (0)
   CHOL_STAMP();

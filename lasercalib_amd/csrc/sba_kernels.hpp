@@ -29,6 +29,35 @@ constexpr int GROUP_ROWS = GROUP_CAMS * NCP;   // 176
 constexpr int GROUP_TILES = GROUP_ROWS / 16;   // 11
 constexpr int NSCAL = 8;
 
+// Current / trial parameter buffers.  The table lives in device memory and k_decide swaps its two halves when a
+// step is accepted, so the host never has to learn the outcome of an iteration before enqueueing the next one.
+template <typename T> struct ParamPtrs {
+  double* cams; double* pts; T* ptsT; T* campre;                 // current point x
+  double* cams_new; double* pts_new; T* ptsT_new; T* campre_new; // trial point x + delta
+};
+
+struct LMState {
+  double lam, nu;
+  double cost, cost_new, pred, rho, actual;
+  double step_norm, x_norm, gnorm;
+  double ftol, xtol, gtol;
+  double pred_c, dx2_c, x2_c, gmax_c;
+  double lam_min, lam_max;
+  long long nfev, njev, max_nfev;
+  int status;        // -1: keep iterating; else scipy status code.  Every LM kernel is a no-op once it is >= 0.
+  int accepted;      // decision of the last trial
+  int chol_fail;
+  int fresh;         // a new linearization is waiting to be absorbed into the camera scaling
+  int iter, n_accepted;
+  int free_cams;     // 0: points-only mode
+  int need_lin;      // the next linearize launches do work (set by k_decide: accepted, or bench's always_relinearize)
+  int always_relin;
+  int max_iter;      // > 0: stop (status 0) after this many trial steps
+  int cur;           // parity of accepted steps (which host-side buffer pair is "current")
+  int pad;
+};
+__device__ inline bool lm_done(const LMState* st) { return st != nullptr && st->status >= 0; }
+
 template <typename T> struct Vec2;
 template <> struct Vec2<double> { using type = double2; };
 template <> struct Vec2<float> { using type = float2; };
@@ -216,16 +245,18 @@ __global__ __launch_bounds__(PM_BLOCK) void k_resjac(
 // cost partial and max|gp| partial.
 template <typename T>
 __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points(
-    const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
+    const ParamPtrs<T>* __restrict__ pp, const LMState* __restrict__ st, int C,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start,
     const int32_t* __restrict__ blk_pt, double* __restrict__ V, double* __restrict__ gp,
     double* __restrict__ D2p, double* __restrict__ cost_part, double* __restrict__ gmax_part) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (st && (st->status >= 0 || !st->need_lin)) return;
+  const T* __restrict__ campre = pp->campre;
+  const T* __restrict__ ptsT = pp->ptsT;
   double* s_red = reinterpret_cast<double*>(smem);              // [256][9]
   T* s_cam = reinterpret_cast<T*>(s_red + PM_BLOCK * 9);
   __shared__ double s_scr[PM_BLOCK / 64];
-  __shared__ int s_pt_lo;
   stage_campre(campre, s_cam, C);
   const int p_lo = blk_pt[blockIdx.x], p_hi = blk_pt[blockIdx.x + 1];
   const int o_lo = pt_start[p_lo], o_hi = pt_start[p_hi];
@@ -274,7 +305,6 @@ __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points(
   const double cs = block_sum(sq, s_scr);
   const double gm = block_max(gmax, s_scr);
   if (threadIdx.x == 0) { cost_part[blockIdx.x] = 0.5 * cs; gmax_part[blockIdx.x] = gm; }
-  (void)s_pt_lo;
 }
 
 // ------------------------------------------------------------------ MFMA wrappers (16x16x4, A and B one value per lane)
@@ -303,7 +333,7 @@ template <> struct Mfma<float> {
 // (16x16) in 4 accumulator registers.  No shuffles, no atomics; one 16x16 partial per wave.
 template <typename T>
 __global__ __launch_bounds__(256) void k_linearize_cams(
-    const T* __restrict__ campre, const T* __restrict__ ptsT,
+    const ParamPtrs<T>* __restrict__ pp, const LMState* __restrict__ st,
     const typename Vec2<T>::type* __restrict__ uv_cm, const T* __restrict__ w_cm,
     const int32_t* __restrict__ pi_cm, const int32_t* __restrict__ chunk_cam,
     const int32_t* __restrict__ chunk_begin, const int32_t* __restrict__ chunk_end,
@@ -312,6 +342,9 @@ __global__ __launch_bounds__(256) void k_linearize_cams(
   __shared__ T s_tile[4][16 * LD];
   __shared__ T s_cam[CAMPRE];
   using M_ = Mfma<T>;
+  if (st && (st->status >= 0 || !st->need_lin)) return;
+  const T* __restrict__ campre = pp->campre;
+  const T* __restrict__ ptsT = pp->ptsT;
   const int chunk = blockIdx.x;
   const int cam = chunk_cam[chunk];
   const int beg = chunk_begin[chunk], end = chunk_end[chunk];
@@ -362,8 +395,10 @@ __global__ __launch_bounds__(256) void k_linearize_cams(
 // (4 groups x 256 entries; group g takes chunks g, g+4, ... ; groups are folded through LDS in a fixed order).
 __global__ __launch_bounds__(1024) void k_reduce_cams(const double* __restrict__ Upart,
                                                       const int32_t* __restrict__ cam_chunk_start /*C+1*/,
-                                                      double* __restrict__ U, double* __restrict__ gc) {
+                                                      double* __restrict__ U, double* __restrict__ gc,
+                                                      const LMState* __restrict__ st) {
   __shared__ double s_p[4][256];
+  if (st && (st->status >= 0 || !st->need_lin)) return;
   const int c = blockIdx.x;
   const int e = threadIdx.x & 255, g = threadIdx.x >> 8;
   const int a = cam_chunk_start[c], b = cam_chunk_start[c + 1];
@@ -388,10 +423,10 @@ __global__ __launch_bounds__(1024) void k_reduce_cams(const double* __restrict__
 constexpr int PF = 12;
 template <typename T>
 __global__ void k_point_factor(const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
-                               const double* __restrict__ lam_ptr, int N, T* __restrict__ pf) {
+                               const LMState* __restrict__ st, int N, T* __restrict__ pf) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= N) return;
-  const double lam = *lam_ptr;
+  if (p >= N || st->status >= 0) return;
+  const double lam = st->lam;
   double v6[6], li[6];
   v6[0] = V[(size_t)p * 6 + 0] + lam * fmax_pos(D2p[(size_t)p * 3 + 0]);
   v6[1] = V[(size_t)p * 6 + 1];
@@ -506,7 +541,7 @@ __device__ inline void schur_store_diag(T* __restrict__ slab, int lane, const ty
 
 template <typename T, bool DIAG>
 __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
-    const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
+    const ParamPtrs<T>* __restrict__ pp, const LMState* __restrict__ st, int C,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start, int N,
     const T* __restrict__ pf, const int32_t* __restrict__ pair_ga, const int32_t* __restrict__ pair_gb,
@@ -517,6 +552,9 @@ __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
   using Cfg = SchurCfg<T, DIAG>;
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, NCW = Cfg::NCW, MAXSLOT = Cfg::MAXSLOT, NTILE = Cfg::NTILE;
   constexpr int PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF;
+  if (st->status >= 0) return;
+  const T* __restrict__ campre = pp->campre;
+  const T* __restrict__ ptsT = pp->ptsT;
   const int pair = pair0 + blockIdx.y;
   const int ga = pair_ga[pair], gb = pair_gb[pair];
   const int camA0 = ga * GROUP_CAMS, camB0 = gb * GROUP_CAMS;

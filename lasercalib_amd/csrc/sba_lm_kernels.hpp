@@ -8,23 +8,6 @@
 
 namespace sba {
 
-struct LMState {
-  double lam, nu;
-  double cost, cost_new, pred, rho, actual;
-  double step_norm, x_norm, gnorm;
-  double ftol, xtol, gtol;
-  double pred_c, dx2_c, x2_c, gmax_c;
-  double lam_min, lam_max;
-  long long nfev, njev, max_nfev;
-  int status;        // -1: keep iterating; else scipy status code
-  int accepted;      // decision of the last trial
-  int chol_fail;
-  int fresh;         // a new linearization is waiting to be absorbed into the camera scaling
-  int iter, n_accepted;
-  int free_cams;     // 0: points-only mode
-  int pad;
-};
-
 constexpr int CHOL_THREADS = 1024;
 constexpr int CHOL_LDS_MAX_N = 176;    // packed lower triangle of 176x176 doubles = 124.6 KB of the 160 KB LDS
 
@@ -39,9 +22,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_build_exchange(
     const T* __restrict__ slabs, const double* __restrict__ bpart, int ksplit, const int32_t* __restrict__ pair_ga,
     const int32_t* __restrict__ pair_gb, int npairs, const double* __restrict__ U, const double* __restrict__ gc,
-    const double* __restrict__ cost_part, int n_cost_part, int C, int free_cams, double* __restrict__ E) {
+    const double* __restrict__ cost_part, int n_cost_part, int C, int free_cams, double* __restrict__ E,
+    const LMState* __restrict__ st) {
   using M_ = Mfma<T>;
   __shared__ double s_p[4][64];
+  if (st->status >= 0) return;
   __shared__ double scr[4];
   constexpr int NT = GROUP_TILES * GROUP_TILES;
   const int n = C * NCP;
@@ -134,9 +119,13 @@ struct TriGlobal {
 template <bool LDSMODE, typename T>
 __global__ __launch_bounds__(CHOL_THREADS) void k_cholesky_solve(
     double* __restrict__ E /* summed exchange buffer; S is destroyed in global mode */, int C,
-    LMState* __restrict__ st, double* __restrict__ D2c, const double* __restrict__ cams,
-    double* __restrict__ delta_c, double* __restrict__ cams_new, T* __restrict__ campre_new) {
+    LMState* __restrict__ st, double* __restrict__ D2c, const ParamPtrs<T>* __restrict__ pp,
+    double* __restrict__ delta_c) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (st->status >= 0) return;
+  const double* __restrict__ cams = pp->cams;
+  double* __restrict__ cams_new = pp->cams_new;
+  T* __restrict__ campre_new = pp->campre_new;
   __shared__ double s_y[GROUP_ROWS * 8 > 1408 ? GROUP_ROWS * 8 : 1408];   // rhs / solution, n <= 1408
   __shared__ double s_piv;
   __shared__ int s_fail;
@@ -232,6 +221,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_cholesky_solve(
 
 // points-only mode: no camera system.  Zero step for the cameras, cost from the partials.
 __global__ void k_nocam_step(LMState* __restrict__ st, const double* __restrict__ E, int n) {
+  if (st->status >= 0) return;
   if (threadIdx.x == 0) {
     st->cost = E[(size_t)n * n + 3 * n];
     st->pred_c = 0; st->dx2_c = 0; st->x2_c = 0; st->gmax_c = 0; st->chol_fail = 0; st->fresh = 0;
@@ -246,14 +236,19 @@ __global__ void k_nocam_step(LMState* __restrict__ st, const double* __restrict_
 // partials per block: trial_part[4][nblk] = cost_new, pred_p, |delta_p|^2, |X|^2
 template <typename T>
 __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
-    const T* __restrict__ campre, const T* __restrict__ campre_new, int C, const double* __restrict__ pts,
-    const T* __restrict__ ptsT, const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
+    const ParamPtrs<T>* __restrict__ pp, int C, const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start,
     const int32_t* __restrict__ blk_pt,
     const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
-    const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ pts_new,
-    T* __restrict__ ptsT_new, double* __restrict__ trial_part, int nblk) {
+    const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ trial_part, int nblk) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (st->status >= 0) return;
+  const T* __restrict__ campre = pp->campre;
+  const T* __restrict__ campre_new = pp->campre_new;
+  const double* __restrict__ pts = pp->pts;
+  const T* __restrict__ ptsT = pp->ptsT;
+  double* __restrict__ pts_new = pp->pts_new;
+  T* __restrict__ ptsT_new = pp->ptsT_new;
   double* s_t = reinterpret_cast<double*>(smem);          // [256][3]
   double* s_xn = s_t + PM_BLOCK * 3;                      // [256][3] new point coordinates (per local point)
   T* s_cam = reinterpret_cast<T*>(s_xn + PM_BLOCK * 3);   // [C][CAMPRE] current
@@ -346,6 +341,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
 __global__ void k_trial_scalars(const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
                                 int nblk, const LMState* __restrict__ st, double* __restrict__ scal) {
   __shared__ double scr[4];
+  if (st->status >= 0) return;
   double a = 0, b = 0, c = 0, d = 0, g = 0;
   for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
     a += trial_part[i]; b += trial_part[nblk + i]; c += trial_part[2 * nblk + i]; d += trial_part[3 * nblk + i];
@@ -358,14 +354,37 @@ __global__ void k_trial_scalars(const double* __restrict__ trial_part, const dou
   }
 }
 
-// ------------------------------------------------------------------ accept / reject / terminate (1 thread)
-__global__ void k_decide(LMState* __restrict__ st, const double* __restrict__ scal_all, int n_ranks) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// ------------------------------------------------------------------ accept / reject / terminate
+// One iteration-log row per trial step, same columns scipy prints with verbose=2 (layout = sba_lm_iter_log).
+struct LMLogRow { int iteration; int accepted; long long nfev; double cost, cost_reduction, step_norm, optimality, lambda, rho; };
+
+// scal_all: n_ranks x 8 scalars (already gathered), or -- single rank -- nullptr, in which case the block folds the
+// per-block partials itself (what k_trial_scalars does for the multi-rank path) and no separate launch is needed.
+template <typename T>
+__global__ __launch_bounds__(256) void k_decide(LMState* __restrict__ st, ParamPtrs<T>* __restrict__ pp,
+                                                const double* __restrict__ scal_all, int n_ranks,
+                                                const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
+                                                int nblk, LMLogRow* __restrict__ log, int log_cap) {
+  __shared__ double scr[4];
+  if (st->status >= 0) return;
   double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
-  for (int r = 0; r < n_ranks; ++r) {
-    const double* s = scal_all + (size_t)r * NSCAL;
-    cost_new += s[0]; pred += s[1]; dx2 += s[2]; x2 += s[3];
-    gmax = fmax(gmax, s[4]); failv = fmax(failv, s[5]);
+  if (scal_all == nullptr) {
+    double a = 0, b = 0, c = 0, d = 0, g = 0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+      a += trial_part[i]; b += trial_part[nblk + i]; c += trial_part[2 * nblk + i]; d += trial_part[3 * nblk + i];
+      g = fmax(g, gmax_part[i]);
+    }
+    cost_new = block_sum(a, scr); pred = block_sum(b, scr); dx2 = block_sum(c, scr); x2 = block_sum(d, scr);
+    gmax = block_max(g, scr);
+    failv = (double)st->chol_fail;
+  }
+  if (threadIdx.x != 0) return;
+  if (scal_all != nullptr) {
+    for (int r = 0; r < n_ranks; ++r) {
+      const double* s = scal_all + (size_t)r * NSCAL;
+      cost_new += s[0]; pred += s[1]; dx2 += s[2]; x2 += s[3];
+      gmax = fmax(gmax, s[4]); failv = fmax(failv, s[5]);
+    }
   }
   pred += st->pred_c; dx2 += st->dx2_c; x2 += st->x2_c; gmax = fmax(gmax, st->gmax_c);
   st->gnorm = gmax;
@@ -374,37 +393,53 @@ __global__ void k_decide(LMState* __restrict__ st, const double* __restrict__ sc
   st->cost_new = cost_new;
   st->pred = pred;
   st->iter += 1;
-  if (gmax < st->gtol) {                      // scipy trf.py:452 tests this before taking a step
-    st->status = 1; st->accepted = 0; st->actual = 0; st->rho = 0;
-    return;
-  }
-  st->nfev += 1;
-  const bool ok = !(failv > 0) && isfinite(cost_new) && pred > 0;
-  const double actual = ok ? st->cost - cost_new : -1.0;
-  const double rho = ok ? actual / pred : -1.0;
-  st->actual = actual; st->rho = rho;
   int status = -1;
-  if (ok) {                                    // scipy common.py:705-717
-    const bool f_ok = actual < st->ftol * st->cost && rho > 0.25;
-    const bool x_ok = sqrt(dx2) < st->xtol * (st->xtol + sqrt(x2));
-    status = (f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : -1;
-  }
-  if (actual > 0) {
-    const double t = 2.0 * rho - 1.0;
-    double l = st->lam * fmax(1.0 / 3.0, 1.0 - t * t * t);
-    st->lam = fmin(fmax(l, st->lam_min), st->lam_max);
-    st->nu = 2.0;
-    st->accepted = 1;
-    st->n_accepted += 1;
-    st->cost = cost_new;        // refreshed again from the exchange buffer after the next linearization
-    st->njev += 1;              // the accepted point gets a new Jacobian (scipy counts it the same way)
-    st->fresh = 1;
+  int accepted = 0;
+  double actual = 0, rho = 0;
+  if (gmax < st->gtol) {                      // scipy trf.py:452 tests this before taking a step
+    status = 1;
   } else {
-    st->lam = fmin(st->lam * st->nu, st->lam_max);
-    st->nu *= 2.0;
-    st->accepted = 0;
+    st->nfev += 1;
+    const bool ok = !(failv > 0) && isfinite(cost_new) && pred > 0;
+    actual = ok ? st->cost - cost_new : -1.0;
+    rho = ok ? actual / pred : -1.0;
+    if (ok) {                                  // scipy common.py:705-717
+      const bool f_ok = actual < st->ftol * st->cost && rho > 0.25;
+      const bool x_ok = sqrt(dx2) < st->xtol * (st->xtol + sqrt(x2));
+      status = (f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : -1;
+    }
+    if (actual > 0) {
+      const double t = 2.0 * rho - 1.0;
+      const double l = st->lam * fmax(1.0 / 3.0, 1.0 - t * t * t);
+      st->lam = fmin(fmax(l, st->lam_min), st->lam_max);
+      st->nu = 2.0;
+      accepted = 1;
+      st->n_accepted += 1;
+      st->cost = cost_new;        // refreshed again from the exchange buffer after the next linearization
+      st->njev += 1;              // the accepted point gets a new Jacobian (scipy counts it the same way)
+      st->fresh = 1;
+      st->cur ^= 1;
+      ParamPtrs<T> q = *pp;       // the trial point becomes the current one
+      ParamPtrs<T> r;
+      r.cams = q.cams_new; r.pts = q.pts_new; r.ptsT = q.ptsT_new; r.campre = q.campre_new;
+      r.cams_new = q.cams; r.pts_new = q.pts; r.ptsT_new = q.ptsT; r.campre_new = q.campre;
+      *pp = r;
+    } else {
+      st->lam = fmin(st->lam * st->nu, st->lam_max);
+      st->nu *= 2.0;
+    }
+    if (status < 0 && st->nfev >= st->max_nfev) status = 0;
   }
-  if (status < 0 && st->nfev >= st->max_nfev) status = 0;
+  if (status < 0 && st->max_iter > 0 && st->iter >= st->max_iter) status = 0;
+  st->accepted = accepted; st->actual = actual; st->rho = rho;
+  st->need_lin = (accepted || st->always_relin) ? 1 : 0;
+  if (log && st->iter <= log_cap) {
+    LMLogRow row;
+    row.iteration = st->iter; row.accepted = accepted; row.nfev = st->nfev; row.cost = st->cost;
+    row.cost_reduction = actual; row.step_norm = st->step_norm; row.optimality = gmax; row.lambda = st->lam; row.rho = rho;
+    log[st->iter - 1] = row;
+  }
+  __threadfence();
   st->status = status;
 }
 
