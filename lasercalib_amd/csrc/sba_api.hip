@@ -365,7 +365,7 @@ struct Engine : EngineBase {
     const size_t lds = (size_t)PM_BLOCK * 6 * sizeof(double) + (2 * (size_t)C * CAMPRE + (size_t)C * NCP) * sizeof(T);
     hipLaunchKernelGGL(k_backsub_trial<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, d_pp.p, C,
                        uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_pt.p,
-                       V.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nblk);
+                       pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nblk);
   }
 
   // ------------------------------------------------------------------ model evaluation entry points
@@ -485,7 +485,7 @@ struct Engine : EngineBase {
     {
       const int fc = (int)h_state->free_cams;
       const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 63) / 64 : 0) + 1;
-      hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(256), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
+      hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, npairs, U.p, gc.p, cost_part.p, nblk, C, fc, E, d_state.p);
     }
     prof_end(KP_REDUCE);
@@ -523,6 +523,8 @@ struct Engine : EngineBase {
       prof_end(KP_CHOL);
     } else {
       hipLaunchKernelGGL(k_nocam_step, dim3(1), dim3(64), 0, stream, d_state.p, E, n);
+      if (N > 0)
+        hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
     }
     prof_begin(KP_BACKSUB);
     launch_backsub_trial();

@@ -14,20 +14,21 @@ constexpr int CHOL_LDS_MAX_N = 176;    // packed lower triangle of 176x176 doubl
 // ------------------------------------------------------------------ reduced system assembly
 // One launch builds the whole exchange buffer E = [S | rhs | diagU | gc | cost]:
 //   blocks [0, 4*NT*npairs):   S(i,j) = [same camera] U(i,j) - sum_ks slab      (NT = 121 tile slots per pair)
-//       block = (pair, tile, quarter of the tile's 256 entries); 256 threads = 4 k-split groups x 64 entries,
-//       group g sums slabs g, g+4, ...; the groups are folded through LDS in a fixed order (deterministic).
+//       block = (pair, tile, quarter of the tile's 256 entries); 1024 threads = 16 k-split groups x 64 entries,
+//       group g sums slabs g, g+16, ...; the groups are folded through LDS in a fixed order (deterministic).
 //   blocks [.., +nrow_blocks): rhs = -gc + sum_ks bpart ; diagU ; gc           (64 rows x 4 k-split groups)
 //   last block:                cost = sum cost_part
 template <typename T>
-__global__ __launch_bounds__(256) void k_build_exchange(
+__global__ __launch_bounds__(1024) void k_build_exchange(
     const T* __restrict__ slabs, const double* __restrict__ bpart, int ksplit, const int32_t* __restrict__ pair_ga,
     const int32_t* __restrict__ pair_gb, int npairs, const double* __restrict__ U, const double* __restrict__ gc,
     const double* __restrict__ cost_part, int n_cost_part, int C, int free_cams, double* __restrict__ E,
     const LMState* __restrict__ st) {
   using M_ = Mfma<T>;
-  __shared__ double s_p[4][64];
+  constexpr int NG = 16;
+  __shared__ double s_p[NG][64];
   if (st->status >= 0) return;
-  __shared__ double scr[4];
+  __shared__ double scr[16];
   constexpr int NT = GROUP_TILES * GROUP_TILES;
   const int n = C * NCP;
   const int tile_blocks = free_cams ? 4 * NT * npairs : 0;
@@ -52,17 +53,19 @@ __global__ __launch_bounds__(256) void k_build_exchange(
     const T* src = slabs + (size_t)pair * ksplit * stride + (size_t)t * 256 + e;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int k = g;
-    for (; k + 12 < ksplit; k += 16) {
+    for (; k + 3 * NG < ksplit; k += 4 * NG) {
       s0 += (double)src[(size_t)k * stride];
-      s1 += (double)src[(size_t)(k + 4) * stride];
-      s2 += (double)src[(size_t)(k + 8) * stride];
-      s3 += (double)src[(size_t)(k + 12) * stride];
+      s1 += (double)src[(size_t)(k + NG) * stride];
+      s2 += (double)src[(size_t)(k + 2 * NG) * stride];
+      s3 += (double)src[(size_t)(k + 3 * NG) * stride];
     }
-    for (; k < ksplit; k += 4) s0 += (double)src[(size_t)k * stride];
+    for (; k < ksplit; k += NG) s0 += (double)src[(size_t)k * stride];
     s_p[g][l64] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && i < n && j < n) {
-      const double s = (s_p[0][l64] + s_p[1][l64]) + (s_p[2][l64] + s_p[3][l64]);
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) s += s_p[q][l64];
       const int ci_ = i / NCP, cj_ = j / NCP;
       double v = -s;
       if (ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
@@ -83,14 +86,16 @@ __global__ __launch_bounds__(256) void k_build_exchange(
       const double* src = bpart + (size_t)grp * ksplit * GROUP_ROWS + rho;
       double b0 = 0, b1 = 0;
       int k = g;
-      for (; k + 4 < ksplit; k += 8) { b0 += src[(size_t)k * GROUP_ROWS]; b1 += src[(size_t)(k + 4) * GROUP_ROWS]; }
+      for (; k + NG < ksplit; k += 2 * NG) { b0 += src[(size_t)k * GROUP_ROWS]; b1 += src[(size_t)(k + NG) * GROUP_ROWS]; }
       if (k < ksplit) b0 += src[(size_t)k * GROUP_ROWS];
       b = b0 + b1;
     }
     s_p[g][l64] = b;
     __syncthreads();
     if (g == 0 && i < n) {
-      const double bs = (s_p[0][l64] + s_p[1][l64]) + (s_p[2][l64] + s_p[3][l64]);
+      double bs = 0;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) bs += s_p[q][l64];
       const int c = i / NCP, e = i - c * NCP;
       rhs[i] = -gc[i] + bs;
       dU[i] = U[(size_t)c * 121 + e * NCP + e];
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
     const ParamPtrs<T>* __restrict__ pp, int C, const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start,
     const int32_t* __restrict__ blk_pt,
-    const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
+    const T* __restrict__ pf, const double* __restrict__ gp, const double* __restrict__ D2p,
     const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ trial_part, int nblk) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (st->status >= 0) return;
@@ -263,6 +268,18 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
   const int p_lo = blk_pt[blockIdx.x], p_hi = blk_pt[blockIdx.x + 1];
   const int o_lo = pt_start[p_lo], o_hi = pt_start[p_hi];
   const int nobs = o_hi - o_lo, npts = p_hi - p_lo;
+  // per-point operands of phase 2 (thread q < npts owns point p_lo + q): requested now, consumed after phase 1
+  const bool own_pt = (int)threadIdx.x < npts;
+  const size_t myq = (size_t)(p_lo + (own_pt ? (int)threadIdx.x : 0));
+  T f[PF];
+  double g0 = 0, g1 = 0, g2 = 0, dd0 = 1, dd1 = 1, dd2 = 1, X0 = 0, X1 = 0, X2 = 0;
+  if (own_pt) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) f[k] = pf[myq * PF + k];
+    g0 = gp[myq * 3]; g1 = gp[myq * 3 + 1]; g2 = gp[myq * 3 + 2];
+    dd0 = fmax_pos(D2p[myq * 3]); dd1 = fmax_pos(D2p[myq * 3 + 1]); dd2 = fmax_pos(D2p[myq * 3 + 2]);
+    X0 = pts[myq * 3]; X1 = pts[myq * 3 + 1]; X2 = pts[myq * 3 + 2];
+  }
   __syncthreads();
   int my_p = -1, my_c = 0;
   typename Vec2<T>::type my_uv; my_uv.x = 0; my_uv.y = 0;
@@ -289,32 +306,30 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
   }
   __syncthreads();
   double pred = 0, dx2 = 0, x2 = 0;
-  for (int q = threadIdx.x; q < npts; q += PM_BLOCK) {
-    const size_t p = (size_t)(p_lo + q);
+  if (own_pt) {      // a point-aligned block holds at most 256 points: one per thread
+    const int q = threadIdx.x;
+    const size_t p = myq;
     const int a = pt_start[p] - o_lo, b = pt_start[p + 1] - o_lo;
     double t0 = 0, t1 = 0, t2 = 0;
     for (int k = a; k < b; ++k) { t0 += s_t[k * 3]; t1 += s_t[k * 3 + 1]; t2 += s_t[k * 3 + 2]; }
-    const double g0 = gp[p * 3], g1 = gp[p * 3 + 1], g2 = gp[p * 3 + 2];
-    const double d0 = fmax_pos(D2p[p * 3]), d1 = fmax_pos(D2p[p * 3 + 1]), d2 = fmax_pos(D2p[p * 3 + 2]);
-    double v6[6], li[6];
-    v6[0] = V[p * 6] + lam * d0; v6[1] = V[p * 6 + 1]; v6[2] = V[p * 6 + 2];
-    v6[3] = V[p * 6 + 3] + lam * d1; v6[4] = V[p * 6 + 4]; v6[5] = V[p * 6 + 5] + lam * d2;
     double e0 = 0, e1 = 0, e2 = 0;
-    if (chol3_inv<double>(v6, li)) {
-      const double b0 = -(g0 + t0), b1 = -(g1 + t1), b2 = -(g2 + t2);
-      const double y0 = li[0] * b0, y1 = li[1] * b0 + li[2] * b1, y2 = li[3] * b0 + li[4] * b1 + li[5] * b2;
-      e0 = li[0] * y0 + li[1] * y1 + li[3] * y2;     // L^-T y
-      e1 = li[2] * y1 + li[4] * y2;
-      e2 = li[5] * y2;
+    if (f[9] != (T)0) {     // delta = -(V + lam D)^-1 (g + t) = -L^-T ( z + L^-1 t ),  z = L^-1 g from k_point_factor
+      const double l0 = f[0], l1 = f[1], l2 = f[2], l3 = f[3], l4 = f[4], l5 = f[5];
+      const double y0 = -((double)f[6] + l0 * t0);
+      const double y1 = -((double)f[7] + l1 * t0 + l2 * t1);
+      const double y2 = -((double)f[8] + l3 * t0 + l4 * t1 + l5 * t2);
+      e0 = l0 * y0 + l1 * y1 + l3 * y2;     // L^-T y
+      e1 = l2 * y1 + l4 * y2;
+      e2 = l5 * y2;
     }
-    const double X0 = pts[p * 3], X1 = pts[p * 3 + 1], X2 = pts[p * 3 + 2];
     const double n0 = X0 + e0, n1 = X1 + e1, n2 = X2 + e2;
     pts_new[p * 3] = n0; pts_new[p * 3 + 1] = n1; pts_new[p * 3 + 2] = n2;
     ptsT_new[p * 3] = (T)n0; ptsT_new[p * 3 + 1] = (T)n1; ptsT_new[p * 3 + 2] = (T)n2;
     s_xn[q * 3] = n0; s_xn[q * 3 + 1] = n1; s_xn[q * 3 + 2] = n2;
-    pred += 0.5 * (e0 * (lam * d0 * e0 - g0) + e1 * (lam * d1 * e1 - g1) + e2 * (lam * d2 * e2 - g2));
-    dx2 += e0 * e0 + e1 * e1 + e2 * e2;
-    x2 += X0 * X0 + X1 * X1 + X2 * X2;
+    const double lam_ = lam;
+    pred = 0.5 * (e0 * (lam_ * dd0 * e0 - g0) + e1 * (lam_ * dd1 * e1 - g1) + e2 * (lam_ * dd2 * e2 - g2));
+    dx2 = e0 * e0 + e1 * e1 + e2 * e2;
+    x2 = X0 * X0 + X1 * X1 + X2 * X2;
   }
   __syncthreads();
   double sq = 0;
