@@ -56,8 +56,12 @@ typedef struct {
   int64_t n_obs;         /* M */
   int32_t dtype;         /* sba_dtype: arithmetic type of the per-observation math               */
   int32_t device;        /* HIP device ordinal                                                    */
-  void*   stream;        /* hipStream_t to run on, or NULL to create a private stream             */
-  int32_t reserved[4];
+  void*   stream;        /* hipStream_t to run on (see use_stream)                                */
+  int32_t use_stream;    /* 0: ignore `stream`, create a private non-blocking stream.
+                            1: run on `stream` exactly as given -- NULL then means the legacy default
+                               stream (what torch.cuda.current_stream() is unless the caller changed it),
+                               so that the caller's collectives are ordered with the engine's kernels */
+  int32_t reserved[3];
 } sba_problem_desc;
 
 typedef struct {
@@ -168,6 +172,8 @@ int sba_lm_decide(sba_handle* h, const double* scalars_all_dev /*n_ranks*8*/, in
 int sba_lm_decide_async(sba_handle* h, const double* scalars_all_dev /* NULL when n_ranks == 1 */, int32_t n_ranks);
 int sba_lm_poll(sba_handle* h, int32_t* status_out, int32_t* iterations_out);
 int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report);
+/* Rows of the per-iteration log collected so far (filled in by sba_lm_poll / sba_lm_finish). */
+int sba_lm_get_log(sba_handle* h, sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * Runs `reps` launches of one named kernel on the current parameters and returns the mean launch

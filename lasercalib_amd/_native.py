@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "sba_create", "sba_upload", "sba_set_params", "sba_get_params", "sba_destroy",
     "sba_get_gradient", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
-    "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_finish", "sba_time_kernel", "sba_get_kernel_profile",
+    "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_finish", "sba_lm_get_log", "sba_time_kernel", "sba_get_kernel_profile",
 )
 
 
@@ -35,7 +35,7 @@ class SbaError(RuntimeError):
 class ProblemDesc(C.Structure):
     _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int64),
                 ("dtype", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
-                ("reserved", C.c_int32 * 4)]
+                ("use_stream", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class LmOpts(C.Structure):
@@ -100,6 +100,7 @@ def load():
         "sba_lm_decide_async": (C.c_int, [H, C.c_void_p, C.c_int32]),
         "sba_lm_poll": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "sba_lm_finish": (C.c_int, [H, dp, dp, C.POINTER(LmReport)]),
+        "sba_lm_get_log": (C.c_int, [H, C.POINTER(LmIterLog), C.c_int32, C.POINTER(C.c_int32)]),
         "sba_time_kernel": (C.c_int, [H, C.c_char_p, C.c_int32, dp]),
         "sba_get_kernel_profile": (C.c_int, [H, dp, ip]),
     }
@@ -193,8 +194,9 @@ class Problem:
             if w.shape[0] != self.M:
                 raise ValueError("pointWeights must have one entry per observation")
         self.dtype = dtype_code(dtype)
+        # stream=None: private stream.  stream=<int handle>: run on it (0 = the legacy default stream).
         desc = ProblemDesc(self.C, self.N, self.M, self.dtype, device,
-                           C.c_void_p(stream) if stream else None, (C.c_int32 * 4)())
+                           C.c_void_p(stream) if stream else None, 0 if stream is None else 1, (C.c_int32 * 3)())
         h = C.c_void_p()
         _check(lib.sba_create(C.byref(desc), C.byref(h)))
         self._h = h
@@ -311,6 +313,12 @@ class Problem:
         rep = LmReport()
         _check(self._lib.sba_lm_finish(self._h, _dptr(cams), _dptr(pts), C.byref(rep)), self._h)
         return cams, pts, rep
+
+    def iteration_log(self, capacity=4096):
+        log = (LmIterLog * capacity)()
+        rows = C.c_int32(0)
+        _check(self._lib.sba_lm_get_log(self._h, log, capacity, C.byref(rows)), self._h)
+        return [log[i] for i in range(min(rows.value, capacity))]
 
     # -- measurement
     PROFILE_SLOTS = ("linearize_points", "linearize_cams", "schur", "schur_reduce", "cholesky_solve", "backsub")

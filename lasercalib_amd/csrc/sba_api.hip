@@ -136,7 +136,7 @@ struct Engine : EngineBase {
   void init(const sba_problem_desc& d) {
     C = d.n_cams; N = d.n_points; M = d.n_obs; device = d.device; n = C * NCP;
     HIPCHK(hipSetDevice(device));
-    if (d.stream) { stream = reinterpret_cast<hipStream_t>(d.stream); own_stream = false; }
+    if (d.use_stream) { stream = reinterpret_cast<hipStream_t>(d.stream); own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(LMState), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_pp), sizeof(ParamPtrs<T>), hipHostMallocDefault));
@@ -903,6 +903,16 @@ int sba_lm_decide_async(sba_handle* h, const double* scalars_all_dev, int32_t n_
 int sba_lm_poll(sba_handle* h, int32_t* status_out, int32_t* iterations_out) {
   if (!h) return SBA_ERR_INVALID;
   return guarded(h, [&] { return DISPATCH(h, lm_poll(status_out, iterations_out)); });
+}
+int sba_lm_get_log(sba_handle* h, sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows) {
+  if (!h || !log_rows) return SBA_ERR_INVALID;
+  auto get = [&](auto* e) {
+    const int nrow = std::min<int>(log_capacity, (int)e->log.size());
+    if (log) for (int i = 0; i < nrow; ++i) log[i] = e->log[i];
+    *log_rows = (int32_t)e->log.size();
+    return (int)SBA_OK;
+  };
+  return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
 }
 int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report) {
   if (!h) return SBA_ERR_INVALID;

@@ -130,19 +130,25 @@ class SoloComm:
 
 # ----------------------------------------------------------------------------- the loop
 def run_lm(engine, comm, max_iter=0):
-    """Engine-agnostic sharded LM loop.  Returns (status, iterations)."""
+    """Engine-agnostic sharded LM loop.  Returns (status, iterations).
+
+    ``engine.batch`` iterations are enqueued between two polls of the engine's state: the HIP engine decides
+    accept / reject / terminate on the device (later launches of a finished solve are no-ops there, and the
+    collectives of such a tail still match on every rank because all ranks take identical decisions), so the
+    host does not synchronise with the GPU per iteration.
+    """
     status, it = None, 0
-    need_lin = True
+    batch = max(1, int(getattr(engine, "batch", 1)))
     while status is None:
-        if need_lin:
-            engine.linearize()
-        E = engine.form_reduced()
-        comm.all_reduce_sum(E)
-        sc = engine.solve_trial(E)
-        sc_all = comm.all_gather_rows(sc)
-        status, accepted = engine.decide(sc_all, comm.n)
-        need_lin = accepted or getattr(engine, "always_relinearize", False)
-        it += 1
+        todo = batch if not max_iter else max(1, min(batch, max_iter - it))
+        for _ in range(todo):
+            engine.linearize()                       # skipped inside the engine after a rejected step
+            E = engine.form_reduced()
+            comm.all_reduce_sum(E)
+            sc = engine.solve_trial(E)
+            sc_all = comm.all_gather_rows(sc)
+            engine.decide_async(sc_all, comm.n)
+        status, it = engine.poll()
         if status is None and max_iter and it >= max_iter:
             status = 0
     return status, it
@@ -165,7 +171,7 @@ class HipEngine:
         dev = torch.device("cuda", device)
         self.E = torch.empty(self.prob.exchange_size(), dtype=torch.float64, device=dev)
         self.sc = torch.empty(NSCALARS, dtype=torch.float64, device=dev)
-        self.log = []
+        self.batch = 1 if opts_kwargs.get("profile") else 4
         self.prob.lm_begin(self.opts)
 
     def linearize(self):
@@ -179,10 +185,12 @@ class HipEngine:
         self.prob.lm_solve_trial(E.data_ptr(), self.sc.data_ptr())
         return self.sc
 
-    def decide(self, sc_all, n_ranks):
-        status, acc, row = self.prob.lm_decide(sc_all.data_ptr(), n_ranks)
-        self.log.append(row)
-        return (None if status < 0 else status), acc
+    def decide_async(self, sc_all, n_ranks):
+        self.prob.lm_decide_async(sc_all.data_ptr(), n_ranks)
+
+    def poll(self):
+        status, iters = self.prob.lm_poll()
+        return (None if status < 0 else status), iters
 
     def finish(self):
         return self.prob.lm_finish()
@@ -208,6 +216,7 @@ def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device,
         cams_opt, pts_loc, rep = eng.finish()
         gc_loc, gp_loc = eng.prob.get_gradient()
         fvec_loc, cost_loc = eng.prob.residual()
+        log = eng.prob.iteration_log()
     finally:
         eng.close()
     gp_max = float(np.max(np.abs(gp_loc))) if gp_loc.size else 0.0
@@ -226,5 +235,5 @@ def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device,
         opt = max(opt, gpm)
     opt = max(opt, float(np.max(np.abs(gc))))
     rep.cost, rep.optimality, rep.status, rep.initial_cost = cost, opt, status, cost0
-    res, c, p = sba._package(mode, cams_opt, pts_opt, rep, eng.log, fvec, verbose if comm.r == 0 else 0)
+    res, c, p = sba._package(mode, cams_opt, pts_opt, rep, log, fvec, verbose if comm.r == 0 else 0)
     return res, c, p

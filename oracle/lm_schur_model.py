@@ -223,7 +223,19 @@ class ModelEngine:
     def exchange_size(self):
         return self.n * self.n + 3 * self.n + 1
 
+    batch = 1
+
+    def decide_async(self, scalars_all, n_ranks=None):
+        self._status, _ = self.decide(scalars_all, n_ranks)
+        self._iters = getattr(self, "_iters", 0) + 1
+        self.need_lin = self.accepted
+
+    def poll(self):
+        return self._status, self._iters
+
     def linearize(self):
+        if not getattr(self, "need_lin", True):
+            return
         res, Jc, Jp = residual_jacobian(self.cams, self.pts, self.uv, self.ci, self.pi, self.w)
         self.res = res
         self.U, self.gc, self.V, self.gp, self.W = normal_blocks(res, Jc, Jp, self.ci, self.pi, self.C, self.N)

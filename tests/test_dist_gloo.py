@@ -35,6 +35,9 @@ def _worker(rank, world, port, tag, q):
             full[p0:p0 + pl.shape[0]] = pl
             cost += c
         q.put((rank, status, iters, eng.cams.copy(), full, cost, eng.nfev))
+    except BaseException as e:          # never leave the parent waiting on the queue
+        q.put((rank, repr(e)))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -50,6 +53,7 @@ def test_two_rank_sharded_lm_matches_single_rank_and_reference(tag):
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    assert all(len(r) > 2 for r in results), results
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -24,6 +24,9 @@ def _worker(rank, world, port, tag, q):
         sba = PySBA(g[f"{tag}_cams0"].copy(), g[f"{tag}_pts0"].copy(), g[f"{tag}_uv"], g[f"{tag}_ci"], g[f"{tag}_pi"])
         res = sba.bundleAdjust(1e-4)
         q.put((rank, res.status, res.cost, res.nfev, sba.cameraArray.copy(), sba.points3D.copy(), res.fun.copy(), res.optimality))
+    except BaseException as e:          # never leave the parent waiting on the queue
+        q.put((rank, repr(e)))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -40,7 +43,8 @@ def test_sharded_gpu_solve_two_ranks(tag):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, tag, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    results = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    assert all(len(r) > 2 for r in results), results
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
