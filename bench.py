@@ -33,6 +33,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # f32-in MFMA = vector rate 157.3 TF; f64 MFMA is half that on CDNA4
+# HBM bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_*: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+# 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).  Valid for the default workload only
+# (16 cams x 50k points, f32, one GPU); other shapes report null.
+PMC_TRAFFIC_BYTES_16x50k_F32 = {"schur": 26.58e6, "resjac": 104.62e6, "linearize_points": 20.30e6,
+                                "linearize_cams": 15.53e6, "backsub": 22.26e6, "residual": 13.12e6}
 
 
 def parse():
@@ -183,6 +188,8 @@ def main():
     out = None
     if rank == 0:
         n = 11 * C
+        default_shape = (C == 16 and Np == 50000 and a.dtype == "f32" and world == 1)
+        traffic = lambda k: PMC_TRAFFIC_BYTES_16x50k_F32.get(k) if default_shape else None
         dominant = max(("schur", "linearize_cams", "linearize_points", "backsub", "cholesky_solve", "schur_reduce"), key=lambda k: kt[k])
         if dominant in ("cholesky_solve", "schur_reduce"):
             # latency-bound single-workgroup / reduction stages have no meaningful bandwidth roofline; report the
@@ -192,17 +199,17 @@ def main():
             flops = (n * (n + 1) / 2) * 3 * shard["pts"].shape[0] * 2          # symmetric S: n(n+1)/2 entries x K=3N x 2
             ach = flops / (kt["schur"] * 1e-6) / 1e12
             roof = {"kernel": "k_schur", "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[a.dtype],
-                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype], "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype], "traffic": traffic("schur"),
                     "algorithmic_flops_per_launch": flops, "launch_us": kt["schur"]}
         else:
             by = algorithmic_bytes_per_obs(dominant, s, C, shard["pts"].shape[0], M_local) * M_local
             ach = by / (kt[dominant] * 1e-6) / 1e9
             roof = {"kernel": "k_" + dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": by, "launch_us": kt[dominant]}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic(dominant), "algorithmic_bytes_per_launch": by, "launch_us": kt[dominant]}
         rj_bytes = algorithmic_bytes_per_obs("resjac", s, C, shard["pts"].shape[0], M_local) * M_local
         rj = {"kernel": "k_resjac", "bound": "hbm", "achieved": rj_bytes / (kt["resjac"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": rj_bytes / (kt["resjac"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "launch_us": kt["resjac"],
-              "algorithmic_bytes_per_launch": rj_bytes, "mobs_per_s": M_local / kt["resjac"]}
+              "algorithmic_bytes_per_launch": rj_bytes, "mobs_per_s": M_local / kt["resjac"], "traffic": traffic("resjac")}
         out = {
             "metric": "LM iters/sec and residual+Jacobian Mobs/s at 16 cams x 50k points",
             "value": M_total * a.steps / dt / 1e6,
