@@ -415,6 +415,28 @@ struct Engine : EngineBase {
     return SBA_OK;
   }
 
+  // shared intrinsics (pySBA.py:252-325): unknowns [f,k1,k2 | 6 extrinsics x C | 2 centre x C], pySBA.py:313 order
+  void build_tie_tables() {
+    n_tied = 3 + 8 * C;
+    std::vector<int32_t> tie(n), start(n_tied + 1, 0), idx(n), firstv(n_tied);
+    for (int c = 0; c < C; ++c)
+      for (int e = 0; e < NCP; ++e)
+        tie[c * NCP + e] = e < 6 ? 3 + 6 * c + e : e < 9 ? e - 6 : 3 + 6 * C + 2 * c + (e - 9);
+    for (int i = 0; i < n; ++i) start[tie[i] + 1]++;
+    for (int a = 0; a < n_tied; ++a) start[a + 1] += start[a];
+    std::vector<int32_t> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < n; ++i) idx[fill[tie[i]]++] = i;
+    for (int a = 0; a < n_tied; ++a) firstv[a] = idx[start[a]];
+    h_tie = tie;
+    tie_map.upload(tie, stream); tie_pre_start.upload(start, stream); tie_pre_idx.upload(idx, stream); tie_first.upload(firstv, stream);
+    E_tied.alloc((size_t)n_tied * n_tied + 3 * (size_t)n_tied + 1);
+    sync();
+  }
+  int n_tied = 0;
+  std::vector<int32_t> h_tie;
+  DevBuf<int32_t> tie_map, tie_pre_start, tie_pre_idx, tie_first;
+  DevBuf<double> E_tied;
+
   // ------------------------------------------------------------------ LM phases
   int64_t exchange_size() const { return (int64_t)n * n + 3 * (int64_t)n + 1; }
   static constexpr int LOG_CAP = 4096;
@@ -428,7 +450,10 @@ struct Engine : EngineBase {
     for (int k = 0; k < KP_N; ++k) { prof_us[k] = 0; prof_cnt[k] = 0; }
     pslot = 0;
     for (auto& u : pev_used) u = false;
-    if (opts.mode != SBA_MODE_FULL && opts.mode != SBA_MODE_POINTS_ONLY) { err = "unsupported mode"; return SBA_ERR_UNSUPPORTED; }
+    if (opts.mode != SBA_MODE_FULL && opts.mode != SBA_MODE_POINTS_ONLY && opts.mode != SBA_MODE_SHARED_INTR) {
+      err = "unsupported mode"; return SBA_ERR_UNSUPPORTED;
+    }
+    if (opts.mode == SBA_MODE_SHARED_INTR) build_tie_tables();
     // initial cost; scipy raises ValueError when it is not finite (least_squares.py:844-845)
     double c0 = 0;
     int rc = residual(nullptr, nullptr, &c0);
@@ -441,13 +466,13 @@ struct Engine : EngineBase {
     s.ftol = opts.ftol; s.xtol = opts.xtol; s.gtol = opts.gtol;
     s.lam_min = 1e-12; s.lam_max = 1e12;
     s.nfev = 1; s.njev = 1;
-    const long long nparam = (opts.mode == SBA_MODE_FULL ? (long long)n : 0) + 3LL * N;
+    const long long nparam = (opts.mode == SBA_MODE_FULL ? (long long)n : opts.mode == SBA_MODE_SHARED_INTR ? (long long)n_tied : 0) + 3LL * N;
     s.max_nfev = opts.max_nfev > 0 ? opts.max_nfev : 100 * nparam;
     s.status = -1; s.fresh = 1; s.need_lin = 1;
     s.always_relin = opts.always_relinearize ? 1 : 0;
     s.max_iter = opts.max_iter > 0 ? opts.max_iter : 0;
     s.cur = 0;
-    s.free_cams = (opts.mode == SBA_MODE_FULL) ? 1 : 0;
+    s.free_cams = (opts.mode == SBA_MODE_POINTS_ONLY) ? 0 : 1;
     *h_state = s;
     HIPCHK(hipMemcpyAsync(d_state.p, h_state, sizeof(LMState), hipMemcpyHostToDevice, stream));
     D2p.zero(stream); D2c.zero(stream); delta_c.zero(stream);
@@ -497,12 +522,21 @@ struct Engine : EngineBase {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     if (h_state->free_cams) {
       prof_begin(KP_CHOL);
-      if (n <= CHOL_LDS_MAX_N && !chol_old) {
-        const int nb = (n + CB - 1) / CB;
+      const bool tied = (opts.mode == SBA_MODE_SHARED_INTR);
+      const int n_sys = tied ? n_tied : n;
+      double* Esys = E;
+      if (tied) {   // collapse the camera system onto the tied unknowns
+        hipLaunchKernelGGL(k_tie_system, dim3(n_tied), dim3(256), 0, stream, E, n, n_tied, tie_pre_start.p, tie_pre_idx.p,
+                           E_tied.p, d_state.p);
+        Esys = E_tied.p;
+      }
+      if (n_sys <= CHOL_LDS_MAX_N && !chol_old) {
+        const int nb = (n_sys + CB - 1) / CB;
         const size_t lds = ((size_t)(nb * (nb + 1) / 2 + 2) * CBS + 3 * (size_t)nb * CB) * sizeof(double);
         if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }
-        hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_THREADS), lds, stream, E, C, d_state.p, D2c.p,
-                           d_pp.p, delta_c.p, chol_debug ? chol_dbg.p : nullptr);
+        hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
+                           d_pp.p, delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr,
+                           chol_debug ? chol_dbg.p : nullptr);
         if (chol_debug) {
           std::vector<long long> st(64);
           HIPCHK(hipMemcpyAsync(st.data(), chol_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
@@ -512,13 +546,13 @@ struct Engine : EngineBase {
           fprintf(stderr, " backsub %lld  epilogue %lld  total %lld\n", st[3 + 2 * nb] - st[2 + 2 * nb], st[4 + 2 * nb] - st[3 + 2 * nb], st[4 + 2 * nb] - st[0]);
           chol_debug = false;
         }
-      } else if (n <= CHOL_LDS_MAX_N) {
-        const size_t lds = (size_t)n * (n + 1) / 2 * sizeof(double);
-        hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, E, C, d_state.p, D2c.p,
-                           d_pp.p, delta_c.p);
+      } else if (n_sys <= CHOL_LDS_MAX_N) {
+        const size_t lds = (size_t)n_sys * (n_sys + 1) / 2 * sizeof(double);
+        hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
+                           d_pp.p, delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       } else {
-        hipLaunchKernelGGL((k_cholesky_solve<false, T>), dim3(1), dim3(CHOL_THREADS), 0, stream, E, C, d_state.p, D2c.p,
-                           d_pp.p, delta_c.p);
+        hipLaunchKernelGGL((k_cholesky_solve<false, T>), dim3(1), dim3(CHOL_THREADS), 0, stream, Esys, C, d_state.p, D2c.p,
+                           d_pp.p, delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       }
       prof_end(KP_CHOL);
     } else {
@@ -602,7 +636,13 @@ struct Engine : EngineBase {
     HIPCHK(hipGetLastError());
     double cost = 0;
     for (int i = 0; i < nblk; ++i) { gmax = std::max(gmax, gm[i]); cost += cp[i]; }
-    for (double v : gch) gmax = std::max(gmax, std::fabs(v));
+    if (opts.mode == SBA_MODE_SHARED_INTR && (int)h_tie.size() == n) {   // gradient in the tied unknowns
+      std::vector<double> gs(n_tied, 0.0);
+      for (int i = 0; i < n; ++i) gs[h_tie[i]] += gch[i];
+      for (double v : gs) gmax = std::max(gmax, std::fabs(v));
+    } else {
+      for (double v : gch) gmax = std::max(gmax, std::fabs(v));
+    }
     if (rep) {
       const LMState& s = *h_state;
       rep->cost = cost; rep->initial_cost = initial_cost; rep->optimality = gmax; rep->step_norm = s.step_norm;

@@ -75,7 +75,10 @@ template <typename T>
 __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
     const double* __restrict__ E /* summed exchange buffer [S | rhs | diagU | gc | cost] */, int C,
     LMState* __restrict__ st, double* __restrict__ D2c, const ParamPtrs<T>* __restrict__ pp,
-    double* __restrict__ delta_c, long long* __restrict__ dbg /* optional cycle stamps (diagnostic runs only) */) {
+    double* __restrict__ delta_c, int n_sys /* size of the system in E: 11*C, or fewer when cameras share parameters */,
+    const int32_t* __restrict__ tie /* [11*C] camera parameter -> system row, or NULL = identity */,
+    const int32_t* __restrict__ first /* [n_sys] system row -> one camera parameter mapped to it, or NULL */,
+    long long* __restrict__ dbg /* optional cycle stamps (diagnostic runs only) */) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (st->status >= 0) return;
   const double* __restrict__ cams = pp->cams;
@@ -84,7 +87,8 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   int nstamp = 0;
 #define CHOL_STAMP() do { if (dbg && threadIdx.x == 0) dbg[nstamp] = clock64(); ++nstamp; } while (0)
   CHOL_STAMP();
-  const int n = C * NCP;
+  const int ncam = C * NCP;      // camera parameters
+  const int n = n_sys;           // rows of the system being solved
   const int nb = (n + CB - 1) / CB;
   const int n16 = nb * CB;
   const int nblk = nb * (nb + 1) / 2;
@@ -103,7 +107,8 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   const double lam = st->lam;
   const bool fresh = st->fresh != 0;
   // operands of the epilogue, requested now so that their latency is hidden behind the factorisation
-  const double my_cam = (tid < n) ? cams[tid] : 0.0;
+  const double my_cam = (tid < ncam) ? cams[tid] : 0.0;                       // camera parameter tid
+  const double my_xs = (tid < n) ? cams[first ? first[tid] : tid] : 0.0;      // system unknown tid (a shared one counts once)
   const double my_g = (tid < n) ? gct[tid] : 0.0;
 
   // camera scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
@@ -271,13 +276,16 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   __syncthreads();
   CHOL_STAMP();
   double pred = 0, dx2 = 0, x2 = 0, gm = 0;
-  if (tid < n) {                                     // n <= 176 < CHOLB_THREADS: one entry per thread
-    const double d = fail ? 0.0 : s_y[tid];
+  if (tid < ncam) {                                  // 11*C <= 176 < CHOLB_THREADS: one camera parameter per thread
+    const double d = fail ? 0.0 : s_y[tie ? tie[tid] : tid];
     delta_c[tid] = d;
     cams_new[tid] = my_cam + d;
+  }
+  if (tid < n) {                                     // scalars of the step live in the system's own unknowns
+    const double d = fail ? 0.0 : s_y[tid];
     pred = 0.5 * d * (s_d[tid] * d - my_g);
     dx2 = d * d;
-    x2 = my_cam * my_cam;
+    x2 = my_xs * my_xs;
     gm = fabs(my_g);
   }
   pred = wave_sum(pred); dx2 = wave_sum(dx2); x2 = wave_sum(x2); gm = wave_max(gm);

@@ -109,6 +109,32 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
   if (threadIdx.x == 0) E[(size_t)n * n + 3 * n] = s;
 }
 
+// ------------------------------------------------------------------ shared camera parameters (PySBA.bundleAdjust_sharedcam)
+// The reference's shared-intrinsics variant (pySBA.py:252-325) optimises f, k1, k2 once for all cameras.  With
+// delta_c = T delta_s (T a 0/1 matrix, `tie` = its row->column map) the reduced system in the tied unknowns is
+// S_s = T^T S T, rhs_s = T^T rhs, and the Jacobian column norms add up: diagU_s = T^T diagU.  grid = n_s rows.
+__global__ void k_tie_system(const double* __restrict__ E, int n, int n_s, const int32_t* __restrict__ pre_start,
+                             const int32_t* __restrict__ pre_idx, double* __restrict__ Es, const LMState* __restrict__ st) {
+  if (st->status >= 0) return;
+  const int a = blockIdx.x;
+  const double* rhs = E + (size_t)n * n;
+  double* rhs_s = Es + (size_t)n_s * n_s;
+  for (int b = threadIdx.x; b < n_s; b += blockDim.x) {
+    double s = 0;
+    for (int ia = pre_start[a]; ia < pre_start[a + 1]; ++ia) {
+      const double* row = E + (size_t)pre_idx[ia] * n;
+      for (int ib = pre_start[b]; ib < pre_start[b + 1]; ++ib) s += row[pre_idx[ib]];
+    }
+    Es[(size_t)a * n_s + b] = s;
+  }
+  if (threadIdx.x < 3) {       // rhs, diagU, gc
+    double s = 0;
+    for (int ia = pre_start[a]; ia < pre_start[a + 1]; ++ia) s += rhs[(size_t)threadIdx.x * n + pre_idx[ia]];
+    rhs_s[(size_t)threadIdx.x * n_s + a] = s;
+  }
+  if (a == 0 && threadIdx.x == 0) Es[(size_t)n_s * n_s + 3 * n_s] = E[(size_t)n * n + 3 * n];
+}
+
 // ------------------------------------------------------------------ dense Cholesky + solve of the reduced camera system
 // Single workgroup.  A = S + lam*diag(D2c) ; A = L L^T ; delta_c = A^-1 rhs.  LDSMODE keeps the packed
 // lower triangle in LDS (n <= 176); otherwise factors in place in the caller's S copy in global memory.
@@ -125,7 +151,7 @@ template <bool LDSMODE, typename T>
 __global__ __launch_bounds__(CHOL_THREADS) void k_cholesky_solve(
     double* __restrict__ E /* summed exchange buffer; S is destroyed in global mode */, int C,
     LMState* __restrict__ st, double* __restrict__ D2c, const ParamPtrs<T>* __restrict__ pp,
-    double* __restrict__ delta_c) {
+    double* __restrict__ delta_c, int n_sys, const int32_t* __restrict__ tie, const int32_t* __restrict__ first) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (st->status >= 0) return;
   const double* __restrict__ cams = pp->cams;
@@ -135,7 +161,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_cholesky_solve(
   __shared__ double s_piv;
   __shared__ int s_fail;
   __shared__ double s_scr[CHOL_THREADS / 64];
-  const int n = C * NCP;
+  const int ncam = C * NCP;
+  const int n = n_sys;
   const int tid = threadIdx.x;
   double* S = E;
   const double* rhs = E + (size_t)n * n;
@@ -201,11 +228,14 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_cholesky_solve(
   }
   __syncthreads();
   double pred = 0, dx2 = 0, x2 = 0, gm = 0;
+  for (int i = tid; i < ncam; i += CHOL_THREADS) {
+    const double d = fail ? 0.0 : s_y[tie ? tie[i] : i];
+    delta_c[i] = d;
+    cams_new[i] = cams[i] + d;
+  }
   for (int i = tid; i < n; i += CHOL_THREADS) {
     const double d = fail ? 0.0 : s_y[i];
-    delta_c[i] = d;
-    const double x = cams[i];
-    cams_new[i] = x + d;
+    const double x = cams[first ? first[i] : i];
     pred += 0.5 * d * (lam * fmax_pos(D2c[i]) * d - gct[i]);
     dx2 += d * d;
     x2 += x * x;

@@ -174,6 +174,8 @@ class PySBA:
         C_, N_ = cams_opt.shape[0], pts_opt.shape[0]
         if mode == _native.MODE_POINTS_ONLY:
             x = pts_opt.ravel().copy()
+        elif mode == _native.MODE_SHARED_INTR:      # parameter order of pySBA.py:313
+            x = np.hstack((cams_opt[0, 6:9], cams_opt[:, :6].ravel(), cams_opt[:, 9:].ravel(), pts_opt.ravel()))
         else:
             x = np.hstack((cams_opt.ravel(), pts_opt.ravel()))
         message = TERMINATION_MESSAGES[rep.status]
@@ -185,7 +187,8 @@ class PySBA:
         def make_jac():
             with _native.Problem(cams_opt, pts_opt, uv, ci, pi, weights=w, dtype=dt, device=dev) as prob:
                 _, Jc, Jp = prob.residual_jacobian()
-            return assemble_jacobian(Jc, Jp, ci, pi, C_, N_, points_only=(mode == _native.MODE_POINTS_ONLY))
+            return assemble_jacobian(Jc, Jp, ci, pi, C_, N_, points_only=(mode == _native.MODE_POINTS_ONLY),
+                                     shared_intrinsics=(mode == _native.MODE_SHARED_INTR))
 
         res = SBAResult(x=x, cost=rep.cost, fun=fvec, optimality=rep.optimality,
                         active_mask=np.zeros_like(x), nfev=int(rep.nfev), njev=int(rep.njev),
@@ -297,19 +300,42 @@ class PySBA:
                                   "there is deliberately no CPU fallback")
 
     def bundleAdjust_sharedcam(self, ftol=1e-6):
-        """pySBA.py:297-325 -- not on the device yet."""
-        raise NotImplementedError("bundleAdjust_sharedcam is not implemented on the MI355X engine yet; "
-                                  "there is deliberately no CPU fallback")
+        """Bundle adjustment with one (f, k1, k2) shared by all cameras (pySBA.py:297-325).
+
+        The shared values start from the mean over cameras (pySBA.py:309); on the device the tied parameters
+        collapse the reduced camera system to 3 + 8*n_cameras unknowns (csrc/sba_lm_kernels.hpp: k_tie_system).
+        """
+        cams0 = np.array(self.cameraArray, dtype=np.float64, copy=True)
+        cams0[:, 6:9] = np.mean(cams0[:, 6:9], axis=0)
+        keep = self.cameraArray
+        self.cameraArray = cams0
+        try:
+            res, cams, pts = self._solve(_native.MODE_SHARED_INTR, ftol)
+        except Exception:
+            self.cameraArray = keep
+            raise
+        self.cameraArray = cams
+        self.points3D = pts
+        return res
 
 
 # pickles written by scripts/calibrate_camera.py:86-88 must load wherever `lasercalib.pySBA` resolves
 PySBA.__module__ = "lasercalib.pySBA"
 
 
-def assemble_jacobian(Jc, Jp, cam_idx, pt_idx, n_cams, n_pts, points_only=False):
-    """Blocks (M,2,11)/(M,2,3) -> the CSR matrix scipy would return as ``res.jac`` (pySBA.py:110-116 layout)."""
+def assemble_jacobian(Jc, Jp, cam_idx, pt_idx, n_cams, n_pts, points_only=False, shared_intrinsics=False):
+    """Blocks (M,2,11)/(M,2,3) -> the CSR matrix scipy would return as ``res.jac`` (pySBA.py:110-116 layout;
+    pySBA.py:252-275 column layout for the shared-intrinsics variant)."""
     M = cam_idx.shape[0]
-    if points_only:
+    if shared_intrinsics:
+        ncp = 3 + 8 * n_cams
+        e = np.arange(N_CAM_PARAMS)
+        ccol = np.where(e[None, :] < 6, 3 + 6 * cam_idx[:, None] + e[None, :],
+                        np.where(e[None, :] < 9, e[None, :] - 6, 3 + 6 * n_cams + 2 * cam_idx[:, None] + (e[None, :] - 9)))
+        cols = np.concatenate([ccol, ncp + pt_idx[:, None] * 3 + np.arange(3)[None, :]], axis=1)
+        data = np.concatenate([Jc, Jp], axis=2).reshape(2 * M, 14)
+        width, ncol = 14, ncp + n_pts * 3
+    elif points_only:
         cols = (pt_idx[:, None] * 3 + np.arange(3)[None, :])
         data = Jp.reshape(2 * M, 3)
         width, ncol = 3, n_pts * 3

@@ -202,14 +202,23 @@ class ModelEngine:
         [ S (n*n, row-major) | rhs (n) | diagU (n) | gc (n) | cost ]
     """
 
-    def __init__(self, cams, pts_local, uv, ci, pi_local, w=None):
+    def __init__(self, cams, pts_local, uv, ci, pi_local, w=None, shared_intrinsics=False):
         self.cams = np.array(cams, dtype=np.float64)
+        self.shared = shared_intrinsics
         self.pts = np.array(pts_local, dtype=np.float64)
         self.uv, self.ci, self.pi = uv, ci, pi_local
         self.w = np.ones(ci.shape[0]) if w is None else np.asarray(w, dtype=np.float64).reshape(-1)
         self.C, self.N = self.cams.shape[0], self.pts.shape[0]
         self.n = self.C * NCP
-        self.D2c = np.zeros(self.n)
+        if self.shared:     # pySBA.py:252-325: [f,k1,k2 | 6 extrinsics x C | 2 centre x C]
+            C = self.C
+            self.ns = 3 + 8 * C
+            self.T = np.zeros((self.n, self.ns))
+            for c in range(C):
+                for e in range(NCP):
+                    col = 3 + 6 * c + e if e < 6 else e - 6 if e < 9 else 3 + 6 * C + 2 * c + (e - 9)
+                    self.T[c * NCP + e, col] = 1.0
+        self.D2c = np.zeros(self.ns if self.shared else self.n)
         self.D2p = np.zeros((self.N, 3))
         self.lam, self.nu = LAMBDA0, 2.0
         self.nfev = self.njev = 0
@@ -269,6 +278,10 @@ class ModelEngine:
         diagU = E[n * n + n:n * n + 2 * n]
         self.gc_tot = E[n * n + 2 * n:n * n + 3 * n]
         self.cost = float(E[-1])
+        if self.shared:
+            T = self.T
+            S, rhs, diagU, self.gc_tot = T.T @ S @ T, T.T @ rhs, T.T @ diagU, T.T @ self.gc_tot
+            n = self.ns
         if self.fresh:
             self.D2c = np.maximum(self.D2c, diagU)
             self.fresh = False
@@ -280,6 +293,10 @@ class ModelEngine:
             dc = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
         except np.linalg.LinAlgError:
             fail, dc = 1.0, np.zeros(n)
+        self.ds = dc                                    # step in the system's own unknowns
+        self.xs = (np.linalg.pinv(self.T) @ self.cams.ravel()) if self.shared else self.cams.ravel()
+        if self.shared:
+            dc = self.T @ dc
         self.dc = dc
         # back-substitution: dp = V'^-1 ( -gp - W^T dc )
         Wt_dc = np.zeros((self.N, 3))
@@ -307,10 +324,10 @@ class ModelEngine:
         x2 = float(np.sum(scalars_all[:, 3]))
         gmax = float(np.max(scalars_all[:, 4]))
         fail = float(np.max(scalars_all[:, 5])) > 0
-        dc = self.dc
+        dc = self.ds
         pred += 0.5 * float(np.sum(dc * (self.lam * self.D2c_eff * dc - self.gc_tot)))
         dx2 += float(np.sum(dc ** 2))
-        x2 += float(np.sum(self.cams ** 2))
+        x2 += float(np.sum(self.xs ** 2))
         gmax = max(gmax, float(np.max(np.abs(self.gc_tot))))
         self.optimality = gmax
         self.step_norm = np.sqrt(dx2)

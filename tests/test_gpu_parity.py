@@ -289,6 +289,35 @@ def test_nocam_matches_reference(golden):
     assert np.array_equal(sba.cameraArray, g["cams0"])
 
 
+def test_sharedcam_matches_reference(golden):
+    """PySBA.bundleAdjust_sharedcam (pySBA.py:297-325): f, k1, k2 tied across cameras."""
+    g = golden("f5_variants.npz")
+    sba = PySBA(g["cams0"].copy(), g["pts0"].copy(), g["uv"], g["ci"], g["pi"])
+    res = sba.bundleAdjust_sharedcam()
+    C, N = g["cams0"].shape[0], g["pts0"].shape[0]
+    assert res.x.shape == (3 + 8 * C + 3 * N,) and res.status in (2, 3, 4)
+    assert np.all(sba.cameraArray[:, 6:9] == sba.cameraArray[0, 6:9])          # one shared (f, k1, k2)
+    assert np.array_equal(res.x[:3], sba.cameraArray[0, 6:9])
+    ref = float(g["sharedcam_cost"])
+    # one-sided like every tight-tolerance comparison with the reference's TRF step: never worse, same basin
+    assert res.cost <= ref * (1 + 1e-9) and res.cost >= 0.95 * ref
+    # the oracle's residual function in the reference's parameterisation agrees with the device result vector
+    f = orc.fun_sharedcam(res.x, C, N, g["ci"], g["pi"], g["uv"], 1.0)
+    assert np.max(np.abs(f - res.fun)) <= 1e-8 and abs(0.5 * f @ f - res.cost) <= 1e-9 * res.cost
+    # scipy restarted from the device solution (same variant, same arguments) cannot improve it
+    again, _, _ = orc.bundle_adjust_sharedcam(sba.cameraArray, sba.points3D, g["uv"], g["ci"], g["pi"], ftol=1e-6)
+    assert again.cost >= res.cost * (1 - 1e-5)
+    # trajectory = numpy model of the device algorithm with the same tying
+    cams0 = g["cams0"].copy()
+    cams0[:, 6:9] = cams0[:, 6:9].mean(axis=0)
+    eng = model.ModelEngine(cams0, g["pts0"], g["uv"], g["ci"], g["pi"], shared_intrinsics=True)
+    out = model.run_lm_single(eng, ftol=1e-6)
+    assert abs(out["cost"] - res.cost) <= 1e-7 * res.cost and abs(out["nfev"] - res.nfev) <= 2
+    # Jacobian in the shared layout: J^T r = gradient, optimality consistent
+    assert res.jac.shape == (2 * g["ci"].size, 3 + 8 * C + 3 * N)
+    assert abs(np.max(np.abs(res.grad)) - res.optimality) <= 1e-6 * max(1.0, res.optimality)
+
+
 def test_nonfinite_start_raises_value_error():
     rig = make_rig(2, 50, seed=1)
     cams = rig["cams0"].copy()
