@@ -77,6 +77,7 @@ struct Engine : EngineBase {
   DevBuf<T> w_pm, w_cm;
   DevBuf<int32_t> ci_pm, pi_pm, pt_start, blk_pt, pi_cm, chunk_cam, chunk_begin, chunk_end, cam_chunk_start;
   DevBuf<int32_t> pair_ga, pair_gb;
+  DevBuf<int4> blk_desc;
   // parameters (double-buffered: cur / trial)
   DevBuf<double> cams[2], pts[2];
   DevBuf<T> ptsT[2], campre[2];
@@ -87,8 +88,6 @@ struct Engine : EngineBase {
   DevBuf<T2> r_pm;
   DevBuf<T> Jc_pm, Jp_pm;
   DevBuf<LMState> d_state;
-  DevBuf<ParamPtrs<T>> d_pp;
-  ParamPtrs<T>* h_pp = nullptr;        // pinned
   DevBuf<sba_lm_iter_log> d_log;
   int log_read = 0;
   int cur_at_begin = 0;
@@ -127,7 +126,7 @@ struct Engine : EngineBase {
   ~Engine() override {
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) if (pev[k][j]) (void)hipEventDestroy(pev[k][j]);
     if (h_state) (void)hipHostFree(h_state);
-    if (h_pp) (void)hipHostFree(h_pp);
+
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -139,8 +138,6 @@ struct Engine : EngineBase {
     if (d.use_stream) { stream = reinterpret_cast<hipStream_t>(d.stream); own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(LMState), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_pp), sizeof(ParamPtrs<T>), hipHostMallocDefault));
-    d_pp.alloc(1);
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) HIPCHK(hipEventCreate(&pev[k][j]));
@@ -214,6 +211,8 @@ struct Engine : EngineBase {
       }
     }
     nblk = (int)blk.size() - 1;
+    std::vector<int4> bdesc(nblk);
+    for (int b = 0; b < nblk; ++b) bdesc[b] = make_int4(blk[b], blk[b + 1], ptstart[blk[b]], ptstart[blk[b + 1]]);
     // camera-major order of the pm list (stable => points ascending inside a camera)
     std::vector<int32_t> camcount(C + 1, 0);
     for (int64_t k = 0; k < M; ++k) camcount[cip[k] + 1]++;
@@ -255,7 +254,7 @@ struct Engine : EngineBase {
 
     uv_pm.upload(uvp, stream); ci_pm.upload(cip, stream); pi_pm.upload(pip, stream);
     if (has_w) { w_pm.upload(wp, stream); w_cm.upload(wc, stream); }
-    pt_start.upload(ptstart, stream); blk_pt.upload(blk, stream);
+    pt_start.upload(ptstart, stream); blk_pt.upload(blk, stream); blk_desc.upload(bdesc, stream);
     uv_cm.upload(uvc, stream); pi_cm.upload(pic, stream);
     chunk_cam.upload(ch_cam, stream); chunk_begin.upload(ch_beg, stream); chunk_end.upload(ch_end, stream);
     cam_chunk_start.upload(cam_ch, stream);
@@ -300,13 +299,15 @@ struct Engine : EngineBase {
   // ------------------------------------------------------------------ kernel launchers
   // The LM kernels read the current / trial buffers through a device-resident pointer table that k_decide swaps on
   // acceptance; the host mirror `cur` is refreshed from LMState::cur whenever the state is read back.
-  void push_ptrs() {
-    ParamPtrs<T> t;
-    t.cams = cams[cur].p; t.pts = pts[cur].p; t.ptsT = ptsT[cur].p; t.campre = campre[cur].p;
-    t.cams_new = cams[1 - cur].p; t.pts_new = pts[1 - cur].p; t.ptsT_new = ptsT[1 - cur].p; t.campre_new = campre[1 - cur].p;
-    *h_pp = t;
-    HIPCHK(hipMemcpyAsync(d_pp.p, h_pp, sizeof(ParamPtrs<T>), hipMemcpyHostToDevice, stream));
+  ParamSets<T> psets{};              // both buffer sets + the side that was current at lm_begin
+  void push_ptrs() {                 // (re)build the by-value kernel argument for the host's notion of `cur`
+    for (int b = 0; b < 2; ++b) { psets.cams[b] = cams[b].p; psets.pts[b] = pts[b].p; psets.ptsT[b] = ptsT[b].p; psets.campre[b] = campre[b].p; }
+    psets.base = cur;
   }
+  // argument for launches inside the LM loop (side = base ^ LMState::cur) ...
+  ParamSets<T> ps_lm() const { return psets; }
+  // ... and for launches outside it (st == nullptr): the host's current side
+  ParamSets<T> ps_now() const { ParamSets<T> q = psets; q.base = cur; return q; }
   void launch_residual(T2* r_out) {
     const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
     if (g == 0) return;
@@ -325,13 +326,13 @@ struct Engine : EngineBase {
   void launch_linearize_points(const LMState* st) {
     if (nblk == 0) return;
     const size_t lds = (size_t)PM_BLOCK * 9 * sizeof(double) + lds_cams();
-    hipLaunchKernelGGL(k_linearize_points<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, d_pp.p, st, C,
-                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_pt.p, V.p, gp.p, D2p.p,
+    hipLaunchKernelGGL(k_linearize_points<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, st ? ps_lm() : ps_now(), st, C,
+                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_desc.p, V.p, gp.p, D2p.p,
                        cost_part.p, gmax_part.p);
   }
   void launch_linearize_cams(const LMState* st) {
     if (nchunk == 0) return;
-    hipLaunchKernelGGL(k_linearize_cams<T>, dim3(nchunk), dim3(256), 0, stream, d_pp.p, st, uv_cm.p,
+    hipLaunchKernelGGL(k_linearize_cams<T>, dim3(nchunk), dim3(256), 0, stream, st ? ps_lm() : ps_now(), st, uv_cm.p,
                        has_w ? w_cm.p : nullptr, pi_cm.p, chunk_cam.p, chunk_begin.p, chunk_end.p, Upart.p);
     hipLaunchKernelGGL(k_reduce_cams, dim3(C), dim3(1024), 0, stream, Upart.p, cam_chunk_start.p, U.p, gc.p, st);
   }
@@ -342,7 +343,7 @@ struct Engine : EngineBase {
     using CfgD = SchurCfg<T, true>;
     using CfgO = SchurCfg<T, false>;
     hipLaunchKernelGGL((k_schur<T, true>), dim3(ksplit, ngroups), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
-                       stream, d_pp.p, d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
+                       stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
                        pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,
                        schur_debug ? schur_dbg.p : nullptr);
     if (schur_debug) {
@@ -356,15 +357,15 @@ struct Engine : EngineBase {
     }
     if (npairs > ngroups)
       hipLaunchKernelGGL((k_schur<T, false>), dim3(ksplit, npairs - ngroups), dim3(CfgO::THREADS),
-                         CfgO::LDS_BYTES, stream, d_pp.p, d_state.p, C, uv_pm.p,
+                         CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
                          has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
                          pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
   }
   void launch_backsub_trial() {
     if (nblk == 0) return;
     const size_t lds = (size_t)PM_BLOCK * 6 * sizeof(double) + (2 * (size_t)C * CAMPRE + (size_t)C * NCP) * sizeof(T);
-    hipLaunchKernelGGL(k_backsub_trial<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, d_pp.p, C,
-                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_pt.p,
+    hipLaunchKernelGGL(k_backsub_trial<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, ps_lm(), C,
+                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_desc.p,
                        pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nblk);
   }
 
@@ -535,7 +536,7 @@ struct Engine : EngineBase {
         const size_t lds = ((size_t)(nb * (nb + 1) / 2 + 2) * CBS + 3 * (size_t)nb * CB) * sizeof(double);
         if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }
         hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
-                           d_pp.p, delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr,
+                           ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr,
                            chol_debug ? chol_dbg.p : nullptr);
         if (chol_debug) {
           std::vector<long long> st(64);
@@ -549,10 +550,10 @@ struct Engine : EngineBase {
       } else if (n_sys <= CHOL_LDS_MAX_N) {
         const size_t lds = (size_t)n_sys * (n_sys + 1) / 2 * sizeof(double);
         hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
-                           d_pp.p, delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
+                           ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       } else {
         hipLaunchKernelGGL((k_cholesky_solve<false, T>), dim3(1), dim3(CHOL_THREADS), 0, stream, Esys, C, d_state.p, D2c.p,
-                           d_pp.p, delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
+                           ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       }
       prof_end(KP_CHOL);
     } else {
@@ -571,7 +572,7 @@ struct Engine : EngineBase {
   // enqueue the accept / reject / terminate kernel; nothing is read back
   int lm_decide_async(const double* scal_all, int n_ranks) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
-    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(256), 0, stream, d_state.p, d_pp.p, scal_all, n_ranks, trial_part.p,
+    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(256), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
                        gmax_part.p, nblk, reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
     pslot_advance();
     return SBA_OK;

@@ -74,16 +74,17 @@ __device__ __forceinline__ bool chol16_wave(double* __restrict__ blk, double* __
 template <typename T>
 __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
     const double* __restrict__ E /* summed exchange buffer [S | rhs | diagU | gc | cost] */, int C,
-    LMState* __restrict__ st, double* __restrict__ D2c, const ParamPtrs<T>* __restrict__ pp,
+    LMState* __restrict__ st, double* __restrict__ D2c, const ParamSets<T> ps,
     double* __restrict__ delta_c, int n_sys /* size of the system in E: 11*C, or fewer when cameras share parameters */,
     const int32_t* __restrict__ tie /* [11*C] camera parameter -> system row, or NULL = identity */,
     const int32_t* __restrict__ first /* [n_sys] system row -> one camera parameter mapped to it, or NULL */,
     long long* __restrict__ dbg /* optional cycle stamps (diagnostic runs only) */) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (st->status >= 0) return;
-  const double* __restrict__ cams = pp->cams;
-  double* __restrict__ cams_new = pp->cams_new;
-  T* __restrict__ campre_new = pp->campre_new;
+  const int cur_ = ps_cur(ps, st);
+  const double* __restrict__ cams = ps.cams[cur_];
+  double* __restrict__ cams_new = ps.cams[cur_ ^ 1];
+  T* __restrict__ campre_new = ps.campre[cur_ ^ 1];
   int nstamp = 0;
 #define CHOL_STAMP() do { if (dbg && threadIdx.x == 0) dbg[nstamp] = clock64(); ++nstamp; } while (0)
   CHOL_STAMP();

@@ -29,11 +29,13 @@ constexpr int GROUP_ROWS = GROUP_CAMS * NCP;   // 176
 constexpr int GROUP_TILES = GROUP_ROWS / 16;   // 11
 constexpr int NSCAL = 8;
 
-// Current / trial parameter buffers.  The table lives in device memory and k_decide swaps its two halves when a
-// step is accepted, so the host never has to learn the outcome of an iteration before enqueueing the next one.
-template <typename T> struct ParamPtrs {
-  double* cams; double* pts; T* ptsT; T* campre;                 // current point x
-  double* cams_new; double* pts_new; T* ptsT_new; T* campre_new; // trial point x + delta
+// Current / trial parameter buffers: both sets travel BY VALUE as a kernel argument (no extra dependent load), and
+// a kernel picks its side from LMState::cur, which k_decide flips when a step is accepted -- so the host never has
+// to learn the outcome of an iteration before enqueueing the next one.  `base` is the side that was current when
+// the solve began (or simply the current side for launches outside the LM loop, where st == nullptr).
+template <typename T> struct ParamSets {
+  double* cams[2]; double* pts[2]; T* ptsT[2]; T* campre[2];
+  int base;
 };
 
 struct LMState {
@@ -57,6 +59,7 @@ struct LMState {
   int pad;
 };
 __device__ inline bool lm_done(const LMState* st) { return st != nullptr && st->status >= 0; }
+template <typename T> __device__ inline int ps_cur(const ParamSets<T>& ps, const LMState* st) { return (ps.base ^ (st ? st->cur : 0)) & 1; }
 
 template <typename T> struct Vec2;
 template <> struct Vec2<double> { using type = double2; };
@@ -245,21 +248,23 @@ __global__ __launch_bounds__(PM_BLOCK) void k_resjac(
 // cost partial and max|gp| partial.
 template <typename T>
 __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points(
-    const ParamPtrs<T>* __restrict__ pp, const LMState* __restrict__ st, int C,
+    const ParamSets<T> ps, const LMState* __restrict__ st, int C,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start,
-    const int32_t* __restrict__ blk_pt, double* __restrict__ V, double* __restrict__ gp,
-    double* __restrict__ D2p, double* __restrict__ cost_part, double* __restrict__ gmax_part) {
+    const int4* __restrict__ blk_desc /* {p_lo, p_hi, o_lo, o_hi} per block */, double* __restrict__ V,
+    double* __restrict__ gp, double* __restrict__ D2p, double* __restrict__ cost_part, double* __restrict__ gmax_part) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (st && (st->status >= 0 || !st->need_lin)) return;
-  const T* __restrict__ campre = pp->campre;
-  const T* __restrict__ ptsT = pp->ptsT;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ campre = ps.campre[cur_];
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
   double* s_red = reinterpret_cast<double*>(smem);              // [256][9]
   T* s_cam = reinterpret_cast<T*>(s_red + PM_BLOCK * 9);
   __shared__ double s_scr[PM_BLOCK / 64];
+  const int4 bd = blk_desc[blockIdx.x];
   stage_campre(campre, s_cam, C);
-  const int p_lo = blk_pt[blockIdx.x], p_hi = blk_pt[blockIdx.x + 1];
-  const int o_lo = pt_start[p_lo], o_hi = pt_start[p_hi];
+  const int p_lo = bd.x, p_hi = bd.y;
+  const int o_lo = bd.z, o_hi = bd.w;
   const int nobs = o_hi - o_lo;
   __syncthreads();
   double sq = 0;
@@ -333,7 +338,7 @@ template <> struct Mfma<float> {
 // (16x16) in 4 accumulator registers.  No shuffles, no atomics; one 16x16 partial per wave.
 template <typename T>
 __global__ __launch_bounds__(256) void k_linearize_cams(
-    const ParamPtrs<T>* __restrict__ pp, const LMState* __restrict__ st,
+    const ParamSets<T> ps, const LMState* __restrict__ st,
     const typename Vec2<T>::type* __restrict__ uv_cm, const T* __restrict__ w_cm,
     const int32_t* __restrict__ pi_cm, const int32_t* __restrict__ chunk_cam,
     const int32_t* __restrict__ chunk_begin, const int32_t* __restrict__ chunk_end,
@@ -343,8 +348,9 @@ __global__ __launch_bounds__(256) void k_linearize_cams(
   __shared__ T s_cam[CAMPRE];
   using M_ = Mfma<T>;
   if (st && (st->status >= 0 || !st->need_lin)) return;
-  const T* __restrict__ campre = pp->campre;
-  const T* __restrict__ ptsT = pp->ptsT;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ campre = ps.campre[cur_];
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
   const int chunk = blockIdx.x;
   const int cam = chunk_cam[chunk];
   const int beg = chunk_begin[chunk], end = chunk_end[chunk];
@@ -541,7 +547,7 @@ __device__ inline void schur_store_diag(T* __restrict__ slab, int lane, const ty
 
 template <typename T, bool DIAG>
 __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
-    const ParamPtrs<T>* __restrict__ pp, const LMState* __restrict__ st, int C,
+    const ParamSets<T> ps, const LMState* __restrict__ st, int C,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start, int N,
     const T* __restrict__ pf, const int32_t* __restrict__ pair_ga, const int32_t* __restrict__ pair_gb,
@@ -553,8 +559,9 @@ __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, NCW = Cfg::NCW, MAXSLOT = Cfg::MAXSLOT, NTILE = Cfg::NTILE;
   constexpr int PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF;
   if (st->status >= 0) return;
-  const T* __restrict__ campre = pp->campre;
-  const T* __restrict__ ptsT = pp->ptsT;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ campre = ps.campre[cur_];
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
   const int pair = pair0 + blockIdx.y;
   const int ga = pair_ga[pair], gb = pair_gb[pair];
   const int camA0 = ga * GROUP_CAMS, camB0 = gb * GROUP_CAMS;

@@ -150,13 +150,14 @@ struct TriGlobal {
 template <bool LDSMODE, typename T>
 __global__ __launch_bounds__(CHOL_THREADS) void k_cholesky_solve(
     double* __restrict__ E /* summed exchange buffer; S is destroyed in global mode */, int C,
-    LMState* __restrict__ st, double* __restrict__ D2c, const ParamPtrs<T>* __restrict__ pp,
+    LMState* __restrict__ st, double* __restrict__ D2c, const ParamSets<T> ps,
     double* __restrict__ delta_c, int n_sys, const int32_t* __restrict__ tie, const int32_t* __restrict__ first) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (st->status >= 0) return;
-  const double* __restrict__ cams = pp->cams;
-  double* __restrict__ cams_new = pp->cams_new;
-  T* __restrict__ campre_new = pp->campre_new;
+  const int cur_ = ps_cur(ps, st);
+  const double* __restrict__ cams = ps.cams[cur_];
+  double* __restrict__ cams_new = ps.cams[cur_ ^ 1];
+  T* __restrict__ campre_new = ps.campre[cur_ ^ 1];
   __shared__ double s_y[GROUP_ROWS * 8 > 1408 ? GROUP_ROWS * 8 : 1408];   // rhs / solution, n <= 1408
   __shared__ double s_piv;
   __shared__ int s_fail;
@@ -271,19 +272,20 @@ __global__ void k_nocam_step(LMState* __restrict__ st, const double* __restrict_
 // partials per block: trial_part[4][nblk] = cost_new, pred_p, |delta_p|^2, |X|^2
 template <typename T>
 __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
-    const ParamPtrs<T>* __restrict__ pp, int C, const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
+    const ParamSets<T> ps, int C, const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start,
-    const int32_t* __restrict__ blk_pt,
+    const int4* __restrict__ blk_desc /* {p_lo, p_hi, o_lo, o_hi} per block */,
     const T* __restrict__ pf, const double* __restrict__ gp, const double* __restrict__ D2p,
     const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ trial_part, int nblk) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (st->status >= 0) return;
-  const T* __restrict__ campre = pp->campre;
-  const T* __restrict__ campre_new = pp->campre_new;
-  const double* __restrict__ pts = pp->pts;
-  const T* __restrict__ ptsT = pp->ptsT;
-  double* __restrict__ pts_new = pp->pts_new;
-  T* __restrict__ ptsT_new = pp->ptsT_new;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ campre = ps.campre[cur_];
+  const T* __restrict__ campre_new = ps.campre[cur_ ^ 1];
+  const double* __restrict__ pts = ps.pts[cur_];
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  double* __restrict__ pts_new = ps.pts[cur_ ^ 1];
+  T* __restrict__ ptsT_new = ps.ptsT[cur_ ^ 1];
   double* s_t = reinterpret_cast<double*>(smem);          // [256][3]
   double* s_xn = s_t + PM_BLOCK * 3;                      // [256][3] new point coordinates (per local point)
   T* s_cam = reinterpret_cast<T*>(s_xn + PM_BLOCK * 3);   // [C][CAMPRE] current
@@ -295,8 +297,9 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
   stage_campre(campre, s_cam, C);
   stage_campre(campre_new, s_camn, C);
   for (int i = threadIdx.x; i < C * NCP; i += PM_BLOCK) s_dc[i] = (T)delta_c[i];
-  const int p_lo = blk_pt[blockIdx.x], p_hi = blk_pt[blockIdx.x + 1];
-  const int o_lo = pt_start[p_lo], o_hi = pt_start[p_hi];
+  const int4 bd = blk_desc[blockIdx.x];
+  const int p_lo = bd.x, p_hi = bd.y;
+  const int o_lo = bd.z, o_hi = bd.w;
   const int nobs = o_hi - o_lo, npts = p_hi - p_lo;
   // per-point operands of phase 2 (thread q < npts owns point p_lo + q): requested now, consumed after phase 1
   const bool own_pt = (int)threadIdx.x < npts;
@@ -406,7 +409,7 @@ struct LMLogRow { int iteration; int accepted; long long nfev; double cost, cost
 // scal_all: n_ranks x 8 scalars (already gathered), or -- single rank -- nullptr, in which case the block folds the
 // per-block partials itself (what k_trial_scalars does for the multi-rank path) and no separate launch is needed.
 template <typename T>
-__global__ __launch_bounds__(256) void k_decide(LMState* __restrict__ st, ParamPtrs<T>* __restrict__ pp,
+__global__ __launch_bounds__(256) void k_decide(LMState* __restrict__ st,
                                                 const double* __restrict__ scal_all, int n_ranks,
                                                 const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
                                                 int nblk, LMLogRow* __restrict__ log, int log_cap) {
@@ -463,12 +466,7 @@ __global__ __launch_bounds__(256) void k_decide(LMState* __restrict__ st, ParamP
       st->cost = cost_new;        // refreshed again from the exchange buffer after the next linearization
       st->njev += 1;              // the accepted point gets a new Jacobian (scipy counts it the same way)
       st->fresh = 1;
-      st->cur ^= 1;
-      ParamPtrs<T> q = *pp;       // the trial point becomes the current one
-      ParamPtrs<T> r;
-      r.cams = q.cams_new; r.pts = q.pts_new; r.ptsT = q.ptsT_new; r.campre = q.campre_new;
-      r.cams_new = q.cams; r.pts_new = q.pts; r.ptsT_new = q.ptsT; r.campre_new = q.campre;
-      *pp = r;
+      st->cur ^= 1;               // the trial point becomes the current one
     } else {
       st->lam = fmin(st->lam * st->nu, st->lam_max);
       st->nu *= 2.0;
