@@ -572,7 +572,7 @@ struct Engine : EngineBase {
   // enqueue the accept / reject / terminate kernel; nothing is read back
   int lm_decide_async(const double* scal_all, int n_ranks) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
-    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(256), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
+    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(1024), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
                        gmax_part.p, nblk, reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
     pslot_advance();
     return SBA_OK;

@@ -301,18 +301,8 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
   const int p_lo = bd.x, p_hi = bd.y;
   const int o_lo = bd.z, o_hi = bd.w;
   const int nobs = o_hi - o_lo, npts = p_hi - p_lo;
-  // per-point operands of phase 2 (thread q < npts owns point p_lo + q): requested now, consumed after phase 1
-  const bool own_pt = (int)threadIdx.x < npts;
+  const bool own_pt = (int)threadIdx.x < npts;      // phase 2: thread q < npts owns point p_lo + q
   const size_t myq = (size_t)(p_lo + (own_pt ? (int)threadIdx.x : 0));
-  T f[PF];
-  double g0 = 0, g1 = 0, g2 = 0, dd0 = 1, dd1 = 1, dd2 = 1, X0 = 0, X1 = 0, X2 = 0;
-  if (own_pt) {
-#pragma unroll
-    for (int k = 0; k < PF; ++k) f[k] = pf[myq * PF + k];
-    g0 = gp[myq * 3]; g1 = gp[myq * 3 + 1]; g2 = gp[myq * 3 + 2];
-    dd0 = fmax_pos(D2p[myq * 3]); dd1 = fmax_pos(D2p[myq * 3 + 1]); dd2 = fmax_pos(D2p[myq * 3 + 2]);
-    X0 = pts[myq * 3]; X1 = pts[myq * 3 + 1]; X2 = pts[myq * 3 + 2];
-  }
   __syncthreads();
   int my_p = -1, my_c = 0;
   typename Vec2<T>::type my_uv; my_uv.x = 0; my_uv.y = 0;
@@ -342,6 +332,13 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
   if (own_pt) {      // a point-aligned block holds at most 256 points: one per thread
     const int q = threadIdx.x;
     const size_t p = myq;
+    // operands are read here, not ahead of phase 1: keeping ~27 more values live across it costs a wave of occupancy
+    T f[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) f[k] = pf[myq * PF + k];
+    const double g0 = gp[myq * 3], g1 = gp[myq * 3 + 1], g2 = gp[myq * 3 + 2];
+    const double dd0 = fmax_pos(D2p[myq * 3]), dd1 = fmax_pos(D2p[myq * 3 + 1]), dd2 = fmax_pos(D2p[myq * 3 + 2]);
+    const double X0 = pts[myq * 3], X1 = pts[myq * 3 + 1], X2 = pts[myq * 3 + 2];
     const int a = pt_start[p] - o_lo, b = pt_start[p + 1] - o_lo;
     double t0 = 0, t1 = 0, t2 = 0;
     for (int k = a; k < b; ++k) { t0 += s_t[k * 3]; t1 += s_t[k * 3 + 1]; t2 += s_t[k * 3 + 2]; }
@@ -409,18 +406,20 @@ struct LMLogRow { int iteration; int accepted; long long nfev; double cost, cost
 // scal_all: n_ranks x 8 scalars (already gathered), or -- single rank -- nullptr, in which case the block folds the
 // per-block partials itself (what k_trial_scalars does for the multi-rank path) and no separate launch is needed.
 template <typename T>
-__global__ __launch_bounds__(256) void k_decide(LMState* __restrict__ st,
+__global__ __launch_bounds__(1024) void k_decide(LMState* __restrict__ st,
                                                 const double* __restrict__ scal_all, int n_ranks,
                                                 const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
                                                 int nblk, LMLogRow* __restrict__ log, int log_cap) {
-  __shared__ double scr[4];
+  __shared__ double scr[16];
   if (st->status >= 0) return;
   double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
   if (scal_all == nullptr) {
     double a = 0, b = 0, c = 0, d = 0, g = 0;
+    // 1024 threads, all five loads of an index independent: a few rounds of memory latency in total
     for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
-      a += trial_part[i]; b += trial_part[nblk + i]; c += trial_part[2 * nblk + i]; d += trial_part[3 * nblk + i];
-      g = fmax(g, gmax_part[i]);
+      const double t0 = trial_part[i], t1 = trial_part[nblk + i], t2 = trial_part[2 * nblk + i], t3 = trial_part[3 * nblk + i];
+      const double t4 = gmax_part[i];
+      a += t0; b += t1; c += t2; d += t3; g = fmax(g, t4);
     }
     cost_new = block_sum(a, scr); pred = block_sum(b, scr); dx2 = block_sum(c, scr); x2 = block_sum(d, scr);
     gmax = block_max(g, scr);
