@@ -19,6 +19,42 @@
 
 using namespace sba;
 
+#include <dlfcn.h>
+// rocSOLVER / rocBLAS are bound at run time and only when a camera system is too large for the in-LDS Cholesky
+// (more than 16 cameras): the common path never loads them.
+namespace {
+struct RocSolver {
+  using handle_t = void*;
+  int (*create)(handle_t*) = nullptr;
+  int (*destroy)(handle_t) = nullptr;
+  int (*set_stream)(handle_t, hipStream_t) = nullptr;
+  int (*dpotrf)(handle_t, int /*rocblas_fill*/, int, double*, int, int*) = nullptr;
+  int (*dpotrs)(handle_t, int, int, int, double*, int, double*, int) = nullptr;
+  bool ok = false;
+  std::string why;
+  static RocSolver& get() {
+    static RocSolver r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    void* blas = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    if (!blas) blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    void* sol = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (!sol) sol = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!blas || !sol) { r.why = std::string("cannot load rocBLAS/rocSOLVER: ") + (dlerror() ? dlerror() : "?"); return r; }
+    r.create = reinterpret_cast<decltype(r.create)>(dlsym(blas, "rocblas_create_handle"));
+    r.destroy = reinterpret_cast<decltype(r.destroy)>(dlsym(blas, "rocblas_destroy_handle"));
+    r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(blas, "rocblas_set_stream"));
+    r.dpotrf = reinterpret_cast<decltype(r.dpotrf)>(dlsym(sol, "rocsolver_dpotrf"));
+    r.dpotrs = reinterpret_cast<decltype(r.dpotrs)>(dlsym(sol, "rocsolver_dpotrs"));
+    r.ok = r.create && r.destroy && r.set_stream && r.dpotrf && r.dpotrs;
+    if (!r.ok) r.why = "rocBLAS/rocSOLVER symbols missing";
+    return r;
+  }
+};
+constexpr int ROCBLAS_FILL_UPPER = 121;   // rocblas_fill_upper (column-major upper == our row-major lower)
+}  // namespace
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -95,6 +131,10 @@ struct Engine : EngineBase {
   sba_lm_opts opts{};
   bool lm_active = false;
   bool chol_old = false;
+  void* rs_handle = nullptr;
+  int rocsolver_min_n = 512;
+  DevBuf<double> chol_sol;
+  DevBuf<int> chol_info;
   bool chol_debug = false;
   bool schur_debug = false;
   DevBuf<long long> schur_dbg;
@@ -125,6 +165,7 @@ struct Engine : EngineBase {
 
   ~Engine() override {
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) if (pev[k][j]) (void)hipEventDestroy(pev[k][j]);
+    if (rs_handle) RocSolver::get().destroy(rs_handle);
     if (h_state) (void)hipHostFree(h_state);
 
     if (ev0) (void)hipEventDestroy(ev0);
@@ -150,6 +191,7 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     if (const char* e = getenv("SBA_CHOL")) chol_old = (std::string(e) == "old");
     if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
+    if (const char* e = getenv("SBA_ROCSOLVER_MIN_N")) rocsolver_min_n = atoi(e);
     if (getenv("SBA_SCHUR_DEBUG")) { schur_debug = true; schur_dbg.alloc(64); schur_dbg.zero(stream); }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -551,6 +593,20 @@ struct Engine : EngineBase {
         const size_t lds = (size_t)n_sys * (n_sys + 1) / 2 * sizeof(double);
         hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
                            ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
+      } else if (n_sys > rocsolver_min_n && RocSolver::get().ok) {
+        // large systems (default: more than 512 unknowns, i.e. 47+ cameras): library potrf/potrs between our prepare /
+        // epilogue kernels.  Below that the single-workgroup global-memory kernel is used: slower per call, but it
+        // spares small jobs the one-off load of the rocBLAS/rocSOLVER code objects (tens of seconds on a cold machine).
+        RocSolver& rs = RocSolver::get();
+        if (!rs_handle) { if (rs.create(&rs_handle) != 0) { err = "rocblas_create_handle failed"; return SBA_ERR_HIP; } rs.set_stream(rs_handle, stream); }
+        if (chol_sol.n < (size_t)n_sys) { chol_sol.alloc(n_sys); chol_info.alloc(1); }
+        hipLaunchKernelGGL(k_chol_prepare, dim3((n_sys + 255) / 256), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p, chol_sol.p);
+        if (rs.dpotrf(rs_handle, ROCBLAS_FILL_UPPER, n_sys, Esys, n_sys, chol_info.p) != 0 ||
+            rs.dpotrs(rs_handle, ROCBLAS_FILL_UPPER, n_sys, 1, Esys, n_sys, chol_sol.p, n_sys) != 0) {
+          err = "rocsolver potrf/potrs failed"; return SBA_ERR_HIP;
+        }
+        hipLaunchKernelGGL(k_chol_epilogue<T>, dim3(1), dim3(1024), 0, stream, Esys, C, n_sys, d_state.p, D2c.p, ps_lm(), delta_c.p,
+                           chol_sol.p, chol_info.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       } else {
         hipLaunchKernelGGL((k_cholesky_solve<false, T>), dim3(1), dim3(CHOL_THREADS), 0, stream, Esys, C, d_state.p, D2c.p,
                            ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);

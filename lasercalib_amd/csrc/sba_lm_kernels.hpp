@@ -264,6 +264,77 @@ __global__ void k_nocam_step(LMState* __restrict__ st, const double* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ large camera systems (n_sys > 176): library factorisation
+// For more than 16 cameras the reduced system no longer fits the single-workgroup LDS Cholesky; the dense
+// factor/solve is then a plain library call (rocSOLVER potrf/potrs on the engine's stream) bracketed by these
+// two kernels, which keep the LM-specific parts on our side: Marquardt scaling + damping before, step, trial
+// cameras and the step's scalars after.
+__global__ void k_chol_prepare(double* __restrict__ E, int n, LMState* __restrict__ st, double* __restrict__ D2c,
+                               double* __restrict__ sol /* [n] rhs in, solution out */) {
+  if (st->status >= 0) return;
+  const double* rhs = E + (size_t)n * n;
+  const double* dU = rhs + n;
+  const double lam = st->lam;
+  const bool fresh = st->fresh != 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double d = D2c[i];
+    if (fresh) { d = fmax(d, dU[i]); D2c[i] = d; }
+    E[(size_t)i * n + i] += lam * fmax_pos(d);
+    sol[i] = rhs[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->cost = E[(size_t)n * n + 3 * n];
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_chol_epilogue(
+    const double* __restrict__ E, int C, int n, LMState* __restrict__ st, const double* __restrict__ D2c,
+    const ParamSets<T> ps, double* __restrict__ delta_c, const double* __restrict__ sol, const int* __restrict__ info,
+    const int32_t* __restrict__ tie, const int32_t* __restrict__ first) {
+  __shared__ double s_scr[16];
+  if (st->status >= 0) return;
+  const int cur_ = ps_cur(ps, st);
+  const double* __restrict__ cams = ps.cams[cur_];
+  double* __restrict__ cams_new = ps.cams[cur_ ^ 1];
+  T* __restrict__ campre_new = ps.campre[cur_ ^ 1];
+  const int ncam = C * NCP;
+  const double* gct = E + (size_t)n * n + 2 * n;
+  const double lam = st->lam;
+  bool fail = (*info != 0);
+  // a factorisation of an indefinite matrix that "succeeds" numerically still shows up as a non-finite step
+  double bad = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) if (!isfinite(sol[i])) bad = 1;
+  bad = block_max(bad, s_scr);
+  __shared__ int s_fail;
+  if (threadIdx.x == 0) s_fail = (fail || bad > 0) ? 1 : 0;
+  __syncthreads();
+  fail = s_fail != 0;
+  double pred = 0, dx2 = 0, x2 = 0, gm = 0;
+  for (int i = threadIdx.x; i < ncam; i += blockDim.x) {
+    const double d = fail ? 0.0 : sol[tie ? tie[i] : i];
+    delta_c[i] = d;
+    cams_new[i] = cams[i] + d;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double d = fail ? 0.0 : sol[i];
+    const double x = cams[first ? first[i] : i];
+    pred += 0.5 * d * (lam * fmax_pos(D2c[i]) * d - gct[i]);
+    dx2 += d * d;
+    x2 += x * x;
+    gm = fmax(gm, fabs(gct[i]));
+  }
+  pred = block_sum(pred, s_scr);
+  dx2 = block_sum(dx2, s_scr);
+  x2 = block_sum(x2, s_scr);
+  gm = block_max(gm, s_scr);
+  if (threadIdx.x == 0) {
+    st->pred_c = pred; st->dx2_c = dx2; st->x2_c = x2; st->gmax_c = gm;
+    st->chol_fail = fail ? 1 : 0;
+    st->fresh = 0;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C) campre_build<T>(cams_new + (size_t)threadIdx.x * NCP, campre_new + (size_t)threadIdx.x * CAMPRE);
+}
+
 // ------------------------------------------------------------------ K6: back-substitution + trial point + trial residual
 // Same point-aligned workgroups as k_linearize_points.
 //   phase 1 (lane = observation): t_i = Jp^T (Jc delta_c[cam])                      -> LDS
