@@ -45,7 +45,12 @@ typedef enum { SBA_F64 = 0, SBA_F32 = 1 } sba_dtype;
 typedef enum {
   SBA_MODE_FULL = 0,       /* PySBA.bundleAdjust            (pySBA.py:132-147) cameras + points     */
   SBA_MODE_POINTS_ONLY = 1,/* PySBA.bundleAdjust_nocam      (pySBA.py:237-250) cameras held fixed   */
-  SBA_MODE_SHARED_INTR = 2 /* PySBA.bundleAdjust_sharedcam  (pySBA.py:297-325) f,k1,k2 shared      */
+  SBA_MODE_SHARED_INTR = 2,/* PySBA.bundleAdjust_sharedcam  (pySBA.py:297-325) f,k1,k2 shared      */
+  SBA_MODE_CAMS_ONLY_SQ = 3,/* PySBA.bundle_adjustment_camonly (pySBA.py:151-173): cameras free, points fixed,
+                               residual = w*(pixel error)^2, x_scale = 1                               */
+  SBA_MODE_TRANSFORM_SQ = 4 /* PySBA.bundleAdjust_transform_points_3d (pySBA.py:176-205): one 3x4 affine on all
+                               points, cameras fixed, residual = w*(pixel error)^2; points_out receives the
+                               transformed points, sba_get_transform the 12 parameters               */
 } sba_mode;
 
 typedef struct sba_handle sba_handle;
@@ -131,6 +136,8 @@ int sba_destroy(sba_handle* h);
 /* J^T r blocks of the last linearization (after sba_solve_lm / sba_lm_finish: at the returned point).
  * gc_out: 11*C camera part (THIS handle's observations only), gp_out: 3*N point part.  Either may be NULL. */
 int sba_get_gradient(sba_handle* h, double* gc_out, double* gp_out);
+/* The 3x4 affine (row-major, 12 doubles) found by the last SBA_MODE_TRANSFORM_SQ solve. */
+int sba_get_transform(sba_handle* h, double* theta12_out);
 
 /* sba_residual <-> PySBA.fun(params, ...) (pySBA.py:92-101). x==NULL: use the handle's parameters. */
 int sba_residual(sba_handle* h, const double* x, double* r_out /*2M or NULL*/, double* cost_out);

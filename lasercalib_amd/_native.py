@@ -15,14 +15,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsba_hip.so")
 
 SBA_F64, SBA_F32 = 0, 1
-MODE_FULL, MODE_POINTS_ONLY, MODE_SHARED_INTR = 0, 1, 2
+MODE_FULL, MODE_POINTS_ONLY, MODE_SHARED_INTR, MODE_CAMS_ONLY_SQ, MODE_TRANSFORM_SQ = 0, 1, 2, 3, 4
 NSCALARS = 8
 
 # every symbol include/sba_hip.h declares (tests/test_cabi_symbols.py checks the .so exports all of them)
 EXPORTED_SYMBOLS = (
     "sba_abi_version", "sba_device_count", "sba_last_error", "sba_rotate", "sba_project",
     "sba_create", "sba_upload", "sba_set_params", "sba_get_params", "sba_destroy",
-    "sba_get_gradient", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
+    "sba_get_gradient", "sba_get_transform", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
     "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_finish", "sba_lm_get_log", "sba_time_kernel", "sba_get_kernel_profile",
 )
@@ -86,6 +86,7 @@ def load():
         "sba_get_params": (C.c_int, [H, dp, dp]),
         "sba_destroy": (C.c_int, [H]),
         "sba_get_gradient": (C.c_int, [H, dp, dp]),
+        "sba_get_transform": (C.c_int, [H, dp]),
         "sba_residual": (C.c_int, [H, dp, dp, dp]),
         "sba_residual_jacobian": (C.c_int, [H, dp, dp, dp, dp]),
         "sba_solve_lm": (C.c_int, [H, C.POINTER(LmOpts), dp, dp, C.POINTER(LmReport),
@@ -258,6 +259,11 @@ class Problem:
         gp = np.empty((self.N, 3))
         _check(self._lib.sba_get_gradient(self._h, _dptr(gc), _dptr(gp)), self._h)
         return gc, gp
+
+    def get_transform(self):
+        th = np.empty(12)
+        _check(self._lib.sba_get_transform(self._h, _dptr(th)), self._h)
+        return th
 
     # -- solver
     @staticmethod

@@ -16,6 +16,7 @@
 
 #include "sba_lm_kernels.hpp"
 #include "sba_chol_blocked.hpp"
+#include "sba_sq_kernels.hpp"
 
 using namespace sba;
 
@@ -196,6 +197,10 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residual<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_linearize<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_linearize<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_trial<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_trial<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   }
 
   void sync() { HIPCHK(hipStreamSynchronize(stream)); }
@@ -458,6 +463,72 @@ struct Engine : EngineBase {
     return SBA_OK;
   }
 
+  // ------------------------------------------------------------------ squared-pixel-error variants (pySBA.py:151-205)
+  bool sq_mode() const { return opts.mode == SBA_MODE_CAMS_ONLY_SQ || opts.mode == SBA_MODE_TRANSFORM_SQ; }
+  int nblk_sq = 0, nchunk_sq = 0;
+  DevBuf<double> sq_part, sq_16, theta[2];
+  DevBuf<int32_t> sq_start;
+  double h_theta[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  ThetaSets tsets() const { ThetaSets t; t.th[0] = theta[0].p; t.th[1] = theta[1].p; t.base = cur_at_begin; return t; }
+  void sq_setup() {
+    nblk_sq = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
+    std::vector<int32_t> st;
+    if (opts.mode == SBA_MODE_CAMS_ONLY_SQ) {          // one 16x16 per camera, from the camera-major chunks
+      nchunk_sq = nchunk;
+      sq_16.alloc((size_t)C * 256);
+    } else {                                           // one 16x16 for the whole problem
+      nchunk_sq = (int)((M + SQ_CHUNK - 1) / SQ_CHUNK);
+      st = {0, nchunk_sq};
+      sq_start.upload(st, stream);
+      sq_16.alloc(256);
+      for (int b = 0; b < 2; ++b) if (theta[b].n != 12) theta[b].alloc(12);
+    }
+    sq_part.alloc((size_t)std::max(nchunk_sq, 1) * 256);
+    if (trial_part.n < (size_t)4 * std::max(nblk_sq, 1)) trial_part.alloc((size_t)4 * std::max(nblk_sq, 1));
+    if (gmax_part.n < (size_t)std::max(nblk_sq, 1)) gmax_part.alloc(std::max(nblk_sq, 1));
+    gmax_part.zero(stream);
+  }
+  void launch_sq_linearize(const LMState* st) {
+    if (nchunk_sq == 0) return;
+    const ParamSets<T> ps = st ? ps_lm() : ps_now();
+    ThetaSets ts = tsets();
+    if (!st) ts.base = cur;
+    if (opts.mode == SBA_MODE_CAMS_ONLY_SQ) {
+      const size_t lds = ((size_t)4 * 16 * 130 + CAMPRE) * sizeof(T);
+      hipLaunchKernelGGL((k_sq_linearize<T, 1>), dim3(nchunk_sq), dim3(256), lds, stream, ps, ts, st, C, uv_cm.p,
+                         has_w ? w_cm.p : nullptr, (const int32_t*)nullptr, pi_cm.p, chunk_cam.p, chunk_begin.p, chunk_end.p, M, sq_part.p);
+      hipLaunchKernelGGL(k_reduce16, dim3(C), dim3(1024), 0, stream, sq_part.p, cam_chunk_start.p, sq_16.p, st);
+    } else {
+      const size_t lds = ((size_t)4 * 16 * 130 + (size_t)C * CAMPRE) * sizeof(T);
+      hipLaunchKernelGGL((k_sq_linearize<T, 2>), dim3(nchunk_sq), dim3(256), lds, stream, ps, ts, st, C, uv_pm.p,
+                         has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                         (const int32_t*)nullptr, M, sq_part.p);
+      hipLaunchKernelGGL(k_reduce16, dim3(1), dim3(1024), 0, stream, sq_part.p, sq_start.p, sq_16.p, st);
+    }
+  }
+  void launch_sq_trial() {
+    if (nblk_sq == 0) return;
+    if (opts.mode == SBA_MODE_CAMS_ONLY_SQ)
+      hipLaunchKernelGGL((k_sq_trial<T, 1>), dim3(nblk_sq), dim3(PM_BLOCK), lds_cams(), stream, ps_lm(), tsets(), d_state.p, C,
+                         uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, trial_part.p, nblk_sq);
+    else
+      hipLaunchKernelGGL((k_sq_trial<T, 2>), dim3(nblk_sq), dim3(PM_BLOCK), lds_cams(), stream, ps_lm(), tsets(), d_state.p, C,
+                         uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, trial_part.p, nblk_sq);
+  }
+  // cost (0.5 sum rho^2) and max |gradient| from the 16x16 sums of the last squared-variant linearization
+  void sq_read(double& cost, double& gmax) {
+    const int ng = (opts.mode == SBA_MODE_CAMS_ONLY_SQ) ? C : 1;
+    const int np = (opts.mode == SBA_MODE_CAMS_ONLY_SQ) ? NCP : 12;
+    std::vector<double> h((size_t)ng * 256);
+    HIPCHK(hipMemcpyAsync(h.data(), sq_16.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
+    sync();
+    cost = 0; gmax = 0;
+    for (int g = 0; g < ng; ++g) {
+      cost += 0.5 * h[(size_t)g * 256 + np * 16 + np];
+      for (int i = 0; i < np; ++i) gmax = std::max(gmax, std::fabs(h[(size_t)g * 256 + i * 16 + np]));
+    }
+  }
+
   // shared intrinsics (pySBA.py:252-325): unknowns [f,k1,k2 | 6 extrinsics x C | 2 centre x C], pySBA.py:313 order
   void build_tie_tables() {
     n_tied = 3 + 8 * C;
@@ -493,9 +564,7 @@ struct Engine : EngineBase {
     for (int k = 0; k < KP_N; ++k) { prof_us[k] = 0; prof_cnt[k] = 0; }
     pslot = 0;
     for (auto& u : pev_used) u = false;
-    if (opts.mode != SBA_MODE_FULL && opts.mode != SBA_MODE_POINTS_ONLY && opts.mode != SBA_MODE_SHARED_INTR) {
-      err = "unsupported mode"; return SBA_ERR_UNSUPPORTED;
-    }
+    if (opts.mode < SBA_MODE_FULL || opts.mode > SBA_MODE_TRANSFORM_SQ) { err = "unsupported mode"; return SBA_ERR_UNSUPPORTED; }
     if (opts.mode == SBA_MODE_SHARED_INTR) build_tie_tables();
     // initial cost; scipy raises ValueError when it is not finite (least_squares.py:844-845)
     double c0 = 0;
@@ -504,12 +573,18 @@ struct Engine : EngineBase {
     initial_cost = c0;
     LMState s{};
     s.lam = opts.lambda0 > 0 ? opts.lambda0 : 1e-4;
+    // x_scale = 1 (unscaled damping): lambda = tau * max diag(J^T J), set on the device.  tau is tiny because the
+    // parameters of these variants differ by orders of magnitude in scale (rotation vs focal length; affine matrix vs
+    // translation column), and only a near Gauss-Newton step moves the weakly scaled ones -- scipy gets the same
+    // effect from its large initial trust radius
+    if (sq_mode()) s.lam = -(opts.lambda0 > 0 ? opts.lambda0 : 1e-9);
     s.nu = 2.0;
     s.cost = c0;
     s.ftol = opts.ftol; s.xtol = opts.xtol; s.gtol = opts.gtol;
     s.lam_min = 1e-12; s.lam_max = 1e12;
     s.nfev = 1; s.njev = 1;
-    const long long nparam = (opts.mode == SBA_MODE_FULL ? (long long)n : opts.mode == SBA_MODE_SHARED_INTR ? (long long)n_tied : 0) + 3LL * N;
+    const long long nparam = opts.mode == SBA_MODE_CAMS_ONLY_SQ ? (long long)n : opts.mode == SBA_MODE_TRANSFORM_SQ ? 12LL :
+        (opts.mode == SBA_MODE_FULL ? (long long)n : opts.mode == SBA_MODE_SHARED_INTR ? (long long)n_tied : 0) + 3LL * N;
     s.max_nfev = opts.max_nfev > 0 ? opts.max_nfev : 100 * nparam;
     s.status = -1; s.fresh = 1; s.need_lin = 1;
     s.always_relin = opts.always_relinearize ? 1 : 0;
@@ -525,6 +600,22 @@ struct Engine : EngineBase {
     push_ptrs();
     cur_at_begin = cur;
     if (d_log.n == 0) d_log.alloc(LOG_CAP);
+    if (sq_mode()) {
+      // points never move in these variants, but the buffer parity flips with every accepted step: both sides equal
+      HIPCHK(hipMemcpyAsync(pts[1 - cur].p, pts[cur].p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToDevice, stream));
+      HIPCHK(hipMemcpyAsync(ptsT[1 - cur].p, ptsT[cur].p, sizeof(T) * (size_t)N * 3, hipMemcpyDeviceToDevice, stream));
+      sq_setup();
+      if (opts.mode == SBA_MODE_TRANSFORM_SQ) {
+        const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};     // x0 of pySBA.py:193
+        for (int b = 0; b < 2; ++b) HIPCHK(hipMemcpyAsync(theta[b].p, ident, sizeof ident, hipMemcpyHostToDevice, stream));
+      }
+      launch_sq_linearize(nullptr);
+      double g0 = 0;
+      sq_read(c0, g0);
+      initial_cost = c0;
+      h_state->cost = c0;
+      HIPCHK(hipMemcpyAsync(d_state.p, h_state, sizeof(LMState), hipMemcpyHostToDevice, stream));
+    }
     sync();
     log.clear();
     log_read = 0;
@@ -535,6 +626,7 @@ struct Engine : EngineBase {
 
   int lm_linearize() {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    if (sq_mode()) { launch_sq_linearize(d_state.p); return SBA_OK; }
     prof_begin(KP_LINP);
     launch_linearize_points(d_state.p);
     prof_end(KP_LINP);
@@ -544,6 +636,11 @@ struct Engine : EngineBase {
 
   int lm_form_reduced(double* E) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    if (sq_mode()) {
+      if (opts.mode == SBA_MODE_CAMS_ONLY_SQ)
+        hipLaunchKernelGGL(k_sq_pack_cams, dim3(64), dim3(256), 0, stream, sq_16.p, C, d_state.p, E);
+      return SBA_OK;
+    }
     if (h_state->free_cams) {
       prof_begin(KP_SCHUR);
       launch_schur();
@@ -563,6 +660,11 @@ struct Engine : EngineBase {
   // scal == nullptr: single rank, the partials are folded inside k_decide and no scalar exchange is needed
   int lm_solve_trial(double* E, double* scal) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    if (opts.mode == SBA_MODE_TRANSFORM_SQ) {
+      hipLaunchKernelGGL(k_sq_solve12, dim3(1), dim3(64), 0, stream, sq_16.p, d_state.p, tsets());
+      launch_sq_trial();
+      return SBA_OK;
+    }
     if (h_state->free_cams) {
       prof_begin(KP_CHOL);
       const bool tied = (opts.mode == SBA_MODE_SHARED_INTR);
@@ -617,6 +719,7 @@ struct Engine : EngineBase {
       if (N > 0)
         hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
     }
+    if (sq_mode()) { launch_sq_trial(); return SBA_OK; }
     prof_begin(KP_BACKSUB);
     launch_backsub_trial();
     prof_end(KP_BACKSUB);
@@ -629,7 +732,7 @@ struct Engine : EngineBase {
   int lm_decide_async(const double* scal_all, int n_ranks) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(1024), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
-                       gmax_part.p, nblk, reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
+                       gmax_part.p, sq_mode() ? nblk_sq : nblk, reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
     pslot_advance();
     return SBA_OK;
   }
@@ -672,6 +775,34 @@ struct Engine : EngineBase {
     int rc = lm_poll(&st, &it);          // refreshes `cur` and the log
     if (rc) return rc;
     push_ptrs();                         // table consistent with `cur` for the unconditional launches below
+    if (sq_mode()) {
+      launch_sq_linearize(nullptr);
+      double cost = 0, gmax = 0;
+      sq_read(cost, gmax);
+      if (opts.mode == SBA_MODE_TRANSFORM_SQ) {
+        HIPCHK(hipMemcpyAsync(h_theta, theta[cur].p, sizeof h_theta, hipMemcpyDeviceToHost, stream));
+        std::vector<double> X((size_t)N * 3);
+        HIPCHK(hipMemcpyAsync(X.data(), pts[cur].p, sizeof(double) * X.size(), hipMemcpyDeviceToHost, stream));
+        sync();
+        if (pts_out)
+          for (int p = 0; p < N; ++p)
+            for (int k = 0; k < 3; ++k)
+              pts_out[3 * (size_t)p + k] = h_theta[4 * k] * X[3 * (size_t)p] + h_theta[4 * k + 1] * X[3 * (size_t)p + 1] +
+                                           h_theta[4 * k + 2] * X[3 * (size_t)p + 2] + h_theta[4 * k + 3];
+      } else if (pts_out) {
+        HIPCHK(hipMemcpyAsync(pts_out, pts[cur].p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost, stream));
+      }
+      if (cams_out) HIPCHK(hipMemcpyAsync(cams_out, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+      sync();
+      if (rep) {
+        const LMState& s = *h_state;
+        rep->cost = cost; rep->initial_cost = initial_cost; rep->optimality = gmax; rep->step_norm = s.step_norm;
+        rep->lambda = s.lam; rep->nfev = s.nfev; rep->njev = s.njev; rep->iterations = s.iter; rep->accepted = s.n_accepted;
+        rep->status = s.status < 0 ? 0 : s.status;
+      }
+      lm_active = false;
+      return SBA_OK;
+    }
     // gradient norm at the returned point (scipy reports optimality there, trf.py:546-551)
     launch_linearize_points(nullptr);
     double gmax = 0;
@@ -934,6 +1065,12 @@ int sba_get_params(sba_handle* h, double* cams_out, double* points_out) {
     };
     return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
   });
+}
+
+int sba_get_transform(sba_handle* h, double* theta12_out) {
+  if (!h || !theta12_out) return SBA_ERR_INVALID;
+  auto get = [&](auto* e) { for (int i = 0; i < 12; ++i) theta12_out[i] = e->h_theta[i]; return (int)SBA_OK; };
+  return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
 }
 
 int sba_get_gradient(sba_handle* h, double* gc_out, double* gp_out) {

@@ -289,15 +289,44 @@ class PySBA:
         A.data[:] = 1
         return lil_matrix(A)
 
+    def _solve_sq(self, mode, ftol, verbose=2):
+        """Squared-pixel-error variants (pySBA.py:151-205): scipy defaults x_scale=1, xtol=gtol=1e-8."""
+        cams = np.ascontiguousarray(self.cameraArray, dtype=np.float64)
+        pts = np.ascontiguousarray(self.points3D, dtype=np.float64)
+        w = self._weights_or_none()
+        with _native.Problem(cams, pts, self.points2D, self.cameraIndices, self.point2DIndices, weights=w,
+                             dtype=_env_dtype(), device=_env_device()) as prob:
+            opts = prob.make_opts(ftol=ftol, xtol=1e-8, gtol=1e-8, mode=mode, verbose=verbose)
+            cams_opt, pts_opt, rep, log = prob.solve_lm(opts)
+            theta = prob.get_transform() if mode == _native.MODE_TRANSFORM_SQ else None
+            # residual of the reference's function: w * (pixel error)^2, from the device's w * (pixel error)
+            r, _ = prob.residual(np.hstack((cams_opt.ravel(), pts_opt.ravel())))
+        wv = np.ones(r.size // 2) if w is None else w
+        with np.errstate(divide="ignore", invalid="ignore"):
+            fvec = np.where(np.repeat(wv, 2) != 0, r * r / np.repeat(wv, 2), 0.0)
+        x = cams_opt.ravel().copy() if mode == _native.MODE_CAMS_ONLY_SQ else theta
+        message = TERMINATION_MESSAGES[rep.status]
+        _print_table(log, rep.initial_cost, rep, message, verbose)
+        res = SBAResult(x=x, cost=rep.cost, fun=fvec, optimality=rep.optimality, active_mask=np.zeros_like(x),
+                        nfev=int(rep.nfev), njev=int(rep.njev), status=int(rep.status), message=message,
+                        success=rep.status > 0)
+        return res, cams_opt, pts_opt
+
     def bundle_adjustment_camonly(self, ftol=1e-4):
-        """pySBA.py:160-173 -- not on the device yet."""
-        raise NotImplementedError("bundle_adjustment_camonly is not implemented on the MI355X engine yet; "
-                                  "there is deliberately no CPU fallback")
+        """Optimise the cameras with the points held fixed, on the SQUARED pixel error (pySBA.py:151-173)."""
+        res, cams, _pts = self._solve_sq(_native.MODE_CAMS_ONLY_SQ, ftol)
+        self.cameraArray = cams
+        return res
 
     def bundleAdjust_transform_points_3d(self, ftol=1e-3):
-        """pySBA.py:190-205 -- not on the device yet."""
-        raise NotImplementedError("bundleAdjust_transform_points_3d is not implemented on the MI355X engine yet; "
-                                  "there is deliberately no CPU fallback")
+        """Fit one 3x4 affine applied to all 3-D points, cameras fixed, squared pixel error (pySBA.py:176-205).
+
+        res.x holds the 12 parameters (row-major 3x4, starting from the identity); self.points3D is replaced by the
+        transformed points like in the reference (pySBA.py:197-204).
+        """
+        res, _cams, pts = self._solve_sq(_native.MODE_TRANSFORM_SQ, ftol)
+        self.points3D = pts
+        return res
 
     def bundleAdjust_sharedcam(self, ftol=1e-6):
         """Bundle adjustment with one (f, k1, k2) shared by all cameras (pySBA.py:297-325).

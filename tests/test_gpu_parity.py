@@ -318,6 +318,42 @@ def test_sharedcam_matches_reference(golden):
     assert abs(np.max(np.abs(res.grad)) - res.optimality) <= 1e-6 * max(1.0, res.optimality)
 
 
+def test_camonly_squared_error_variant(golden):
+    """PySBA.bundle_adjustment_camonly (pySBA.py:151-173): cameras free, points fixed, residual = w*(pixel error)^2."""
+    g = golden("f5_variants.npz")
+    sba = PySBA(g["cams0"].copy(), g["pts0"].copy(), g["uv"], g["ci"], g["pi"])
+    res = sba.bundle_adjustment_camonly()                      # ftol = 1e-4 like the reference's default
+    C, N = g["cams0"].shape[0], g["pts0"].shape[0]
+    ref = float(g["camonly_cost"])
+    assert res.status in (2, 3, 4) and res.x.shape == (11 * C,)
+    assert np.array_equal(sba.points3D, g["pts0"]) and np.array_equal(res.x.reshape(C, 11), sba.cameraArray)
+    # both solvers stop on ftol = 1e-4: the costs agree to within that stopping tolerance
+    assert abs(res.cost - ref) <= 1e-4 * ref
+    f = orc.fun_camonly(res.x, C, N, g["ci"], g["pi"], g["uv"], 1.0, g["pts0"])      # the reference's own residual function
+    assert np.max(np.abs(f - res.fun)) <= 1e-6 and abs(0.5 * f @ f - res.cost) <= 1e-9 * res.cost
+    again, _ = orc.bundle_adjust_camonly(sba.cameraArray, g["pts0"], g["uv"], g["ci"], g["pi"], ftol=1e-4)
+    assert again.cost >= res.cost * (1 - 1e-4)
+
+
+def test_transform_points_3d_squared_error_variant(golden):
+    """PySBA.bundleAdjust_transform_points_3d (pySBA.py:176-205): one 3x4 affine on the points, squared pixel error."""
+    g = golden("f5_variants.npz")
+    sba = PySBA(g["cams0"].copy(), g["pts0"].copy(), g["uv"], g["ci"], g["pi"])
+    res = sba.bundleAdjust_transform_points_3d()               # ftol = 1e-3
+    C, N = g["cams0"].shape[0], g["pts0"].shape[0]
+    ref = float(g["transform_cost"])
+    assert res.status in (2, 3, 4) and res.x.shape == (12,)
+    assert np.array_equal(sba.cameraArray, g["cams0"])
+    assert abs(res.cost - ref) <= 1e-3 * ref                  # within the stopping tolerance both solvers used
+    f = orc.fun_transform_points_3d(res.x, C, N, g["cams0"], g["ci"], g["pi"], g["uv"], 1.0, g["pts0"])
+    assert np.max(np.abs(f - res.fun)) <= 1e-6 and abs(0.5 * f @ f - res.cost) <= 1e-9 * res.cost
+    T = np.vstack((res.x.reshape(3, 4), [0, 0, 0, 1]))
+    moved = (T @ np.vstack((g["pts0"].T, np.ones((1, N))))).T[:, :3]
+    assert np.max(np.abs(moved - sba.points3D)) <= 1e-9       # points3D replaced by the transformed points (pySBA.py:197-204)
+    assert np.max(np.abs(sba.points3D - g["transform_pts"])) <= 0.5      # mm, against the reference's result
+    assert np.max(np.abs(res.x - g["transform_x"])[[0, 1, 2, 4, 5, 6, 8, 9, 10]]) <= 2e-3
+
+
 def test_nonfinite_start_raises_value_error():
     rig = make_rig(2, 50, seed=1)
     cams = rig["cams0"].copy()
