@@ -256,6 +256,28 @@ def test_weighted_solve_matches_oracle():
     assert abs(rep.cost - out["cost"]) <= 1e-8 * out["cost"]
 
 
+def test_config2_scipy_drives_device_residual_and_jacobian():
+    """BASELINE config 2: 8 cams x 5k points, fp64, only the residual / Jacobian kernels on the GPU while scipy's TRF
+    still drives the iterations (same keyword set as pySBA.py:141 except that jac= is the analytic device Jacobian)."""
+    from scipy.optimize import least_squares
+    rig = make_rig(8, 5000, seed=0)
+    C, N = 8, 5000
+    ci, pi, uv = rig["camera_ind"], rig["point_ind"], rig["points_2d"]
+    x0 = np.hstack((rig["cams0"].ravel(), rig["pts0"].ravel()))
+    with _native.Problem(rig["cams0"], rig["pts0"], uv, ci, pi) as prob:
+        fun = lambda x: prob.residual(x)[0]
+
+        def jac(x):
+            _, Jc, Jp = prob.residual_jacobian(x)
+            return assemble_jacobian(Jc, Jp, ci, pi, C, N)
+        res = least_squares(fun, x0, jac=jac, x_scale="jac", ftol=1e-4, method="trf")
+    ref, _, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], uv, ci, pi, ftol=1e-4)
+    # same optimiser, same stopping rule; the Jacobians differ by the FD truncation error only
+    assert res.status == ref.status and abs(res.nfev - ref.nfev) <= 1
+    assert abs(res.cost - ref.cost) <= 1e-6 * ref.cost
+    assert np.max(np.abs(res.x - ref.x)) <= 5e-2      # px / mm; LSMR amplifies the FD-vs-analytic Jacobian difference along weak directions
+
+
 # ----------------------------------------------------------------------------- class surface end to end
 def test_pysba_bundleAdjust_surface(golden, capsys):
     g = golden("f4_solves.npz")
