@@ -294,7 +294,9 @@ struct Engine : EngineBase {
     {
       int target = 256;
       if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
-      int ks = std::max(1, target / npairs);
+      // workgroups per k-split: every pair is dealt to TS workgroups (tile split, grid.z of k_schur)
+      const int wg_per_ks = ngroups * SchurCfg<T, true>::TS + (npairs - ngroups) * SchurCfg<T, false>::TS;
+      int ks = std::max(1, target / wg_per_ks);
       const int maxks = std::max(1, (N + SCHUR_PTS - 1) / SCHUR_PTS);
       ksplit = std::min(ks, maxks);
     }
@@ -389,7 +391,7 @@ struct Engine : EngineBase {
     // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
     using CfgD = SchurCfg<T, true>;
     using CfgO = SchurCfg<T, false>;
-    hipLaunchKernelGGL((k_schur<T, true>), dim3(ksplit, ngroups), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
+    hipLaunchKernelGGL((k_schur<T, true>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
                        stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
                        pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,
                        schur_debug ? schur_dbg.p : nullptr);
@@ -403,7 +405,7 @@ struct Engine : EngineBase {
       schur_debug = false;
     }
     if (npairs > ngroups)
-      hipLaunchKernelGGL((k_schur<T, false>), dim3(ksplit, npairs - ngroups), dim3(CfgO::THREADS),
+      hipLaunchKernelGGL((k_schur<T, false>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
                          CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
                          has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
                          pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);

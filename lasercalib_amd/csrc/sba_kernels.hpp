@@ -15,6 +15,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 #include "sba_model.hpp"
 
 namespace sba {
@@ -467,13 +469,17 @@ __global__ void k_point_factor(const double* __restrict__ V, const double* __res
 //   !DIAG (ga <  gb): two panels, 121 tiles over 8 consumer waves                (grid = (ksplit, npairs - ngroups))
 //   slab layout: [pair][ks][tile (121 slots)][reg 4][lane 64]   (acc type T)
 //   bpart layout: [ga][ks][176] doubles (only diagonal pairs contribute)
-template <bool DIAG> struct SchurThreads { static constexpr int value = DIAG ? 512 : 1024; };
+constexpr int SCHUR_THREADS = 512;                           // 4 producer waves + 4 consumer waves
 template <typename T, bool DIAG> struct SchurCfg {
-  static constexpr int THREADS = SchurThreads<DIAG>::value;
+  static constexpr int THREADS = SCHUR_THREADS;
   static constexpr int NPROD = THREADS / 2;                  // producer threads (first half of the workgroup)
   static constexpr int NCW = THREADS / 128;                  // consumer waves
   static constexpr int NTILE = DIAG ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : GROUP_TILES * GROUP_TILES;
-  static constexpr int MAXSLOT = (NTILE + NCW - 1) / NCW;    // 17 or 16
+  // tile split: the pair's tiles are dealt to TS workgroups (grid.z) so that a consumer wave never holds more than
+  // ~17 f32 / ~9 f64 accumulator tiles (<= 72 VGPRs); every workgroup of a split still builds the whole panel
+  static constexpr int TS = DIAG ? (sizeof(T) == 8 ? 2 : 1) : (sizeof(T) == 8 ? 4 : 2);
+  static constexpr int NV = NCW * TS;                        // "virtual" consumer waves of a pair
+  static constexpr int TPW = (NTILE + NV - 1) / NV;          // tiles per consumer wave: 17 / 9 / 16 / 8
   static constexpr int PTS = (!DIAG && sizeof(T) == 8) ? 8 : 16;   // points per chunk (LDS budget: 2 buffers x panels)
   static constexpr int K = 3 * PTS;
   static constexpr int NPANEL = DIAG ? 1 : 2;
@@ -481,72 +487,94 @@ template <typename T, bool DIAG> struct SchurCfg {
   static constexpr size_t LDS_BYTES = (size_t)(2 * BUF + 2 * GROUP_CAMS * CAMPRE) * sizeof(T);
 };
 
-__device__ inline void schur_tile_rc(bool diag, int t, int& R, int& Tc) {
-  if (diag) {  // upper-triangular enumeration: row R has (11-R) tiles
-    int rem = t; R = 0;
-    while (rem >= GROUP_TILES - R) { rem -= GROUP_TILES - R; ++R; }
-    Tc = R + rem;
-  } else { R = t / GROUP_TILES; Tc = t - R * GROUP_TILES; }
+// row-major enumeration of a pair's tiles: upper triangle (R <= Tc) for a diagonal pair, all 11x11 otherwise
+__host__ __device__ constexpr int schur_tile_R(bool diag, int t) {
+  if (!diag) return t / GROUP_TILES;
+  int R = 0, rem = t;
+  while (rem >= GROUP_TILES - R) { rem -= GROUP_TILES - R; ++R; }
+  return R;
+}
+__host__ __device__ constexpr int schur_tile_T(bool diag, int t) {
+  if (!diag) return t % GROUP_TILES;
+  int R = 0, rem = t;
+  while (rem >= GROUP_TILES - R) { rem -= GROUP_TILES - R; ++R; }
+  return R + rem;
+}
+__device__ inline void schur_tile_rc(bool diag, int t, int& R, int& Tc) { R = schur_tile_R(diag, t); Tc = schur_tile_T(diag, t); }
+// compile-time loop: f(integral_constant<int, LO>) ... f(integral_constant<int, HI-1>)
+template <int LO, int HI, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (LO < HI) { f(std::integral_constant<int, LO>{}); static_for<LO + 1, HI>(f); }
 }
 
-// Static tile ownership of the 4 consumer waves of a diagonal pair: whole block-rows of the upper triangle, paired so
-// that every wave owns 15-17 tiles.  With the rows known at compile time one k-step needs only the (<= 11) distinct
-// 16-row fragments of the panel (A and B operands of a diagonal pair are the same fragments), all MFMAs of a k-step
-// are independent, and the next k-step's fragments are fetched while they issue.
-__host__ __device__ constexpr int diag_row_of(int cw, int k) {
-  constexpr int rows[4][5] = {{0, 5, -1, -1, -1}, {1, 4, -1, -1, -1}, {2, 3, -1, -1, -1}, {6, 7, 8, 9, 10}};
-  return rows[cw][k];
-}
-__host__ __device__ constexpr int diag_min_row(int cw) { return cw == 3 ? 6 : cw; }
-__host__ __device__ constexpr int diag_tile_index(int R, int Tc) { return R * GROUP_TILES - (R * (R - 1)) / 2 + (Tc - R); }
-
-template <typename T, int CW, int K>
-__device__ inline void schur_consume_diag(const T* __restrict__ pl /* panel + lane offset */,
-                                          typename Mfma<T>::acc_t (&acc)[17]) {
+// Consumer wave V of a pair owns the contiguous tile range [V*TPW, V*TPW+TPW): consecutive tiles share their row, so
+// with V a compile-time constant one k-step needs only the distinct 16-row fragments (<= 11 for a diagonal pair, whose
+// A and B operands are the same panel fragments; <= 3 + 11 otherwise), all MFMAs of a k-step are independent, and the
+// next k-step's fragments are fetched while they issue.
+template <typename T, bool DIAG, int V, int K>
+__device__ inline void schur_consume(const T* __restrict__ pla /* panelA + lane offset */, const T* __restrict__ plb,
+                                     typename Mfma<T>::acc_t (&acc)[SchurCfg<T, DIAG>::TPW]) {
   using M_ = Mfma<T>;
-  constexpr int RMIN = diag_min_row(CW);
-  T f[2][GROUP_TILES];
+  using Cfg = SchurCfg<T, DIAG>;
+  constexpr int LO = V * Cfg::TPW, HI = (LO + Cfg::TPW < Cfg::NTILE) ? LO + Cfg::TPW : Cfg::NTILE;
+  if constexpr (LO < HI) {
+    constexpr int RMIN = schur_tile_R(DIAG, LO), RMAX = schur_tile_R(DIAG, HI - 1);
+    T fa[2][GROUP_TILES], fb[2][GROUP_TILES];
+    auto load = [&](int buf, int ks) {
+      if constexpr (DIAG) {
 #pragma unroll
-  for (int b = RMIN; b < GROUP_TILES; ++b) f[0][b] = pl[16 * b];
+        for (int b = RMIN; b < GROUP_TILES; ++b) fa[buf][b] = pla[ks * 4 * GROUP_ROWS + 16 * b];
+      } else {
 #pragma unroll
-  for (int ks = 0; ks < K / 4; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < K / 4) {
+        for (int b = RMIN; b <= RMAX; ++b) fa[buf][b] = pla[ks * 4 * GROUP_ROWS + 16 * b];
 #pragma unroll
-      for (int b = RMIN; b < GROUP_TILES; ++b) f[cur ^ 1][b] = pl[(ks + 1) * 4 * GROUP_ROWS + 16 * b];
-    }
-    int slot = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int R = diag_row_of(CW, k);
-      if (R >= 0) {
-#pragma unroll
-        for (int Tc = R; Tc < GROUP_TILES; ++Tc) { acc[slot] = M_::mma(f[cur][R], f[cur][Tc], acc[slot]); ++slot; }
+        for (int b = 0; b < GROUP_TILES; ++b) fb[buf][b] = plb[ks * 4 * GROUP_ROWS + 16 * b];
       }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < K / 4; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < K / 4) load(cur ^ 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of this step's MFMAs (the scheduler sinks it otherwise)
+      static_for<LO, HI>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int R = schur_tile_R(DIAG, t), Tc = schur_tile_T(DIAG, t);
+        acc[t - LO] = M_::mma(fa[cur][R], DIAG ? fa[cur][Tc] : fb[cur][Tc], acc[t - LO]);
+      });
     }
   }
 }
 
-template <typename T, int CW>
-__device__ inline void schur_store_diag(T* __restrict__ slab, int lane, const typename Mfma<T>::acc_t (&acc)[17]) {
-  int slot = 0;
+template <typename T, bool DIAG, int V>
+__device__ inline void schur_store(T* __restrict__ slab, int lane, const typename Mfma<T>::acc_t (&acc)[SchurCfg<T, DIAG>::TPW]) {
+  using Cfg = SchurCfg<T, DIAG>;
+  constexpr int LO = V * Cfg::TPW, HI = (LO + Cfg::TPW < Cfg::NTILE) ? LO + Cfg::TPW : Cfg::NTILE;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int R = diag_row_of(CW, k);
-    if (R >= 0) {
+  for (int t = LO; t < HI; ++t) {
 #pragma unroll
-      for (int Tc = R; Tc < GROUP_TILES; ++Tc) {
-        const int t = diag_tile_index(R, Tc);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) slab[(size_t)t * 256 + rg * 64 + lane] = acc[slot][rg];
-        ++slot;
-      }
-    }
+    for (int rg = 0; rg < 4; ++rg) slab[(size_t)t * 256 + rg * 64 + lane] = acc[t - LO][rg];
   }
 }
 
+// dispatch on the (runtime) virtual wave index; NV <= 16
+template <typename T, bool DIAG, int K, int V = 0>
+__device__ inline void schur_consume_v(int v, const T* pla, const T* plb, typename Mfma<T>::acc_t (&acc)[SchurCfg<T, DIAG>::TPW]) {
+  if constexpr (V < SchurCfg<T, DIAG>::NV) {
+    if (v == V) schur_consume<T, DIAG, V, K>(pla, plb, acc);
+    else schur_consume_v<T, DIAG, K, V + 1>(v, pla, plb, acc);
+  }
+}
+template <typename T, bool DIAG, int V = 0>
+__device__ inline void schur_store_v(int v, T* slab, int lane, const typename Mfma<T>::acc_t (&acc)[SchurCfg<T, DIAG>::TPW]) {
+  if constexpr (V < SchurCfg<T, DIAG>::NV) {
+    if (v == V) schur_store<T, DIAG, V>(slab, lane, acc);
+    else schur_store_v<T, DIAG, V + 1>(v, slab, lane, acc);
+  }
+}
+
+// ------------------------------------------------------------------ K4: the kernel.  grid = (ksplit, pairs of this kind, TS)
 template <typename T, bool DIAG>
-__global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
     const ParamSets<T> ps, const LMState* __restrict__ st, int C,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start, int N,
@@ -554,9 +582,8 @@ __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
     int pair0, int ksplit, int dense, T* __restrict__ slabs, double* __restrict__ bpart,
     long long* __restrict__ dbg /* optional cycle stamps of workgroup (0,0): [it][producer done, consumer done, barrier out] */) {
   extern __shared__ __align__(16) unsigned char smem[];
-  using M_ = Mfma<T>;
   using Cfg = SchurCfg<T, DIAG>;
-  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, NCW = Cfg::NCW, MAXSLOT = Cfg::MAXSLOT, NTILE = Cfg::NTILE;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, NCW = Cfg::NCW, TPW = Cfg::TPW;
   constexpr int PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF;
   if (st->status >= 0) return;
   const int cur_ = ps_cur(ps, st);
@@ -576,11 +603,13 @@ __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool producer = threadIdx.x < NPROD;
   const int cw = wid - NPROD / 64;                                // consumer wave index (valid when !producer)
+  const int vw = (int)blockIdx.z * NCW + cw;                      // virtual consumer wave of the pair
   const int ct = threadIdx.x - NPROD;                             // consumer thread index
-  typename M_::acc_t acc[MAXSLOT];
+  typename Mfma<T>::acc_t acc[TPW];
 #pragma unroll
-  for (int s = 0; s < MAXSLOT; ++s) acc[s] = typename M_::acc_t{0, 0, 0, 0};
-  double bacc = 0;   // consumer thread rho < 176 accumulates the rhs contribution of row rho (diag pairs only)
+  for (int s = 0; s < TPW; ++s) acc[s] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+  double bacc = 0;   // consumer thread rho < 176 of split 0 accumulates the rhs contribution of row rho (diag pairs only)
+  const bool do_rhs = DIAG && blockIdx.z == 0;
   const int lane_off = (lane >> 4) * GROUP_ROWS + (lane & 15);
 
   // slice of points for this k-split (multiple of PTS)
@@ -607,7 +636,7 @@ __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
     }
   };
   // a chunk holds at most PTS*C observations: one per producer lane only when all cameras are in this one group
-  const bool piped = DIAG && (C <= GROUP_CAMS) && sizeof(T) == 4;   // f64 has no registers to spare for the pipeline state
+  const bool piped = DIAG && (C <= GROUP_CAMS);
   if (piped && producer) {
     load_idx(0, cur_valid, cur_c, cur_p, cur_uv, cur_w);
     if (cur_valid) {
@@ -618,6 +647,9 @@ __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
     load_idx(1, n1_valid, n1_c, n1_p, n1_uv, n1_w);
   }
   __syncthreads();
+  // the consumer waves are the second-dispatched half of the workgroup and lose the per-SIMD issue arbitration against
+  // their producer partner by age; their MFMAs pace the kernel, so they get static priority
+  if (!producer) __builtin_amdgcn_s_setprio(2);
   for (int it = 0; it <= nchunk; ++it) {
     if (producer) {
       if (it < nchunk) {
@@ -699,42 +731,20 @@ __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
       const T* panelB = DIAG ? panelA : panelA + K * GROUP_ROWS;
       const T* s_z = buf + Cfg::NPANEL * K * GROUP_ROWS;
       // rhs: b[rho] += sum_k panel[k][rho] * z[k]
-      if (DIAG && ct < GROUP_ROWS) {
+      if (do_rhs && ct < GROUP_ROWS) {
         T s0 = 0, s1 = 0;
 #pragma unroll 8
         for (int k = 0; k < K; k += 2) { s0 += panelA[k * GROUP_ROWS + ct] * s_z[k]; s1 += panelA[(k + 1) * GROUP_ROWS + ct] * s_z[k + 1]; }
         bacc += (double)(s0 + s1);
       }
-      if constexpr (DIAG) {
-        static_assert(MAXSLOT == 17, "diagonal pairs: 4 consumer waves x <= 17 tiles");
-        const T* pl = panelA + lane_off;
-        switch (cw) {
-          case 0: schur_consume_diag<T, 0, K>(pl, acc); break;
-          case 1: schur_consume_diag<T, 1, K>(pl, acc); break;
-          case 2: schur_consume_diag<T, 2, K>(pl, acc); break;
-          default: schur_consume_diag<T, 3, K>(pl, acc); break;
-        }
-      } else {
-        // generic (off-diagonal pairs): k-step outer so that consecutive MFMAs are independent
-#pragma unroll
-        for (int ks = 0; ks < K / 4; ++ks) {
-#pragma unroll
-          for (int s = 0; s < MAXSLOT; ++s) {
-            const int t = cw + NCW * s;
-            if (t < NTILE) {
-              const int R = t / GROUP_TILES, Tc = t - R * GROUP_TILES;
-              acc[s] = M_::mma(panelA[lane_off + 16 * R + ks * 4 * GROUP_ROWS], panelB[lane_off + 16 * Tc + ks * 4 * GROUP_ROWS], acc[s]);
-            }
-          }
-        }
-      }
+      schur_consume_v<T, DIAG, K>(vw, panelA + lane_off, panelB + lane_off, acc);
     }
-    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && it < 20) {
+    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && it < 20) {
       if (threadIdx.x == 0) dbg[3 * it + 0] = clock64();
       if (threadIdx.x == NPROD) dbg[3 * it + 1] = clock64();
     }
     __syncthreads();
-    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && it < 20 && threadIdx.x == 0) dbg[3 * it + 2] = clock64();
+    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && it < 20 && threadIdx.x == 0) dbg[3 * it + 2] = clock64();
     if (!dense && it >= 1) {
       // sparse visibility: not every panel entry is rewritten by the next chunk, so the buffer that was just
       // consumed is cleared by the whole workgroup before the producers get it back
@@ -746,24 +756,8 @@ __global__ __launch_bounds__(SchurThreads<DIAG>::value) void k_schur(
   // write partial tiles
   if (!producer) {
     T* slab = slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
-    if constexpr (DIAG) {
-      switch (cw) {
-        case 0: schur_store_diag<T, 0>(slab, lane, acc); break;
-        case 1: schur_store_diag<T, 1>(slab, lane, acc); break;
-        case 2: schur_store_diag<T, 2>(slab, lane, acc); break;
-        default: schur_store_diag<T, 3>(slab, lane, acc); break;
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < MAXSLOT; ++s) {
-        const int t = cw + NCW * s;
-        if (t < NTILE) {
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) slab[(size_t)t * 256 + rg * 64 + lane] = acc[s][rg];
-        }
-      }
-    }
-    if (DIAG && ct < GROUP_ROWS)
+    schur_store_v<T, DIAG>(vw, slab, lane, acc);
+    if (do_rhs && ct < GROUP_ROWS)
       bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + ct] = bacc;
   }
 }
