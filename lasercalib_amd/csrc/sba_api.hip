@@ -187,6 +187,8 @@ struct Engine : EngineBase {
     // kernels whose dynamic LDS can exceed the 64 KB default
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -295,7 +297,7 @@ struct Engine : EngineBase {
       int target = 256;
       if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
       // workgroups per k-split: every pair is dealt to TS workgroups (tile split, grid.z of k_schur)
-      const int wg_per_ks = ngroups * SchurCfg<T, true>::TS + (npairs - ngroups) * SchurCfg<T, false>::TS;
+      const int wg_per_ks = ngroups * SchurSel<T, true>::TS + (npairs - ngroups) * SchurSel<T, false>::TS;
       int ks = std::max(1, target / wg_per_ks);
       const int maxks = std::max(1, (N + SCHUR_PTS - 1) / SCHUR_PTS);
       ksplit = std::min(ks, maxks);
@@ -389,8 +391,28 @@ struct Engine : EngineBase {
     if (N > 0)
       hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
     // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
-    using CfgD = SchurCfg<T, true>;
-    using CfgO = SchurCfg<T, false>;
+    using CfgD = SchurSel<T, true>;
+    using CfgO = SchurSel<T, false>;
+    if constexpr (SCHUR_SYM<T>) {
+      hipLaunchKernelGGL((k_schur_sym<T, true>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
+                         stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
+                         pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p, schur_debug ? schur_dbg.p : nullptr);
+      if (schur_debug) {
+        std::vector<long long> st(64);
+        HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+        sync();
+        fprintf(stderr, "[schur_sym stamps, cycles; per chunk: produce-done after-barrier consume-done]\n");
+        for (int i = 0; i < 8; ++i)
+          fprintf(stderr, "  it %2d: P %7lld  B %7lld  C %7lld\n", i, st[3 * i] - st[0], st[3 * i + 1] - st[0], st[3 * i + 2] - st[0]);
+        schur_debug = false;
+      }
+      if (npairs > ngroups)
+        hipLaunchKernelGGL((k_schur_sym<T, false>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
+                           CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
+                           has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
+                           pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
+      return;
+    }
     hipLaunchKernelGGL((k_schur<T, true>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
                        stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
                        pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,

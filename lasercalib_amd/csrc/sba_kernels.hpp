@@ -471,6 +471,8 @@ __global__ void k_point_factor(const double* __restrict__ V, const double* __res
 //   bpart layout: [ga][ks][176] doubles (only diagonal pairs contribute)
 constexpr int SCHUR_THREADS = 512;                           // 4 producer waves + 4 consumer waves
 template <typename T, bool DIAG> struct SchurCfg {
+  using elem = T;
+  static constexpr bool diag = DIAG;
   static constexpr int THREADS = SCHUR_THREADS;
   static constexpr int NPROD = THREADS / 2;                  // producer threads (first half of the workgroup)
   static constexpr int NCW = THREADS / 128;                  // consumer waves
@@ -506,15 +508,42 @@ template <int LO, int HI, typename F> __device__ __forceinline__ void static_for
   if constexpr (LO < HI) { f(std::integral_constant<int, LO>{}); static_for<LO + 1, HI>(f); }
 }
 
+// Symmetric variant (used for f64): all 8 waves first build the panel of a chunk, then all 8 consume it.  f32/f64 MFMA
+// and VALU instructions of the two waves of a SIMD do not overlap on gfx950 (tools/micro/mix_rate.hip: the times add),
+// so specialising waves buys nothing beyond latency hiding, while the f64 accumulators of a pair (66 tiles x 8 VGPRs)
+// only fit when they are spread over all 8 waves; v_mfma_f64_16x16x4 runs at 64 cycles per SIMD with LDS-fed
+// operands (tools/micro/mfma64_lds.hip), which is the floor of the consume phase.
+template <typename T, bool DIAG> struct SchurSymCfg {
+  using elem = T;
+  static constexpr bool diag = DIAG;
+  static constexpr int THREADS = SCHUR_THREADS;
+  static constexpr int NCW = THREADS / 64;                   // every wave consumes
+  static constexpr int NTILE = DIAG ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : GROUP_TILES * GROUP_TILES;
+  static constexpr int TS = DIAG ? 1 : 2;
+  static constexpr int NV = NCW * TS;
+  static constexpr int TPW = (NTILE + NV - 1) / NV;          // 9 / 8 tiles per wave
+  static constexpr int PTS = DIAG ? 32 : 16;                 // one single-buffered chunk: 96 (48+48) panel rows
+  static constexpr int K = 3 * PTS;
+  static constexpr int NPANEL = DIAG ? 1 : 2;
+  static constexpr int BUF = NPANEL * K * GROUP_ROWS + K;
+  static constexpr size_t LDS_BYTES = (size_t)(BUF + 2 * GROUP_CAMS * CAMPRE) * sizeof(T);
+};
+
+// which flavour runs: f64 -> symmetric, f32 -> producer/consumer specialised
+template <typename T> constexpr bool SCHUR_SYM = sizeof(T) == 8;
+template <typename T, bool DIAG> using SchurSel = std::conditional_t<SCHUR_SYM<T>, SchurSymCfg<T, DIAG>, SchurCfg<T, DIAG>>;
+
 // Consumer wave V of a pair owns the contiguous tile range [V*TPW, V*TPW+TPW): consecutive tiles share their row, so
 // with V a compile-time constant one k-step needs only the distinct 16-row fragments (<= 11 for a diagonal pair, whose
 // A and B operands are the same panel fragments; <= 3 + 11 otherwise), all MFMAs of a k-step are independent, and the
 // next k-step's fragments are fetched while they issue.
-template <typename T, bool DIAG, int V, int K>
-__device__ inline void schur_consume(const T* __restrict__ pla /* panelA + lane offset */, const T* __restrict__ plb,
-                                     typename Mfma<T>::acc_t (&acc)[SchurCfg<T, DIAG>::TPW]) {
+template <typename Cfg, int V, int K>
+__device__ inline void schur_consume(const typename Cfg::elem* __restrict__ pla /* panelA + lane offset */,
+                                     const typename Cfg::elem* __restrict__ plb,
+                                     typename Mfma<typename Cfg::elem>::acc_t (&acc)[Cfg::TPW]) {
+  using T = typename Cfg::elem;
   using M_ = Mfma<T>;
-  using Cfg = SchurCfg<T, DIAG>;
+  constexpr bool DIAG = Cfg::diag;
   constexpr int LO = V * Cfg::TPW, HI = (LO + Cfg::TPW < Cfg::NTILE) ? LO + Cfg::TPW : Cfg::NTILE;
   if constexpr (LO < HI) {
     constexpr int RMIN = schur_tile_R(DIAG, LO), RMAX = schur_tile_R(DIAG, HI - 1);
@@ -545,9 +574,9 @@ __device__ inline void schur_consume(const T* __restrict__ pla /* panelA + lane 
   }
 }
 
-template <typename T, bool DIAG, int V>
-__device__ inline void schur_store(T* __restrict__ slab, int lane, const typename Mfma<T>::acc_t (&acc)[SchurCfg<T, DIAG>::TPW]) {
-  using Cfg = SchurCfg<T, DIAG>;
+template <typename Cfg, int V>
+__device__ inline void schur_store(typename Cfg::elem* __restrict__ slab, int lane,
+                                   const typename Mfma<typename Cfg::elem>::acc_t (&acc)[Cfg::TPW]) {
   constexpr int LO = V * Cfg::TPW, HI = (LO + Cfg::TPW < Cfg::NTILE) ? LO + Cfg::TPW : Cfg::NTILE;
 #pragma unroll
   for (int t = LO; t < HI; ++t) {
@@ -557,19 +586,61 @@ __device__ inline void schur_store(T* __restrict__ slab, int lane, const typenam
 }
 
 // dispatch on the (runtime) virtual wave index; NV <= 16
-template <typename T, bool DIAG, int K, int V = 0>
-__device__ inline void schur_consume_v(int v, const T* pla, const T* plb, typename Mfma<T>::acc_t (&acc)[SchurCfg<T, DIAG>::TPW]) {
-  if constexpr (V < SchurCfg<T, DIAG>::NV) {
-    if (v == V) schur_consume<T, DIAG, V, K>(pla, plb, acc);
-    else schur_consume_v<T, DIAG, K, V + 1>(v, pla, plb, acc);
+template <typename Cfg, int K, int V = 0>
+__device__ inline void schur_consume_v(int v, const typename Cfg::elem* pla, const typename Cfg::elem* plb,
+                                       typename Mfma<typename Cfg::elem>::acc_t (&acc)[Cfg::TPW]) {
+  if constexpr (V < Cfg::NV) {
+    if (v == V) schur_consume<Cfg, V, K>(pla, plb, acc);
+    else schur_consume_v<Cfg, K, V + 1>(v, pla, plb, acc);
   }
 }
-template <typename T, bool DIAG, int V = 0>
-__device__ inline void schur_store_v(int v, T* slab, int lane, const typename Mfma<T>::acc_t (&acc)[SchurCfg<T, DIAG>::TPW]) {
-  if constexpr (V < SchurCfg<T, DIAG>::NV) {
-    if (v == V) schur_store<T, DIAG, V>(slab, lane, acc);
-    else schur_store_v<T, DIAG, V + 1>(v, slab, lane, acc);
+template <typename Cfg, int V = 0>
+__device__ inline void schur_store_v(int v, typename Cfg::elem* slab, int lane,
+                                     const typename Mfma<typename Cfg::elem>::acc_t (&acc)[Cfg::TPW]) {
+  if constexpr (V < Cfg::NV) {
+    if (v == V) schur_store<Cfg, V>(slab, lane, acc);
+    else schur_store_v<Cfg, V + 1>(v, slab, lane, acc);
   }
+}
+
+// One observation -> its 11x3 block of Ytilde = Jc^T Jp L^-T in the panel (+ z of its point).  f = k_point_factor's row
+// of the point: L^-1 (6), z (3), ok flag.
+template <typename T, bool DIAG>
+__device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict__ panelB, T* __restrict__ s_z,
+                                           const T* __restrict__ s_cam, int camA0, int nA, int camB0, int nB, int dense,
+                                           int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f) {
+  const bool inA = (c >= camA0 && c < camA0 + nA);
+  const bool inB = !DIAG && (c >= camB0 && c < camB0 + nB);
+  if (!inA && !inB) return;
+  T* pan = inA ? panelA : panelB;
+  const int col0 = (inA ? (c - camA0) : (c - camB0)) * NCP;
+  if (f[9] == (T)0) {              // degenerate point
+    if (dense) {
+#pragma unroll
+      for (int e = 0; e < NCP; ++e)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pan[(3 * q + d) * GROUP_ROWS + col0 + e] = (T)0;
+    }
+    return;
+  }
+  const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
+  T r[2], Jc[2][NCP], Jp[2][3];
+  obs_resjac<T>(cp, X0, X1, X2, ux, uy, ww, r, Jc, Jp);
+  // Jp~ = Jp * L^-T  (2x3):  (L^-T)[k][d] = Linv[d][k]
+  T Jt[2][3];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    Jt[rr][0] = Jp[rr][0] * f[0];
+    Jt[rr][1] = Jp[rr][0] * f[1] + Jp[rr][1] * f[2];
+    Jt[rr][2] = Jp[rr][0] * f[3] + Jp[rr][1] * f[4] + Jp[rr][2] * f[5];
+  }
+#pragma unroll
+  for (int e = 0; e < NCP; ++e) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      pan[(3 * q + d) * GROUP_ROWS + col0 + e] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
+  }
+  if (DIAG) { s_z[3 * q + 0] = f[6]; s_z[3 * q + 1] = f[7]; s_z[3 * q + 2] = f[8]; }   // same 3 values from every observation of the point
 }
 
 // ------------------------------------------------------------------ K4: the kernel.  grid = (ksplit, pairs of this kind, TS)
@@ -663,40 +734,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
             const int rowi = (i % (K * GROUP_ROWS)) / GROUP_ROWS;
             if (rowi >= 3 * (p1 - p0)) buf[i] = (T)0;
           }
-        // one observation -> its 11x3 block of Ytilde in the panel (+ z of its point)
         auto emit = [&](int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f) {
-          const bool inA = (c >= camA0 && c < camA0 + nA);
-          const bool inB = !DIAG && (c >= camB0 && c < camB0 + nB);
-          if (!inA && !inB) return;
-          T* pan = inA ? panelA : panelB;
-          const int col0 = (inA ? (c - camA0) : (c - camB0)) * NCP;
-          if (f[9] == (T)0) {              // degenerate point
-            if (dense) {
-#pragma unroll
-              for (int e = 0; e < NCP; ++e)
-#pragma unroll
-                for (int d = 0; d < 3; ++d) pan[(3 * q + d) * GROUP_ROWS + col0 + e] = (T)0;
-            }
-            return;
-          }
-          const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
-          T r[2], Jc[2][NCP], Jp[2][3];
-          obs_resjac<T>(cp, X0, X1, X2, ux, uy, ww, r, Jc, Jp);
-          // Jp~ = Jp * L^-T  (2x3):  (L^-T)[k][d] = Linv[d][k]
-          T Jt[2][3];
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr) {
-            Jt[rr][0] = Jp[rr][0] * f[0];
-            Jt[rr][1] = Jp[rr][0] * f[1] + Jp[rr][1] * f[2];
-            Jt[rr][2] = Jp[rr][0] * f[3] + Jp[rr][1] * f[4] + Jp[rr][2] * f[5];
-          }
-#pragma unroll
-          for (int e = 0; e < NCP; ++e) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-              pan[(3 * q + d) * GROUP_ROWS + col0 + e] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
-          }
-          if (DIAG) { s_z[3 * q + 0] = f[6]; s_z[3 * q + 1] = f[7]; s_z[3 * q + 2] = f[8]; }   // same 3 values from every observation of the point
+          schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, c, q, ux, uy, ww, X0, X1, X2, f);
         };
         if (piped) {
           // <= 16 points x 16 cameras = 256 observations = one per producer lane; operands of the NEXT chunk were
@@ -737,7 +776,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
         for (int k = 0; k < K; k += 2) { s0 += panelA[k * GROUP_ROWS + ct] * s_z[k]; s1 += panelA[(k + 1) * GROUP_ROWS + ct] * s_z[k + 1]; }
         bacc += (double)(s0 + s1);
       }
-      schur_consume_v<T, DIAG, K>(vw, panelA + lane_off, panelB + lane_off, acc);
+      schur_consume_v<Cfg, K>(vw, panelA + lane_off, panelB + lane_off, acc);
     }
     if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && it < 20) {
       if (threadIdx.x == 0) dbg[3 * it + 0] = clock64();
@@ -756,9 +795,150 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
   // write partial tiles
   if (!producer) {
     T* slab = slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
-    schur_store_v<T, DIAG>(vw, slab, lane, acc);
+    schur_store_v<Cfg>(vw, slab, lane, acc);
     if (do_rhs && ct < GROUP_ROWS)
       bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + ct] = bacc;
+  }
+}
+
+// ------------------------------------------------------------------ K4 (symmetric): grid = (ksplit, pairs of this kind, TS)
+template <typename T, bool DIAG>
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
+    const ParamSets<T> ps, const LMState* __restrict__ st, int C,
+    const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start, int N,
+    const T* __restrict__ pf, const int32_t* __restrict__ pair_ga, const int32_t* __restrict__ pair_gb,
+    int pair0, int ksplit, int dense, T* __restrict__ slabs, double* __restrict__ bpart,
+    long long* __restrict__ dbg /* optional cycle stamps of workgroup (0,0,0): [it][produce done, after barrier, consume done] */) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using Cfg = SchurSymCfg<T, DIAG>;
+  constexpr int THREADS = Cfg::THREADS, NCW = Cfg::NCW, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K;
+  if (st->status >= 0) return;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ campre = ps.campre[cur_];
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  const int pair = pair0 + blockIdx.y;
+  const int ga = pair_ga[pair], gb = pair_gb[pair];
+  const int camA0 = ga * GROUP_CAMS, camB0 = gb * GROUP_CAMS;
+  const int nA = min(GROUP_CAMS, C - camA0), nB = min(GROUP_CAMS, C - camB0);
+  T* panelA = reinterpret_cast<T*>(smem);                         // [K][176]
+  T* panelB = DIAG ? panelA : panelA + K * GROUP_ROWS;
+  T* s_z = panelA + Cfg::NPANEL * K * GROUP_ROWS;                 // [K]
+  T* s_cam = s_z + K;                                             // [32][CAMPRE] : group A then group B
+  for (int i = threadIdx.x; i < Cfg::BUF; i += THREADS) panelA[i] = (T)0;
+  for (int i = threadIdx.x; i < nA * CAMPRE; i += THREADS) s_cam[i] = campre[(size_t)camA0 * CAMPRE + i];
+  if (!DIAG)
+    for (int i = threadIdx.x; i < nB * CAMPRE; i += THREADS)
+      s_cam[GROUP_CAMS * CAMPRE + i] = campre[(size_t)camB0 * CAMPRE + i];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int vw = (int)blockIdx.z * NCW + wid;                     // virtual consumer wave of the pair
+  typename Mfma<T>::acc_t acc[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) acc[s] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+  // rhs of a diagonal pair: thread (half, rho) accumulates b[rho] over its half of the panel rows
+  const bool do_rhs = DIAG && blockIdx.z == 0 && threadIdx.x < 2 * GROUP_ROWS;
+  const int rhs_row = threadIdx.x % GROUP_ROWS, rhs_half = threadIdx.x / GROUP_ROWS;
+  double bacc = 0;
+  const int lane_off = (lane >> 4) * GROUP_ROWS + (lane & 15);
+
+  int per = (N + ksplit - 1) / ksplit;
+  per = ((per + PTS - 1) / PTS) * PTS;
+  const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
+  const int nchunk = (pend - pbeg + PTS - 1) / PTS;
+  // software pipeline of the producer phase: operands of the next chunk and indices of the one after are requested
+  // before the consume phase, so their latency is covered by the MFMAs
+  using T2 = typename Vec2<T>::type;
+  bool cur_valid = false, n1_valid = false;
+  int cur_c = 0, cur_p = 0, n1_c = 0, n1_p = 0;
+  T2 cur_uv, n1_uv; cur_uv.x = cur_uv.y = n1_uv.x = n1_uv.y = (T)0;
+  T cur_w = (T)1, n1_w = (T)1;
+  T cur_X[3] = {0, 0, 0};
+  T cur_f[PF];
+#pragma unroll
+  for (int k = 0; k < PF; ++k) cur_f[k] = (T)0;
+  auto load_idx = [&](int chunk, bool& valid, int& c, int& pp, T2& m, T& ww) {
+    valid = false;
+    if (chunk < nchunk) {
+      const int q0 = pbeg + chunk * PTS, q1 = min(pend, q0 + PTS);
+      const int o = pt_start[q0] + (int)threadIdx.x;
+      if (o < pt_start[q1]) { valid = true; c = ci[o]; pp = pi[o]; m = uv[o]; ww = w ? w[o] : (T)1; }
+    }
+  };
+  auto load_point = [&]() {
+    if (cur_valid) {
+      cur_X[0] = ptsT[3 * (size_t)cur_p]; cur_X[1] = ptsT[3 * (size_t)cur_p + 1]; cur_X[2] = ptsT[3 * (size_t)cur_p + 2];
+#pragma unroll
+      for (int k = 0; k < PF; ++k) cur_f[k] = pf[(size_t)cur_p * PF + k];
+    }
+  };
+  // a chunk holds at most PTS*C observations: one per lane only when all cameras are in this one group (32 x 16 = 512)
+  const bool piped = DIAG && (C <= GROUP_CAMS);
+  if (piped) {
+    load_idx(0, cur_valid, cur_c, cur_p, cur_uv, cur_w);
+    load_point();
+    load_idx(1, n1_valid, n1_c, n1_p, n1_uv, n1_w);
+  }
+  __syncthreads();
+  for (int it = 0; it < nchunk; ++it) {
+    // ---- produce
+    const int p0 = pbeg + it * PTS, p1 = min(pend, p0 + PTS);
+    if (dense && p1 - p0 < PTS)          // partial last chunk of a dense problem: clear the rows no observation will write
+      for (int i = (p1 - p0) * 3 * GROUP_ROWS + threadIdx.x; i < Cfg::NPANEL * K * GROUP_ROWS; i += THREADS) {
+        const int rowi = (i % (K * GROUP_ROWS)) / GROUP_ROWS;
+        if (rowi >= 3 * (p1 - p0)) panelA[i] = (T)0;
+      }
+    if (piped) {
+      if (cur_valid)
+        schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, cur_c, cur_p - p0, cur_uv.x, cur_uv.y, cur_w,
+                            cur_X[0], cur_X[1], cur_X[2], cur_f);
+      cur_valid = n1_valid; cur_c = n1_c; cur_p = n1_p; cur_uv = n1_uv; cur_w = n1_w;
+      load_point();
+      load_idx(it + 2, n1_valid, n1_c, n1_p, n1_uv, n1_w);
+    } else {
+      const int o_lo = pt_start[p0], o_hi = pt_start[p1];
+      for (int o = o_lo + threadIdx.x; o < o_hi; o += THREADS) {
+        const int c = ci[o];
+        const int pp = pi[o];
+        T f[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) f[k] = pf[(size_t)pp * PF + k];
+        const auto m = uv[o];
+        schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, c, pp - p0, m.x, m.y, w ? w[o] : (T)1,
+                            ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f);
+      }
+    }
+    const bool stamp = dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && it < 20 && threadIdx.x == 0;
+    if (stamp) dbg[3 * it + 0] = clock64();
+    __syncthreads();
+    if (stamp) dbg[3 * it + 1] = clock64();
+    // ---- consume
+    if (do_rhs) {
+      T s0 = 0, s1 = 0;
+      const int k0 = rhs_half * (K / 2);
+#pragma unroll 8
+      for (int k = k0; k < k0 + K / 2; k += 2) {
+        s0 += panelA[k * GROUP_ROWS + rhs_row] * s_z[k];
+        s1 += panelA[(k + 1) * GROUP_ROWS + rhs_row] * s_z[k + 1];
+      }
+      bacc += (double)(s0 + s1);
+    }
+    schur_consume_v<Cfg, K>(vw, panelA + lane_off, panelB + lane_off, acc);
+    __syncthreads();
+    if (stamp) dbg[3 * it + 2] = clock64();
+    if (!dense) {
+      // sparse visibility: not every panel entry is rewritten by the next chunk
+      for (int i = threadIdx.x; i < Cfg::NPANEL * K * GROUP_ROWS; i += THREADS) panelA[i] = (T)0;
+      __syncthreads();
+    }
+  }
+  T* slab = slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
+  schur_store_v<Cfg>(vw, slab, lane, acc);
+  if (DIAG && blockIdx.z == 0) {
+    double* s_rhs = reinterpret_cast<double*>(smem);              // the panel is free now
+    if (do_rhs && rhs_half == 1) s_rhs[rhs_row] = bacc;
+    __syncthreads();
+    if (do_rhs && rhs_half == 0)
+      bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + rhs_row] = bacc + s_rhs[rhs_row];
   }
 }
 
