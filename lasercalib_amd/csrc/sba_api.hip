@@ -701,7 +701,7 @@ struct Engine : EngineBase {
       }
       if (n_sys <= CHOL_LDS_MAX_N && !chol_old) {
         const int nb = (n_sys + CB - 1) / CB;
-        const size_t lds = ((size_t)(nb * (nb + 1) / 2 + 2) * CBS + 3 * (size_t)nb * CB) * sizeof(double);
+        const size_t lds = ((size_t)(nb * (nb + 1) / 2) * CBS + 2 * (size_t)nb * CB) * sizeof(double);
         if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }
         hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
                            ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr,

@@ -5,12 +5,16 @@
 //
 // Block size 16 (= one f64 MFMA 16x16x4 tile); the lower triangle is kept as 16x16 blocks with a 17-double
 // row stride (conflict-free ds_read_b64 for the MFMA operand pattern lane -> [row lane&15][col lane>>4]).
-// Per block column jb:
-//   B'  every thread owns one row below the diagonal block and forward-substitutes it against L11
-//       (L21 = A21 L11^-T); one more thread does the same with the rhs row, which is the forward solve.
-//   C   wave 0 updates the next diagonal tile and factors it at once (look-ahead), wave 1 downdates the rhs
-//       tail, waves 1..7 apply the rank-16 trailing update tile by tile with 4 MFMAs per tile.
-// After the last column one wave runs the blocked back substitution (16-step shuffle solves per block).
+// Per block column jb (two barriers):
+//   B   the diagonal block already holds Linv^T (below); every wave forms its row blocks of L21 = A21 Linv^T with
+//       4 f64 MFMAs per 16x16 block, one wave forward-solves the rhs block (y = Linv rhs), and wave 0 -- which owns the
+//       block right below the diagonal -- downdates the next diagonal tile with it.
+//   C   wave 0 factors the next diagonal tile (look-ahead) while wave 1 downdates the rhs tail and waves 1..7 apply the
+//       rank-16 trailing update tile by tile (4 MFMAs per tile).
+//   The diagonal factorisation (chol16_wave) is the serial chain of the kernel: lanes 0..15 own the rows of the tile,
+//   lanes 16..31 run the rows of the identity through the same column operations and so end up with Linv^T, which is
+//   all that is stored (L11 itself is never needed again: B' and the back substitution both multiply by Linv).
+// After the last column the blocked back substitution runs right-looking over all waves.
 #pragma once
 #include "sba_lm_kernels.hpp"
 
@@ -30,24 +34,26 @@ __device__ inline double readlane_f64(double v, int src) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
-// 1/sqrt(x): hardware estimate + two Newton steps (the pivot only has to be consistent, not correctly rounded)
+// 1/sqrt(x): hardware estimate (5e-8) + one Newton step -> 4e-15 relative (tools/micro/rsq_acc.hip).  The pivot only
+// has to be used consistently (L_kk = a_kk * piv and the column scaled by the same piv), which perturbs the factored
+// diagonal by ~8e-15 relative -- below the rounding error the 176 column operations accumulate anyway.
 __device__ inline double rsqrt_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(x);
+  return y * (1.5 - 0.5 * x * y * y);
 }
 
-// Cholesky of one 16x16 diagonal block by the calling wave: lane i (< 16) owns row i; broadcasts go through
-// v_readlane (SGPRs), so a step costs ~150 cycles instead of two LDS round trips.  Writes L (lower, upper zeroed)
-// back into the block, L^T into `blkT` and 1/L[k][k] into inv[0..15].  Returns false (wave-uniform) when the block
-// is not positive definite.
-__device__ __forceinline__ bool chol16_wave(double* __restrict__ blk, double* __restrict__ blkT, double* __restrict__ inv) {
+// Cholesky of one 16x16 diagonal block by the calling wave.  Lane i < 16 owns row i of the tile, lane 16+j the row e_j
+// of the identity; both kinds go through the same right-looking column steps (x_k = a_k / L_kk ; a_c -= x_k L[c][k]),
+// whose broadcasts of column k go through v_readlane (SGPRs) instead of LDS round trips.  The identity rows end up as
+// the rows of Linv^T, which replace the tile.  Returns false (wave-uniform) when the block is not positive definite.
+__device__ __forceinline__ bool chol16_wave(double* __restrict__ blk) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15;
+  const bool ident = lane >= 16;
   double a[CB];
 #pragma unroll
-  for (int j = 0; j < CB; ++j) a[j] = blk[i * CLD + j];
+  for (int j = 0; j < CB; ++j) { const double v = blk[i * CLD + j]; a[j] = ident ? ((j == i) ? 1.0 : 0.0) : v; }
+  __builtin_amdgcn_wave_barrier();
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < CB; ++k) {
@@ -56,19 +62,43 @@ __device__ __forceinline__ bool chol16_wave(double* __restrict__ blk, double* __
     const double piv = rsqrt_nr(ok ? akk : 1.0);
     const double lik = a[k] * piv;
     a[k] = lik;
-    if (lane == k) inv[k] = piv;
 #pragma unroll
     for (int j = k + 1; j < CB; ++j) a[j] -= lik * readlane_f64(lik, j);
   }
-  if (lane < CB) {
+  if (lane >= 16 && lane < 32) {
 #pragma unroll
-    for (int j = 0; j < CB; ++j) {
-      const double v = (j <= i) ? a[j] : 0.0;
-      blk[i * CLD + j] = v;
-      blkT[j * CLD + i] = v;
-    }
+    for (int j = 0; j < CB; ++j) blk[i * CLD + j] = a[j];     // row i of Linv^T (zero left of the diagonal)
   }
   return ok;
+}
+
+// one 16x16 block of L21 = A21 * Linv^T, in place, by the calling wave (4 chained f64 MFMAs)
+__device__ __forceinline__ void chol_panel_block(double* __restrict__ Ablk, const double* __restrict__ LinvT) {
+  const int lane = threadIdx.x & 63;
+  const double* Pa = Ablk + (lane & 15) * CLD + (lane >> 4);          // A[row lane&15][k = 4ks + lane>>4]
+  const double* Pl = LinvT + (lane >> 4) * CLD + (lane & 15);         // LinvT[k = 4ks + lane>>4][col lane&15]
+  Mfma<double>::acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) acc = Mfma<double>::mma(Pa[4 * ks], Pl[4 * ks * CLD], acc);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Ablk[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg];
+  __builtin_amdgcn_wave_barrier();
+}
+
+// D -= P P^T (or Pa Pb^T) for one 16x16 tile by the calling wave
+__device__ __forceinline__ void chol_update_tile(double* __restrict__ Dt, const double* __restrict__ Pa_blk, const double* __restrict__ Pb_blk) {
+  const int lane = threadIdx.x & 63;
+  const double* Pa = Pa_blk + (lane & 15) * CLD + (lane >> 4);
+  const double* Pb = Pb_blk + (lane & 15) * CLD + (lane >> 4);
+  Mfma<double>::acc_t acc;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) acc[rg] = Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) acc = Mfma<double>::mma(-Pa[4 * ks], Pb[4 * ks], acc);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg];
+  __builtin_amdgcn_wave_barrier();
 }
 
 template <typename T>
@@ -94,10 +124,8 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   const int n16 = nb * CB;
   const int nblk = nb * (nb + 1) / 2;
   double* Lb = reinterpret_cast<double*>(smem);                   // nblk blocks
-  double* s_LT = Lb + nblk * CBS;                                 // [2][CBS] transposed diagonal block (ping-pong)
-  double* s_y = s_LT + 2 * CBS;                                   // [n16]  rhs -> y -> x
-  double* s_inv = s_y + n16;                                      // [n16]  1 / L[k][k]
-  double* s_d = s_inv + n16;                                      // [n16]  lam * D2c (diagonal damping)
+  double* s_y = Lb + nblk * CBS;                                  // [n16]  rhs -> y -> x
+  double* s_d = s_y + n16;                                        // [n16]  lam * D2c (diagonal damping)
   __shared__ int s_fail;
   __shared__ short s_rc[CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2];   // block index -> (r << 8 | c)
   __shared__ double s_scr[4][CHOLB_THREADS / 64];
@@ -161,59 +189,43 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   __syncthreads();
   CHOL_STAMP();
   if (wid == 0) {
-    if (!chol16_wave(Lb + cb_off(0, 0), s_LT, s_inv)) { if (lane == 0) s_fail = 1; }
+    if (!chol16_wave(Lb + cb_off(0, 0))) { if (lane == 0) s_fail = 1; }
   }
   __syncthreads();
   CHOL_STAMP();
 
+  constexpr int NW = CHOLB_THREADS / 64;
   for (int jb = 0; jb < nb && !s_fail; ++jb) {
     const int m = (nb - jb - 1) * CB;              // rows below the diagonal block
-    const double* LT = s_LT + (jb & 1) * CBS;      // LT[k][j] = L11[j][k]: row k = column k of L11, contiguous
-    const double* inv = s_inv + jb * CB;
-    // ---- B': L21 = A21 L11^-T row by row, right-looking: x_k = a_k / L_kk ; a_j -= x_k L11[j][k] (j > k).
-    //      One more thread does the same with the rhs block, which is the forward solve.
-    if (tid <= m + CB) {
-      double a[CB];
-      // tid < m: panel row ; tid == m: rhs block ; tid in (m, m+16]: row e_j of the identity, whose solution
-      // e_j L11^-T is row j of Linv^T -- stored over the diagonal block itself (B' reads L11 only through its
-      // transposed copy, and nothing but the back substitution needs the diagonal block afterwards)
-      const int jrow = tid - m - 1;
-      double* row = (tid < m) ? Lb + cb_off(jb + 1 + (tid >> 4), jb) + (tid & 15) * CLD
-                  : (tid == m) ? s_y + jb * CB : Lb + cb_off(jb, jb) + jrow * CLD;
-      if (tid <= m) {
-#pragma unroll
-        for (int k = 0; k < CB; ++k) a[k] = row[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < CB; ++k) a[k] = (k == jrow) ? 1.0 : 0.0;
+    const double* LinvT = Lb + cb_off(jb, jb);
+    // ---- B: L21 = A21 Linv^T block by block; wave 0 takes the block right below the diagonal and downdates the next
+    //      diagonal tile with it, the last wave forward-solves the rhs block
+    if (wid == 0) {
+      if (jb + 1 < nb) {
+        double* P = Lb + cb_off(jb + 1, jb);
+        chol_panel_block(P, LinvT);
+        chol_update_tile(Lb + cb_off(jb + 1, jb + 1), P, P);
       }
+    } else {
+      for (int r = jb + 2 + (wid - 1); r < nb; r += NW - 1) chol_panel_block(Lb + cb_off(r, jb), LinvT);
+      if (wid == NW - 1) {
+        // y_blk = Linv rhs_blk :  y[i] = sum_k LinvT[k][i] rhs[k]   (lane = (part, i): 4 terms each, then 2 shuffles)
+        const int i = lane & 15, part = lane >> 4;
+        double x = 0;
 #pragma unroll
-      for (int k = 0; k < CB; ++k) {
-        const double xk = a[k] * inv[k];
-        a[k] = xk;
-#pragma unroll
-        for (int j = k + 1; j < CB; ++j) a[j] -= xk * LT[k * CLD + j];     // wave-uniform address: LDS broadcast
-        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);                 // bound how far loads are hoisted
+        for (int kk = 0; kk < 4; ++kk) { const int k = part + 4 * kk; x += LinvT[k * CLD + i] * s_y[jb * CB + k]; }
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (part == 0) s_y[jb * CB + i] = x;
       }
-#pragma unroll
-      for (int k = 0; k < CB; ++k) row[k] = a[k];
     }
     __syncthreads();
     CHOL_STAMP();
-    // ---- C: trailing update with look-ahead
+    // ---- C: look-ahead factorisation of the next diagonal tile (wave 0) | rhs tail + trailing update (waves 1..7)
     if (wid == 0) {
       if (jb + 1 < nb) {
-        double* D = Lb + cb_off(jb + 1, jb + 1);
-        const double* P = Lb + cb_off(jb + 1, jb) + (lane & 15) * CLD + (lane >> 4);
-        Mfma<double>::acc_t acc;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) acc[rg] = D[((lane >> 4) + 4 * rg) * CLD + (lane & 15)];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = Mfma<double>::mma(-P[4 * ks], P[4 * ks], acc);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) D[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg];
-        __builtin_amdgcn_wave_barrier();
-        if (!chol16_wave(D, s_LT + ((jb + 1) & 1) * CBS, s_inv + (jb + 1) * CB)) { if (lane == 0) s_fail = 1; }
+        if (!chol16_wave(Lb + cb_off(jb + 1, jb + 1))) { if (lane == 0) s_fail = 1; }
       }
     } else {
       if (wid == 1) {
@@ -229,19 +241,10 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
       // tiles (r,c), jb < c <= r < nb, except (jb+1,jb+1): enumerate the trailing block triangle from index 1
       const int q = nb - jb - 1;
       const int ntile = q * (q + 1) / 2;
-      for (int t = 1 + (wid - 1); t < ntile; t += (CHOLB_THREADS / 64 - 1)) {
+      for (int t = 1 + (wid - 1); t < ntile; t += (NW - 1)) {
         const int rc = s_rc[t];
         const int r = jb + 1 + (rc >> 8), c = jb + 1 + (rc & 255);
-        double* Dt = Lb + cb_off(r, c);
-        const double* Pa = Lb + cb_off(r, jb) + (lane & 15) * CLD + (lane >> 4);
-        const double* Pb = Lb + cb_off(c, jb) + (lane & 15) * CLD + (lane >> 4);
-        Mfma<double>::acc_t acc;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) acc[rg] = Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = Mfma<double>::mma(-Pa[4 * ks], Pb[4 * ks], acc);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg];
+        chol_update_tile(Lb + cb_off(r, c), Lb + cb_off(r, jb), Lb + cb_off(c, jb));
       }
     }
     __syncthreads();
