@@ -128,6 +128,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   double* s_d = s_y + n16;                                        // [n16]  lam * D2c (diagonal damping)
   __shared__ int s_fail;
   __shared__ short s_rc[CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2];   // block index -> (r << 8 | c)
+  __shared__ short s_cm[CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2];   // column-major list of the blocks with c >= 1
   __shared__ double s_scr[4][CHOLB_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double* rhs = E + (size_t)n * n;
@@ -140,54 +141,114 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   const double my_xs = (tid < n) ? cams[first ? first[tid] : tid] : 0.0;      // system unknown tid (a shared one counts once)
   const double my_g = (tid < n) ? gct[tid] : 0.0;
 
-  // camera scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
-  for (int i = tid; i < n16; i += CHOLB_THREADS) {
-    double v = 0, dd = 0;
-    if (i < n) {
-      double d = D2c[i];
-      if (fresh) { d = fmax(d, dU[i]); D2c[i] = d; }
-      dd = lam * fmax_pos(d);
-      v = rhs[i];
-    }
-    s_y[i] = v;
-    s_d[i] = dd;
-  }
   if (tid < nblk) {
     int r = 0;
     while ((r + 1) * (r + 2) / 2 <= tid) ++r;
     s_rc[tid] = (short)((r << 8) | (tid - r * (r + 1) / 2));
   }
+  if (tid < nblk - nb) {                           // blocks right of the first block column, column by column
+    int c = 1, q = tid;
+    while (q >= nb - c) { q -= nb - c; ++c; }
+    s_cm[tid] = (short)(((c + q) << 8) | c);
+  }
   if (tid == 0) { s_fail = 0; st->cost = E[(size_t)n * n + 3 * n]; }
   __syncthreads();
-  // load the lower block triangle (+ damping): every thread issues all of its (<= 33) loads before using any of
-  // them, so the fabric latency of reading E (written by other CUs) is paid once; the padded tail is the identity
-  {
-    constexpr int MAXU = (CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2 + 1) / 2;     // 33
-    const int e = tid & 255, ii = e >> 4, jj = e & 15, half = tid >> 8;
-    double v[MAXU];
+  // ---- load the lower block triangle.  E was written by other CUs, so every access is a fabric round trip and one CU
+  // sustains few of them: two doubles per lane per load (16 B, E rows are 16-byte aligned when n is even), all loads
+  // of a thread issued before any is used, the first block column first -- its 11 blocks are all the first
+  // factorisation step needs, so wave 0 starts on it while waves 1..7 are still receiving the other 55 blocks.
+  // The padded tail is the identity.
+  // All loads are unconditional (out-of-range ones are clamped to a valid address and replaced afterwards) and sit in
+  // straight-line code: only then can the compiler wait with vmcnt(N) for the first block column alone.
+  const bool pair_ok = (n & 1) == 0;
+  constexpr int U0 = (CHOLB_MAX_NB + 3) / 4;                                   // 3 rounds of 4 blocks: first block column
+  constexpr int NREM = CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2;                  // 55 other blocks
+  constexpr int TREM = CHOLB_THREADS - 64;                                     // loaded by waves 1..7
+  constexpr int U1 = (NREM * 128 + TREM - 1) / TREM;                           // 16 rounds
+  double c0[U0][2], c1[U1][2];
+  const int nlast = n - 1;
+  auto addr = [&](int I, int J) { return E + (size_t)min(I, nlast) * n + min(J, nlast - 1 + (pair_ok ? 0 : 1)); };
+  auto fix = [&](int I, int J, double& v0, double& v1) {       // padded tail = identity
+    if (I >= n || J >= n) v0 = (I == J) ? 1.0 : 0.0;
+    if (I >= n || J + 1 >= n) v1 = (I == J + 1) ? 1.0 : 0.0;
+  };
+  const int s4 = tid >> 7, ii0 = (tid >> 3) & 15, jp0 = tid & 7;
+  double in_d = 0, in_u = 0, in_r = 0;
+  const int tclamp = min(tid, nlast);
+  if (pair_ok) {
 #pragma unroll
-    for (int u = 0; u < MAXU; ++u) {
-      const int b = 2 * u + half;
-      v[u] = 0;
-      if (b < nblk) {
-        const int rc = s_rc[b];
-        const int I = (rc >> 8) * CB + ii, J = (rc & 255) * CB + jj;
-        if (I < n && J < n) v[u] = E[(size_t)I * n + J];
-        else v[u] = (I == J) ? 1.0 : 0.0;
-      }
+    for (int u = 0; u < U0; ++u) {
+      const double2 t = *reinterpret_cast<const double2*>(addr((4 * u + s4) * CB + ii0, 2 * jp0));
+      c0[u][0] = t.x; c0[u][1] = t.y;
     }
+    in_d = D2c[tclamp]; in_u = dU[tclamp]; in_r = rhs[tclamp];
 #pragma unroll
-    for (int u = 0; u < MAXU; ++u) {
-      const int b = 2 * u + half;
-      if (b < nblk) {
-        const int rc = s_rc[b];
-        const int I = (rc >> 8) * CB + ii, J = (rc & 255) * CB + jj;
-        Lb[b * CBS + ii * CLD + jj] = v[u] + ((I == J && I < n) ? s_d[I] : 0.0);
+    for (int u = 0; u < U1; ++u) {
+      const int e = min(max(tid - 64, 0) + TREM * u, (nblk - nb) * 128 - 1);
+      const int rc = s_cm[e >> 7];
+      const double2 t = *reinterpret_cast<const double2*>(addr((rc >> 8) * CB + ((e >> 3) & 15), (rc & 255) * CB + 2 * (e & 7)));
+      c1[u][0] = t.x; c1[u][1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U0; ++u) {
+      const double* q = addr((4 * u + s4) * CB + ii0, 2 * jp0);
+      c0[u][0] = q[0]; c0[u][1] = q[(2 * jp0 + 1 < n) ? 1 : 0];
+    }
+    in_d = D2c[tclamp]; in_u = dU[tclamp]; in_r = rhs[tclamp];
+#pragma unroll
+    for (int u = 0; u < U1; ++u) {
+      const int e = min(max(tid - 64, 0) + TREM * u, (nblk - nb) * 128 - 1);
+      const int rc = s_cm[e >> 7];
+      const int J = (rc & 255) * CB + 2 * (e & 7);
+      const double* q = addr((rc >> 8) * CB + ((e >> 3) & 15), J);
+      c1[u][0] = q[0]; c1[u][1] = q[(J + 1 < n) ? 1 : 0];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U0; ++u) fix((4 * u + s4) * CB + ii0, 2 * jp0, c0[u][0], c0[u][1]);
+  // camera scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
+  if (tid < n16) {                                 // n16 <= 176 < CHOLB_THREADS
+    double dd = 0;
+    if (tid >= n) in_r = 0;
+    if (tid < n) {
+      double d = in_d;
+      if (fresh) { d = fmax(d, in_u); D2c[tid] = d; }
+      dd = lam * fmax_pos(d);
+    }
+    s_y[tid] = in_r;
+    s_d[tid] = dd;
+  }
+  __syncthreads();
+  {
+    const int ii = ii0, jp = jp0;
+#pragma unroll
+    for (int u = 0; u < U0; ++u) {
+      const int r = 4 * u + s4;
+      if (r < nb) {
+        const int I = r * CB + ii, J = 2 * jp;
+        double* dst = Lb + cb_off(r, 0) + ii * CLD + J;
+        dst[0] = c0[u][0] + ((I == J && I < n) ? s_d[I] : 0.0);
+        dst[1] = c0[u][1] + ((I == J + 1 && I < n) ? s_d[I] : 0.0);
       }
     }
   }
   __syncthreads();
   CHOL_STAMP();
+  if (wid > 0) {
+#pragma unroll
+    for (int u = 0; u < U1; ++u) {
+      const int e = (tid - 64) + TREM * u;
+      if (e < (nblk - nb) * 128) {
+        const int rc = s_cm[e >> 7];
+        const int ii = (e >> 3) & 15, I = (rc >> 8) * CB + ii, J = (rc & 255) * CB + 2 * (e & 7);
+        double* dst = Lb + cb_off(rc >> 8, rc & 255) + ii * CLD + 2 * (e & 7);
+        fix(I, J, c1[u][0], c1[u][1]);
+        dst[0] = c1[u][0] + ((I == J && I < n) ? s_d[I] : 0.0);
+        dst[1] = c1[u][1] + ((I == J + 1 && I < n) ? s_d[I] : 0.0);
+      }
+    }
+  }
   if (wid == 0) {
     if (!chol16_wave(Lb + cb_off(0, 0))) { if (lane == 0) s_fail = 1; }
   }
