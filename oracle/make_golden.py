@@ -165,9 +165,47 @@ def f5_variants():
     np.savez_compressed(os.path.join(OUT, "f5_variants.npz"), **out, **VERS)
 
 
+def f6_convert():
+    """Conversion functions of the reference (lasercalib/convert_params.py:7-27) on the shipped example calibration.
+
+    convert_params imports cv2 at module level (absent here) although the two pure functions recorded below never touch
+    it, and spells NaN as ``np.NaN`` (gone in numpy 2): an empty ``cv2`` module object and the alias are put in place
+    for the import only -- none of the reference's cv2-using functions is called.  The example YAML numbers are stored as
+    plain arrays (data shipped by the reference under example/calib_init_2024_05_02).
+    """
+    import glob
+    import types
+    from lasercalib_amd.convert_params import read_opencv_yaml
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    if not hasattr(np, "NaN"):
+        np.NaN = np.nan
+    from lasercalib import convert_params as ref_cp
+    files = sorted(glob.glob("/root/reference/example/calib_init_2024_05_02/*.yaml"))
+    names = [os.path.splitext(os.path.basename(f))[0] for f in files]
+    K = np.stack([read_opencv_yaml(f)["camera_matrix"] for f in files])
+    D = np.stack([read_opencv_yaml(f)["distortion_coefficients"] for f in files])
+    Rm = np.stack([read_opencv_yaml(f)["rc_ext"] for f in files])
+    T = np.stack([read_opencv_yaml(f)["tc_ext"] for f in files])
+    from oracle import io_oracle
+    cams = np.stack([io_oracle.camera_row_from_calibration(K[i], D[i], Rm[i], T[i]) for i in range(len(files))])
+    rng = np.random.default_rng(6)
+    extra = make_rig(5, 10, seed=6)["cams0"] + rng.normal(0, 1e-3, (5, 11))
+    extra[0, :3] = 0.0                       # zero rotation
+    extra[1, :3] = [np.pi, 0.0, 0.0]         # half turn
+    allc = np.vstack([cams, extra])
+    camList = [ref_cp.sba_to_readable_format(allc[i, :]) for i in range(allc.shape[0])]
+    red = ref_cp.readable_to_red_format(camList)
+    np.savez_compressed(os.path.join(OUT, "f6_convert.npz"), names=np.array(names), K=K, dist=D, R=Rm, T=T,
+                        example_cameraArray=cams, cameraArray=allc,
+                        readable_K=np.stack([c["K"] for c in camList]), readable_R=np.stack([c["R"] for c in camList]),
+                        readable_t=np.stack([c["t"] for c in camList]), readable_d=np.stack([c["d"] for c in camList]),
+                        red=red, **VERS)
+    print("f6_convert: %d example cameras + %d synthetic" % (len(files), extra.shape[0]), flush=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    stages = dict(f1=f1_project, f2=f2_fun, f3=f3_jacobian, f4=f4_f6_solves, f5=f5_variants)
+    stages = dict(f1=f1_project, f2=f2_fun, f3=f3_jacobian, f4=f4_f6_solves, f5=f5_variants, f6=f6_convert)
     for name in (sys.argv[1:] or list(stages)):
         stages[name]()
     for f in sorted(os.listdir(OUT)):

@@ -1,0 +1,164 @@
+"""CPU tests for the rows either side of the hot path: observation-list builder,
+dataset concatenation, parameter conversion and YAML I/O -- product (lasercalib_amd) vs oracle restatement and vs the
+golden vectors recorded from the reference's own conversion functions (tests/golden/f6_convert.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from lasercalib_amd import convert_params as cp
+from lasercalib_amd import dataset as ds
+from oracle import io_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _centroids(rng, n_pts, n_cams, p_seen):
+    c = rng.uniform(0, 3000, size=(n_pts, 2, n_cams))
+    hide = rng.random((n_pts, n_cams)) > p_seen
+    c[np.broadcast_to(hide[:, None, :], c.shape)] = np.nan
+    return c
+
+
+@pytest.mark.parametrize("n_pts,n_cams,p", [(0, 4, 0.5), (1, 1, 1.0), (50, 3, 0.0), (200, 17, 0.6), (333, 5, 1.0)])
+def test_observation_list_matches_reference_loops(n_pts, n_cams, p):
+    rng = np.random.default_rng(n_pts + n_cams)
+    c = _centroids(rng, n_pts, n_cams, p)
+    ci, pi, uv = ds.observation_list(c)
+    ci0, pi0, uv0 = orc.observation_list_loop(c)
+    assert ci.dtype == np.int64 and pi.dtype == np.int64 and uv.dtype == np.float64
+    np.testing.assert_array_equal(ci, ci0)
+    np.testing.assert_array_equal(pi, pi0)
+    np.testing.assert_array_equal(uv, uv0)            # bit-exact: values are copied, not computed
+    assert ds.is_point_major(pi)
+
+
+def test_observation_list_rejects_bad_shape():
+    with pytest.raises(ValueError):
+        ds.observation_list(np.zeros((4, 3, 2)))
+
+
+@pytest.mark.parametrize("min_cams", [1, 4, 17])
+def test_filter_points_matches_reference_loop(min_cams):
+    rng = np.random.default_rng(3)
+    c = _centroids(rng, 400, 17, 0.4)
+    for cam3d in (0, 16):
+        np.testing.assert_array_equal(ds.filter_points(c, min_cams, cam3d), orc.filter_points_loop(c, min_cams, cam3d))
+
+
+def _datasets(k):
+    rng = np.random.default_rng(10 + k)
+    out = []
+    for d in range(k):
+        n = 20 + 7 * d
+        c = _centroids(rng, n, 4, 0.7)
+        c[:, :, 0] = rng.uniform(0, 100, (n, 2))          # camera 0 sees everything
+        out.append(ds.make_dataset(c, rng.normal(size=(n, 3))))
+    return out
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_concatenate_keeps_the_reference_offset_quirk(k):
+    sets = _datasets(k)
+    got = ds.concatenate_datasets(sets)
+    ref = orc.concatenate_loop(sets)
+    assert got[0] == ref[0]
+    for a, b in zip(got[1:], ref[1:]):
+        np.testing.assert_array_equal(a, b)
+    cum = ds.concatenate_datasets(sets, cumulative_offsets=True)
+    if k <= 2:
+        np.testing.assert_array_equal(cum[4], got[4])    # the quirk only bites from the third dataset on
+    else:
+        assert cum[4].max() == sum(s["n_pts"] for s in sets) - 1
+        assert got[4].max() < cum[4].max()
+        assert not ds.is_point_major(got[4]) and ds.is_point_major(cum[4])
+
+
+def test_dataset_dict_layout():
+    d = _datasets(1)[0]
+    assert sorted(d) == ["camera_ind", "n_cams", "n_pts", "point_ind", "points_2d", "points_3d"]
+    assert d["points_2d"].shape == (d["camera_ind"].size, 2)
+
+
+# ----------------------------------------------------------------------------- conversion (pinned by the reference)
+
+@pytest.fixture(scope="module")
+def f6():
+    return np.load(os.path.join(GOLD, "f6_convert.npz"))
+
+
+def test_sba_to_readable_and_red_match_reference_golden(f6):
+    cams = f6["cameraArray"]
+    camList = cp.camera_array_to_readable(cams)
+    for i, c in enumerate(camList):
+        np.testing.assert_array_equal(c["K"], f6["readable_K"][i])
+        np.testing.assert_array_equal(c["R"], f6["readable_R"][i])
+        np.testing.assert_array_equal(c["t"], f6["readable_t"][i])
+        np.testing.assert_array_equal(c["d"], f6["readable_d"][i])
+        o = orc.readable_from_row(cams[i])
+        np.testing.assert_array_equal(o["K"], c["K"])
+        np.testing.assert_array_equal(o["R"], c["R"])
+    red = cp.readable_to_red_format(camList)
+    assert red.shape == (cams.shape[0], 25) and not np.isnan(red).any()
+    np.testing.assert_array_equal(red, f6["red"])
+    np.testing.assert_array_equal(red[0], orc.red_row(camList[0]))
+    assert np.shares_memory(camList[0]["t"], cams)          # t and d are views into the row, like upstream
+
+
+def test_initialize_from_checkerboard_on_example_calibration(f6, tmp_path):
+    names = [str(n) for n in f6["names"]]
+    for i, n in enumerate(names):
+        cp.write_opencv_yaml(str(tmp_path / f"{n}.yaml"), {
+            "camera_matrix": f6["K"][i], "distortion_coefficients": f6["dist"][i], "rc_ext": f6["R"][i], "tc_ext": f6["T"][i]})
+    cams = cp.initialize_from_checkerboard(str(tmp_path), len(names), names)
+    np.testing.assert_array_equal(cams, f6["example_cameraArray"])     # %.16e round-trips f64 exactly
+    assert cams.shape == (17, 11)
+    assert abs(cams[0, 6] - f6["K"][0, 0, 0]) == 0
+
+
+def test_opencv_yaml_round_trip_and_layout(tmp_path):
+    rng = np.random.default_rng(0)
+    nodes = {"image_width": 3208, "camera_matrix": rng.normal(size=(3, 3)) * 1e3, "tc_ext": rng.normal(size=3),
+             "distortion_coefficients": np.array([1e-4, -2e-2, 0, 0, 0])}
+    p = str(tmp_path / "c.yaml")
+    cp.write_opencv_yaml(p, nodes)
+    text = open(p).read()
+    assert text.startswith("%YAML:1.0\n---\n") and "!!opencv-matrix" in text and "dt: d" in text
+    back = cp.read_opencv_yaml(p)
+    assert back["image_width"] == 3208
+    np.testing.assert_array_equal(back["camera_matrix"], nodes["camera_matrix"])
+    np.testing.assert_array_equal(back["tc_ext"], nodes["tc_ext"].reshape(3, 1))
+    assert back["distortion_coefficients"].shape == (5, 1)
+    with open(p, "a") as f:
+        f.write("bad: !!opencv-matrix\n   rows: 2\n   cols: 2\n   dt: d\n   data: [ 1., 2., 3. ]\n")
+    with pytest.raises(ValueError):
+        cp.read_opencv_yaml(p)
+
+
+def test_aruco_export_round_trips_through_initialize(f6, tmp_path):
+    cams = f6["example_cameraArray"]
+    names = [f"Cam{i}" for i in range(cams.shape[0])]
+    cp.readable_format_to_aruco_format(str(tmp_path) + "/", cams.shape[0], cp.camera_array_to_readable(cams), names)
+    back = cp.initialize_from_checkerboard(str(tmp_path), cams.shape[0], names)
+    np.testing.assert_allclose(back, cams, rtol=0, atol=1e-9)
+
+
+def test_shim_module_resolves_to_product(monkeypatch):
+    import lasercalib.convert_params as shim
+    assert shim.sba_to_readable_format is cp.sba_to_readable_format
+    monkeypatch.delenv("LASERCALIB_UPSTREAM", raising=False)
+    with pytest.raises(AttributeError):
+        shim.load_from_blender
+
+
+def test_report_helpers_cpu():
+    from lasercalib_amd import report
+
+    class Stub:
+        cameraArray = np.array([[0.1, -0.2, 0.3, 10.0, 20.0, 30.0, 1000.0, 0.0, 0.0, 500.0, 400.0]])
+    ex = report.camera_extrinsics(Stub())
+    from scipy.spatial.transform import Rotation as R
+    r_f = R.from_rotvec(-Stub.cameraArray[0, :3]).as_matrix()
+    np.testing.assert_allclose(ex[0, :3, :3], r_f)
+    np.testing.assert_allclose(ex[0, :3, 3], -r_f @ Stub.cameraArray[0, 3:6])
+    assert "cx" in report.camera_table(Stub()).splitlines()[0]
