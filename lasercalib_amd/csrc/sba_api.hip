@@ -105,6 +105,8 @@ struct Engine : EngineBase {
   bool has_w = false;
   bool identity_perm = true;
   bool dense = false;                // every point is observed by every camera exactly once
+  bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
+  DevBuf<T> Upart2;
   std::vector<int64_t> perm;          // pm position -> caller's observation index
   int nblk = 0, nchunk = 0, ngroups = 0, npairs = 0, ksplit = 1;
   int n = 0;                          // 11*C
@@ -187,6 +189,7 @@ struct Engine : EngineBase {
     // kernels whose dynamic LDS can exceed the 64 KB default
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -228,6 +231,7 @@ struct Engine : EngineBase {
     int maxdeg = 0;
     for (int p = 0; p < N; ++p) { maxdeg = std::max(maxdeg, ptstart[p + 1]); ptstart[p + 1] += ptstart[p]; }
     dense = (M == (int64_t)N * C);
+    for (int p = 0; p < N && dense; ++p) dense = (ptstart[p + 1] - ptstart[p] == C);
     if (maxdeg > PM_BLOCK) { err = "a point has more than 256 observations"; return SBA_ERR_UNSUPPORTED; }
     perm.resize(M);
     identity_perm = sorted;
@@ -235,6 +239,22 @@ struct Engine : EngineBase {
     else {
       std::vector<int32_t> fill(ptstart.begin(), ptstart.end() - 1);
       for (int64_t i = 0; i < M; ++i) perm[fill[pi_h[i]]++] = i;
+    }
+    if (dense) {
+      // dense = every camera sees every point exactly once; put the observations of a point in camera order
+      // (observation (p, c) at p*C + c), which is what get_points3d.py:78-86 emits anyway
+      std::vector<int64_t> slot(C);
+      for (int p = 0; p < N && dense; ++p) {
+        std::fill(slot.begin(), slot.end(), (int64_t)-1);
+        for (int k = 0; k < C; ++k) {
+          const int64_t i = perm[(size_t)p * C + k];
+          if (slot[ci_h[i]] >= 0) { dense = false; break; }
+          slot[ci_h[i]] = i;
+        }
+        if (!dense) break;
+        for (int k = 0; k < C; ++k)
+          if (perm[(size_t)p * C + k] != slot[k]) { perm[(size_t)p * C + k] = slot[k]; identity_perm = false; }
+      }
     }
     has_w = (w_h != nullptr);
     std::vector<T2> uvp(M);
@@ -322,7 +342,9 @@ struct Engine : EngineBase {
     slabs.alloc((size_t)npairs * ksplit * GROUP_TILES * GROUP_TILES * 256);
     E_own.alloc((size_t)n * n + 3 * n + 1); scal_own.alloc(NSCAL); delta_c.alloc(n);
     const int nres_blocks = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
-    cost_part.alloc((size_t)std::max(std::max(nblk, nres_blocks), 1)); gmax_part.alloc(std::max(nblk, 1));
+    fused_ok = dense && C <= GROUP_CAMS && sizeof(T) == 4 && N > 0 && !getenv("SBA_NO_FUSED");
+    if (fused_ok) Upart2.alloc((size_t)ksplit * C * UPK);
+    cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1));
     trial_part.alloc((size_t)4 * std::max(nblk, 1));
     sync();   // the staging vectors go out of scope now
     uploaded = true;
@@ -387,7 +409,18 @@ struct Engine : EngineBase {
                        has_w ? w_cm.p : nullptr, pi_cm.p, chunk_cam.p, chunk_begin.p, chunk_end.p, Upart.p);
     hipLaunchKernelGGL(k_reduce_cams, dim3(C), dim3(1024), 0, stream, Upart.p, cam_chunk_start.p, U.p, gc.p, st);
   }
+  // the linearisation is folded into the Schur kernel (k_schur_fused) whenever the cameras are free
+  bool fused() const { return fused_ok && h_state && h_state->free_cams; }
+  int n_lin_parts() const { return fused() ? ksplit : nblk; }       // entries of cost_part / gmax_part
   void launch_schur() {
+    if constexpr (sizeof(T) == 4) {
+      if (fused()) {
+        hipLaunchKernelGGL(k_schur_fused, dim3(ksplit), dim3(SCHUR_THREADS), SchurFusedCfg<float>::LDS_BYTES, stream,
+                           ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, N, ksplit, D2p.p, gp.p, pfac.p,
+                           slabs.p, bpart.p, Upart2.p, cost_part.p, gmax_part.p);
+        return;
+      }
+    }
     if (N > 0)
       hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
     // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
@@ -651,6 +684,7 @@ struct Engine : EngineBase {
   int lm_linearize() {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     if (sq_mode()) { launch_sq_linearize(d_state.p); return SBA_OK; }
+    if (fused()) return SBA_OK;          // k_schur_fused linearises
     prof_begin(KP_LINP);
     launch_linearize_points(d_state.p);
     prof_end(KP_LINP);
@@ -675,7 +709,8 @@ struct Engine : EngineBase {
       const int fc = (int)h_state->free_cams;
       const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 63) / 64 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
-                         pair_gb.p, npairs, U.p, gc.p, cost_part.p, nblk, C, fc, E, d_state.p);
+                         pair_gb.p, npairs, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
+                         fused() ? Upart2.p : (const T*)nullptr);
     }
     prof_end(KP_REDUCE);
     return SBA_OK;
@@ -748,7 +783,7 @@ struct Engine : EngineBase {
     launch_backsub_trial();
     prof_end(KP_BACKSUB);
     if (scal)
-      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, nblk, d_state.p, scal);
+      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, nblk, n_lin_parts(), d_state.p, scal);
     return SBA_OK;
   }
 
@@ -756,7 +791,7 @@ struct Engine : EngineBase {
   int lm_decide_async(const double* scal_all, int n_ranks) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(1024), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
-                       gmax_part.p, sq_mode() ? nblk_sq : nblk, reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
+                       gmax_part.p, sq_mode() ? nblk_sq : nblk, sq_mode() ? nblk_sq : n_lin_parts(), reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
     pslot_advance();
     return SBA_OK;
   }

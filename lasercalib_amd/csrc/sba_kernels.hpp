@@ -603,18 +603,13 @@ __device__ inline void schur_store_v(int v, typename Cfg::elem* slab, int lane,
   }
 }
 
-// One observation -> its 11x3 block of Ytilde = Jc^T Jp L^-T in the panel (+ z of its point).  f = k_point_factor's row
-// of the point: L^-1 (6), z (3), ok flag.
-template <typename T, bool DIAG>
-__device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict__ panelB, T* __restrict__ s_z,
-                                           const T* __restrict__ s_cam, int camA0, int nA, int camB0, int nB, int dense,
-                                           int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f) {
-  const bool inA = (c >= camA0 && c < camA0 + nA);
-  const bool inB = !DIAG && (c >= camB0 && c < camB0 + nB);
-  if (!inA && !inB) return;
-  T* pan = inA ? panelA : panelB;
-  const int col0 = (inA ? (c - camA0) : (c - camB0)) * NCP;
-  if (f[9] == (T)0) {              // degenerate point
+// Panel block of one observation from its Jacobian blocks: Ytilde = Jc^T (Jp L^-T)  (11x3), rows 3q..3q+2, columns col0..
+// f = the point's factor row: L^-1 (6), z (3), ok flag.  A degenerate point (ok == 0) writes zeros when `dense` demands
+// that every entry be rewritten.
+template <typename T>
+__device__ __forceinline__ void schur_emit_block(T* __restrict__ pan, int q, int col0, int dense,
+                                                 const T (&Jc)[2][NCP], const T (&Jp)[2][3], const T* f) {
+  if (f[9] == (T)0) {
     if (dense) {
 #pragma unroll
       for (int e = 0; e < NCP; ++e)
@@ -623,9 +618,6 @@ __device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict
     }
     return;
   }
-  const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
-  T r[2], Jc[2][NCP], Jp[2][3];
-  obs_resjac<T>(cp, X0, X1, X2, ux, uy, ww, r, Jc, Jp);
   // Jp~ = Jp * L^-T  (2x3):  (L^-T)[k][d] = Linv[d][k]
   T Jt[2][3];
 #pragma unroll
@@ -640,7 +632,25 @@ __device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict
     for (int d = 0; d < 3; ++d)
       pan[(3 * q + d) * GROUP_ROWS + col0 + e] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
   }
-  if (DIAG) { s_z[3 * q + 0] = f[6]; s_z[3 * q + 1] = f[7]; s_z[3 * q + 2] = f[8]; }   // same 3 values from every observation of the point
+}
+
+// One observation -> its 11x3 block of Ytilde in the panel of its camera group (+ z of its point).
+template <typename T, bool DIAG>
+__device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict__ panelB, T* __restrict__ s_z,
+                                           const T* __restrict__ s_cam, int camA0, int nA, int camB0, int nB, int dense,
+                                           int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f) {
+  const bool inA = (c >= camA0 && c < camA0 + nA);
+  const bool inB = !DIAG && (c >= camB0 && c < camB0 + nB);
+  if (!inA && !inB) return;
+  T* pan = inA ? panelA : panelB;
+  const int col0 = (inA ? (c - camA0) : (c - camB0)) * NCP;
+  T r[2], Jc[2][NCP], Jp[2][3];
+  if (f[9] != (T)0) {
+    const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
+    obs_resjac<T>(cp, X0, X1, X2, ux, uy, ww, r, Jc, Jp);
+  }
+  schur_emit_block<T>(pan, q, col0, dense, Jc, Jp, f);
+  if (DIAG && f[9] != (T)0) { s_z[3 * q + 0] = f[6]; s_z[3 * q + 1] = f[7]; s_z[3 * q + 2] = f[8]; }   // same 3 values from every observation of the point
 }
 
 // ------------------------------------------------------------------ K4: the kernel.  grid = (ksplit, pairs of this kind, TS)
@@ -939,6 +949,226 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
     __syncthreads();
     if (do_rhs && rhs_half == 0)
       bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + rhs_row] = bacc + s_rhs[rhs_row];
+  }
+}
+
+// ------------------------------------------------------------------ K3+K4 fused (dense visibility, <= 16 cameras, f32)
+// When every point is seen by every camera and there is one camera group, the producer lane (q, c) = (point of the
+// chunk, camera) meets the same camera in every chunk, and the 16 lanes of a DPP row hold all observations of one
+// point.  The whole linearisation then fits into the Schur producer, and each observation's Jacobian is evaluated
+// once per LM iteration instead of three times (k_linearize_points, k_linearize_cams, k_schur):
+//   * V_p = sum Jp^T Jp and g_p = sum Jp^T r : DPP row reduction over the 16 lanes of the point; column scaling D2p,
+//     damped 3x3 factor and z = L^-1 g_p follow in registers (the factor row pf[p] is stored for k_backsub_trial);
+//   * U_c = sum Jc^T Jc (66 upper-triangle entries) and g_c = sum Jc^T r (11) : per-lane register accumulators,
+//     folded over the 16 points-lanes of a camera through LDS at the end, one partial per workgroup
+//     (Upart2[wg][c][77]); k_build_exchange sums the partials in the same fixed-order loop as the slabs.
+// The two roles are split at the top level (same number of barriers on both sides), so the producers' 77 accumulators
+// and the consumers' 68 MFMA accumulator registers share the register file instead of adding up.
+constexpr int UPK = NCP * (NCP + 1) / 2 + NCP;                 // 77
+template <typename T> struct SchurFusedCfg : SchurCfg<T, true> {
+  static constexpr size_t LDS_BYTES = SchurCfg<T, true>::LDS_BYTES + (size_t)SchurCfg<T, true>::NPROD * UPK * sizeof(T);
+};
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, result in every lane: xor 1, xor 2 (quad_perm), then mirror inside 8 and inside 16
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);     // row_half_mirror
+  v += dpp_mov<0x140>(v);     // row_mirror
+  return v;
+}
+// L^-1 of the 3x3 SPD matrix (v00,v01,v02,v11,v12,v22) with hardware rsq (1 ulp): no sqrt / divide sequences
+__device__ __forceinline__ bool chol3_inv_fast(const float v[6], float li[6]) {
+  if (!(v[0] > 0.f)) return false;
+  const float i00 = __builtin_amdgcn_rsqf(v[0]);
+  const float l10 = v[1] * i00, l20 = v[2] * i00;
+  const float d11 = v[3] - l10 * l10;
+  if (!(d11 > 0.f)) return false;
+  const float i11 = __builtin_amdgcn_rsqf(d11);
+  const float l21 = (v[4] - l20 * l10) * i11;
+  const float d22 = v[5] - l20 * l20 - l21 * l21;
+  if (!(d22 > 0.f)) return false;
+  const float i22 = __builtin_amdgcn_rsqf(d22);
+  li[0] = i00;
+  li[1] = -l10 * i00 * i11;
+  li[2] = i11;
+  li[3] = (-l20 * i00 - l21 * li[1]) * i22;
+  li[4] = -l21 * i11 * i22;
+  li[5] = i22;
+  return isfinite(i22) && isfinite(i11) && isfinite(i00);
+}
+
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
+    const ParamSets<float> ps, const LMState* __restrict__ st, int C,
+    const float2* __restrict__ uv /* canonical dense order: observation (p, c) at p*C + c */, const float* __restrict__ w,
+    int N, int ksplit, double* __restrict__ D2p, double* __restrict__ gp, float* __restrict__ pf, float* __restrict__ slabs,
+    double* __restrict__ bpart, float* __restrict__ Upart2, double* __restrict__ cost_part, double* __restrict__ gmax_part) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using T = float;
+  using Cfg = SchurCfg<T, true>;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF;
+  static_assert(PTS == 16 && NPROD == 256, "lane = (point of the chunk, camera) needs 16 x 16 producer lanes");
+  if (st->status >= 0) return;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ campre = ps.campre[cur_];
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  T* s_buf = reinterpret_cast<T*>(smem);                          // [2][BUF]: panel [K][176], z [K]
+  T* s_cam = s_buf + 2 * BUF;                                     // [32][CAMPRE] (first 16 used)
+  T* s_U = s_cam + 2 * GROUP_CAMS * CAMPRE;                       // [256][UPK] at the end
+  __shared__ double s_scr[2][NPROD / 64];
+  for (int i = threadIdx.x; i < 2 * BUF; i += THREADS) s_buf[i] = (T)0;
+  for (int i = threadIdx.x; i < C * CAMPRE; i += THREADS) s_cam[i] = campre[i];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool producer = threadIdx.x < NPROD;
+  int per = (N + ksplit - 1) / ksplit;
+  per = ((per + PTS - 1) / PTS) * PTS;
+  const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
+  const int nchunk = (pend - pbeg + PTS - 1) / PTS;
+  const T lam = (T)st->lam;
+  __syncthreads();
+
+  if (producer) {
+    const int q = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const bool cam_ok = c < C;
+    const T* cp = s_cam + c * CAMPRE;
+    T Uacc[UPK];
+    static_for<0, UPK>([&](auto kc) { Uacc[decltype(kc)::value] = (T)0; });
+    T sq = 0, gmx = 0;
+    // operands of the next chunk, requested one chunk ahead
+    float2 n_uv = make_float2(0.f, 0.f);
+    T n_w = 1, n_X[3] = {0, 0, 0};
+    double n_D[3] = {0, 0, 0};
+    bool n_valid = false;
+    auto request = [&](int chunk) {
+      const int p = pbeg + chunk * PTS + q;
+      n_valid = chunk < nchunk && p < pend && cam_ok;
+      if (n_valid) {
+        const size_t o = (size_t)p * C + c;
+        n_uv = uv[o];
+        n_w = w ? w[o] : (T)1;
+        n_X[0] = ptsT[3 * (size_t)p]; n_X[1] = ptsT[3 * (size_t)p + 1]; n_X[2] = ptsT[3 * (size_t)p + 2];
+        n_D[0] = D2p[3 * (size_t)p]; n_D[1] = D2p[3 * (size_t)p + 1]; n_D[2] = D2p[3 * (size_t)p + 2];
+      }
+    };
+    request(0);
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it < nchunk) {
+        T* panel = s_buf + (it & 1) * BUF;
+        T* s_z = panel + K * GROUP_ROWS;
+        const bool valid = n_valid;
+        const float2 m = n_uv;
+        const T ww = n_w, X0 = n_X[0], X1 = n_X[1], X2 = n_X[2];
+        const double D0 = n_D[0], D1 = n_D[1], D2 = n_D[2];
+        const int p = pbeg + it * PTS + q;
+        request(it + 1);
+        T r[2] = {0, 0}, Jc[2][NCP], Jp[2][3];
+#pragma unroll
+        for (int e = 0; e < NCP; ++e) { Jc[0][e] = 0; Jc[1][e] = 0; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { Jp[0][d] = 0; Jp[1][d] = 0; }
+        if (valid) obs_resjac<T>(cp, X0, X1, X2, m.x, m.y, ww, r, Jc, Jp);
+        sq += r[0] * r[0] + r[1] * r[1];
+        // per-point blocks: V (6) and g_p (3), summed over the 16 cameras of the DPP row
+        T v6[6], g3[3];
+        v6[0] = row16_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
+        v6[1] = row16_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
+        v6[2] = row16_sum(Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2]);
+        v6[3] = row16_sum(Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1]);
+        v6[4] = row16_sum(Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2]);
+        v6[5] = row16_sum(Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2]);
+        g3[0] = row16_sum(Jp[0][0] * r[0] + Jp[1][0] * r[1]);
+        g3[1] = row16_sum(Jp[0][1] * r[0] + Jp[1][1] * r[1]);
+        g3[2] = row16_sum(Jp[0][2] * r[0] + Jp[1][2] * r[1]);
+        gmx = fmaxf(gmx, fmaxf(fabsf(g3[0]), fmaxf(fabsf(g3[1]), fabsf(g3[2]))));
+        // point scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
+        const double E0 = fmax(D0, (double)v6[0]), E1 = fmax(D1, (double)v6[3]), E2 = fmax(D2, (double)v6[5]);
+        T f[PF];
+        T li[6];
+        T vd[6] = {v6[0] + lam * (T)fmax_pos(E0), v6[1], v6[2], v6[3] + lam * (T)fmax_pos(E1), v6[4], v6[5] + lam * (T)fmax_pos(E2)};
+        const bool okp = valid && chol3_inv_fast(vd, li);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) f[k] = (T)0;
+        if (okp) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) f[k] = li[k];
+          f[6] = li[0] * g3[0];
+          f[7] = li[1] * g3[0] + li[2] * g3[1];
+          f[8] = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
+          f[9] = (T)1;
+        }
+        if (valid && c == 0) {
+          D2p[3 * (size_t)p] = E0; D2p[3 * (size_t)p + 1] = E1; D2p[3 * (size_t)p + 2] = E2;
+          gp[3 * (size_t)p] = (double)g3[0]; gp[3 * (size_t)p + 1] = (double)g3[1]; gp[3 * (size_t)p + 2] = (double)g3[2];
+          float4* o4 = reinterpret_cast<float4*>(pf + (size_t)p * PF);
+          o4[0] = make_float4(f[0], f[1], f[2], f[3]);
+          o4[1] = make_float4(f[4], f[5], f[6], f[7]);
+          o4[2] = make_float4(f[8], f[9], f[10], f[11]);
+        }
+        if (cam_ok) {
+          schur_emit_block<T>(panel, q, c * NCP, 1, Jc, Jp, f);
+          if (c == 0) { s_z[3 * q + 0] = f[6]; s_z[3 * q + 1] = f[7]; s_z[3 * q + 2] = f[8]; }
+        }
+        // camera blocks: U_c upper triangle + g_c in registers (this lane always serves camera c)
+        static_for<0, NCP>([&](auto ac) {
+          constexpr int a = decltype(ac)::value;
+          static_for<a, NCP>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            constexpr int k = a * NCP - (a * (a - 1)) / 2 + (b - a);
+            Uacc[k] += Jc[0][a] * Jc[0][b] + Jc[1][a] * Jc[1][b];
+          });
+          Uacc[NCP * (NCP + 1) / 2 + a] += Jc[0][a] * r[0] + Jc[1][a] * r[1];
+        });
+      }
+      __syncthreads();
+    }
+    // hand the accumulators over
+    static_for<0, UPK>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * UPK + k] = Uacc[k]; });
+    const double cs = wave_sum((double)sq), gm = wave_max((double)gmx);
+    if (lane == 0) { s_scr[0][wid] = cs; s_scr[1][wid] = gm; }
+  } else {
+    const int cw = wid - NPROD / 64;
+    typename Mfma<T>::acc_t acc[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) acc[s] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+    const int ct = threadIdx.x - NPROD;
+    const int lane_off = (lane >> 4) * GROUP_ROWS + (lane & 15);
+    double bacc = 0;
+    __builtin_amdgcn_s_setprio(2);
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it >= 1) {
+        const T* panel = s_buf + ((it - 1) & 1) * BUF;
+        const T* s_z = panel + K * GROUP_ROWS;
+        if (ct < GROUP_ROWS) {
+          T s0 = 0, s1 = 0;
+#pragma unroll 8
+          for (int k = 0; k < K; k += 2) { s0 += panel[k * GROUP_ROWS + ct] * s_z[k]; s1 += panel[(k + 1) * GROUP_ROWS + ct] * s_z[k + 1]; }
+          bacc += (double)(s0 + s1);
+        }
+        schur_consume_v<Cfg, K>(cw, panel + lane_off, panel + lane_off, acc);
+      }
+      __syncthreads();
+    }
+    T* slab = slabs + (size_t)blockIdx.x * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
+    schur_store_v<Cfg>(cw, slab, lane, acc);
+    if (ct < GROUP_ROWS) bpart[(size_t)blockIdx.x * GROUP_ROWS + ct] = bacc;
+  }
+  __syncthreads();
+  // fold the 16 point-lanes of every camera: Upart2[wg][c][k] = sum_q s_U[(16 q + c)][k]
+  for (int o = threadIdx.x; o < C * UPK; o += THREADS) {
+    const int c = o / UPK, k = o - c * UPK;
+    T s = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += s_U[(q * 16 + c) * UPK + k];
+    Upart2[((size_t)blockIdx.x * C + c) * UPK + k] = s;
+  }
+  if (threadIdx.x == 0) {
+    double cs = 0, gm = 0;
+    for (int wv = 0; wv < NPROD / 64; ++wv) { cs += s_scr[0][wv]; gm = fmax(gm, s_scr[1][wv]); }
+    cost_part[blockIdx.x] = 0.5 * cs;
+    gmax_part[blockIdx.x] = gm;
   }
 }
 

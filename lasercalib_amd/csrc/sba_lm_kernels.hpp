@@ -23,7 +23,8 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     const T* __restrict__ slabs, const double* __restrict__ bpart, int ksplit, const int32_t* __restrict__ pair_ga,
     const int32_t* __restrict__ pair_gb, int npairs, const double* __restrict__ U, const double* __restrict__ gc,
     const double* __restrict__ cost_part, int n_cost_part, int C, int free_cams, double* __restrict__ E,
-    const LMState* __restrict__ st) {
+    const LMState* __restrict__ st,
+    const T* __restrict__ Upart2 /* fused linearisation: per-workgroup camera partials [ksplit][C][UPK] instead of U / gc */) {
   using M_ = Mfma<T>;
   constexpr int NG = 16;
   __shared__ double s_p[NG][64];
@@ -60,15 +61,26 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
       s3 += (double)src[(size_t)(k + 3 * NG) * stride];
     }
     for (; k < ksplit; k += NG) s0 += (double)src[(size_t)k * stride];
+    const int ci_ = i / NCP, cj_ = j / NCP;
+    const bool ublock = (i < n && j < n && ci_ == cj_);
+    if (Upart2 && ublock) {          // the camera's own block: S = U - (Schur partials); U summed in the same order
+      const int a = min(i - ci_ * NCP, j - cj_ * NCP), b = max(i - ci_ * NCP, j - cj_ * NCP);
+      const T* up = Upart2 + (size_t)ci_ * UPK + (a * NCP - (a * (a - 1)) / 2 + (b - a));
+      const size_t us = (size_t)C * UPK;
+      double u0 = 0, u1 = 0;
+      int k2 = g;
+      for (; k2 + NG < ksplit; k2 += 2 * NG) { u0 += (double)up[(size_t)k2 * us]; u1 += (double)up[(size_t)(k2 + NG) * us]; }
+      if (k2 < ksplit) u0 += (double)up[(size_t)k2 * us];
+      s0 -= u0 + u1;
+    }
     s_p[g][l64] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && i < n && j < n) {
       double s = 0;
 #pragma unroll
       for (int q = 0; q < NG; ++q) s += s_p[q][l64];
-      const int ci_ = i / NCP, cj_ = j / NCP;
       double v = -s;
-      if (ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
+      if (!Upart2 && ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
       E[(size_t)i * n + j] = v;
       if (!(diag && R == Tc)) E[(size_t)j * n + i] = v;
     }
@@ -78,6 +90,36 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
   double* rhs = E + (size_t)n * n;
   double* dU = rhs + n;
   double* gv = dU + n;
+  if (bid < row_blocks && Upart2) {
+    // fused linearisation: g_c and diag(U) come from the per-workgroup partials too
+    __shared__ double s_q[2][NG][64];
+    const int i = bid * 64 + l64;
+    double b = 0, gsum = 0, dsum = 0;
+    if (i < n) {
+      const int grp = i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;
+      const int c = i / NCP, e = i - c * NCP;
+      const double* src = bpart + (size_t)grp * ksplit * GROUP_ROWS + rho;
+      const T* ug = Upart2 + (size_t)c * UPK + NCP * (NCP + 1) / 2 + e;
+      const T* ud = Upart2 + (size_t)c * UPK + (e * NCP - (e * (e - 1)) / 2);
+      const size_t us = (size_t)C * UPK;
+      for (int k = g; k < ksplit; k += NG) {
+        b += src[(size_t)k * GROUP_ROWS];
+        gsum += (double)ug[(size_t)k * us];
+        dsum += (double)ud[(size_t)k * us];
+      }
+    }
+    s_p[g][l64] = b; s_q[0][g][l64] = gsum; s_q[1][g][l64] = dsum;
+    __syncthreads();
+    if (g == 0 && i < n) {
+      double bs = 0, gs = 0, dsv = 0;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) { bs += s_p[q][l64]; gs += s_q[0][q][l64]; dsv += s_q[1][q][l64]; }
+      rhs[i] = -gs + bs;
+      dU[i] = dsv;
+      gv[i] = gs;
+    }
+    return;
+  }
   if (bid < row_blocks) {
     const int i = bid * 64 + l64;
     double b = 0;
@@ -455,14 +497,14 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
 
 // one block: fold the per-block partials into this rank's 8 scalars
 __global__ void k_trial_scalars(const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
-                                int nblk, const LMState* __restrict__ st, double* __restrict__ scal) {
+                                int nblk, int n_gmax, const LMState* __restrict__ st, double* __restrict__ scal) {
   __shared__ double scr[4];
   if (st->status >= 0) return;
   double a = 0, b = 0, c = 0, d = 0, g = 0;
   for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
     a += trial_part[i]; b += trial_part[nblk + i]; c += trial_part[2 * nblk + i]; d += trial_part[3 * nblk + i];
-    g = fmax(g, gmax_part[i]);
   }
+  for (int i = threadIdx.x; i < n_gmax; i += blockDim.x) g = fmax(g, gmax_part[i]);
   a = block_sum(a, scr); b = block_sum(b, scr); c = block_sum(c, scr); d = block_sum(d, scr); g = block_max(g, scr);
   if (threadIdx.x == 0) {
     scal[0] = a; scal[1] = b; scal[2] = c; scal[3] = d; scal[4] = g; scal[5] = (double)st->chol_fail;
@@ -480,7 +522,8 @@ template <typename T>
 __global__ __launch_bounds__(1024) void k_decide(LMState* __restrict__ st,
                                                 const double* __restrict__ scal_all, int n_ranks,
                                                 const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
-                                                int nblk, LMLogRow* __restrict__ log, int log_cap) {
+                                                int nblk, int n_gmax /* entries of gmax_part (one per linearisation workgroup) */,
+                                                LMLogRow* __restrict__ log, int log_cap) {
   __shared__ double scr[16];
   if (st->status >= 0) return;
   double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
@@ -489,9 +532,9 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* __restrict__ st,
     // 1024 threads, all five loads of an index independent: a few rounds of memory latency in total
     for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
       const double t0 = trial_part[i], t1 = trial_part[nblk + i], t2 = trial_part[2 * nblk + i], t3 = trial_part[3 * nblk + i];
-      const double t4 = gmax_part[i];
-      a += t0; b += t1; c += t2; d += t3; g = fmax(g, t4);
+      a += t0; b += t1; c += t2; d += t3;
     }
+    for (int i = threadIdx.x; i < n_gmax; i += blockDim.x) g = fmax(g, gmax_part[i]);
     cost_new = block_sum(a, scr); pred = block_sum(b, scr); dx2 = block_sum(c, scr); x2 = block_sum(d, scr);
     gmax = block_max(g, scr);
     failv = (double)st->chol_fail;

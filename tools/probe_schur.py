@@ -45,3 +45,6 @@ if __name__ == "__main__":
     run(20, 200, 0.7)
     run(40, 100, 0.5)
     run(20, 200, 0.7, "f32")
+    run(16, 200, 1.0, "f32")     # dense, one group: fused linearise + Schur kernel
+    run(6, 101, 1.0, "f32")
+    run(16, 37, 1.0, "f32")
