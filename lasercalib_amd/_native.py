@@ -62,6 +62,29 @@ class LmIterLog(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's);
+    if this library pulled in the system copy first, a later ``import torch`` would bring up a second runtime that
+    finds no GPU ("No HIP GPUs are available").  When torch is installed but not imported yet, its copy is loaded
+    first so that both resolve to the same runtime; torch itself is not imported."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.isfile(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libsba_hip.so once; raise (never fall back) when it is not there."""
     global _lib
@@ -71,6 +94,7 @@ def load():
         raise SbaError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C lasercalib_amd/csrc`. lasercalib_amd has no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
     H = C.c_void_p

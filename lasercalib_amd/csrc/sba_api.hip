@@ -105,6 +105,8 @@ struct Engine : EngineBase {
   bool has_w = false;
   bool identity_perm = true;
   bool dense = false;                // every point is observed by every camera exactly once
+  bool dense_one_group = false;      // dense and <= 16 cameras: lane = (point, camera) kernels apply
+  int nbs_dense = 1;                 // workgroups of k_backsub_dense
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
   DevBuf<T> Upart2;
   std::vector<int64_t> perm;          // pm position -> caller's observation index
@@ -342,7 +344,9 @@ struct Engine : EngineBase {
     slabs.alloc((size_t)npairs * ksplit * GROUP_TILES * GROUP_TILES * 256);
     E_own.alloc((size_t)n * n + 3 * n + 1); scal_own.alloc(NSCAL); delta_c.alloc(n);
     const int nres_blocks = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
-    fused_ok = dense && C <= GROUP_CAMS && sizeof(T) == 4 && N > 0 && !getenv("SBA_NO_FUSED");
+    dense_one_group = dense && C <= GROUP_CAMS && N > 0 && !getenv("SBA_NO_DENSE");
+    nbs_dense = std::max(1, std::min((N + 15) / 16, getenv("SBA_BS_WGS") ? atoi(getenv("SBA_BS_WGS")) : (sizeof(T) == 4 ? 768 : 512)));
+    fused_ok = dense_one_group && sizeof(T) == 4 && !getenv("SBA_NO_FUSED");
     if (fused_ok) Upart2.alloc((size_t)ksplit * C * UPK);
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1));
     trial_part.alloc((size_t)4 * std::max(nblk, 1));
@@ -465,8 +469,16 @@ struct Engine : EngineBase {
                          has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
                          pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
   }
+  // dense visibility with one camera group: the row-reduction kernel (any dtype); its partial rows are per workgroup
+  bool backsub_dense() const { return dense_one_group; }
+  int n_trial_parts() const { return backsub_dense() ? nbs_dense : nblk; }
   void launch_backsub_trial() {
     if (nblk == 0) return;
+    if (backsub_dense()) {
+      hipLaunchKernelGGL(k_backsub_dense<T>, dim3(nbs_dense), dim3(PM_BLOCK), 0, stream, ps_lm(), C, uv_pm.p,
+                         has_w ? w_pm.p : nullptr, N, pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nbs_dense);
+      return;
+    }
     const size_t lds = (size_t)PM_BLOCK * 6 * sizeof(double) + (2 * (size_t)C * CAMPRE + (size_t)C * NCP) * sizeof(T);
     hipLaunchKernelGGL(k_backsub_trial<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, ps_lm(), C,
                        uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_desc.p,
@@ -783,7 +795,7 @@ struct Engine : EngineBase {
     launch_backsub_trial();
     prof_end(KP_BACKSUB);
     if (scal)
-      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, nblk, n_lin_parts(), d_state.p, scal);
+      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, n_trial_parts(), n_lin_parts(), d_state.p, scal);
     return SBA_OK;
   }
 
@@ -791,7 +803,7 @@ struct Engine : EngineBase {
   int lm_decide_async(const double* scal_all, int n_ranks) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(1024), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
-                       gmax_part.p, sq_mode() ? nblk_sq : nblk, sq_mode() ? nblk_sq : n_lin_parts(), reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
+                       gmax_part.p, sq_mode() ? nblk_sq : n_trial_parts(), sq_mode() ? nblk_sq : n_lin_parts(), reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
     pslot_advance();
     return SBA_OK;
   }

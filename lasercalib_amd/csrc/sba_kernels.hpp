@@ -980,6 +980,18 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x140>(v);     // row_mirror
   return v;
 }
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
 // L^-1 of the 3x3 SPD matrix (v00,v01,v02,v11,v12,v22) with hardware rsq (1 ulp): no sqrt / divide sequences
 __device__ __forceinline__ bool chol3_inv_fast(const float v[6], float li[6]) {
   if (!(v[0] > 0.f)) return false;

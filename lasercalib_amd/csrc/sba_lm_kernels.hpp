@@ -512,6 +512,104 @@ __global__ void k_trial_scalars(const double* __restrict__ trial_part, const dou
   }
 }
 
+// ------------------------------------------------------------------ K6 for dense visibility, one camera group
+// Same arithmetic as k_backsub_trial, laid out like k_schur_fused: lane (q, c) = (point of a 16-point chunk, camera),
+// so W_p^T delta_c is a DPP row sum instead of an LDS staging pass with two barriers, the workgroup is persistent
+// (camera tables staged once, chunks strided over the grid) and each partial row holds a whole workgroup's share.
+template <typename T>
+__global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
+    const ParamSets<T> ps, int C, const typename Vec2<T>::type* __restrict__ uv /* observation (p, c) at p*C + c */,
+    const T* __restrict__ w, int N, const T* __restrict__ pf, const double* __restrict__ gp, const double* __restrict__ D2p,
+    const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ trial_part, int nparts) {
+  __shared__ T s_cam[GROUP_CAMS * CAMPRE], s_camn[GROUP_CAMS * CAMPRE], s_dc[GROUP_CAMS * NCP];
+  __shared__ double s_scr[PM_BLOCK / 64];
+  if (st->status >= 0) return;
+  const int cur_ = ps_cur(ps, st);
+  const double* __restrict__ pts = ps.pts[cur_];
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  double* __restrict__ pts_new = ps.pts[cur_ ^ 1];
+  T* __restrict__ ptsT_new = ps.ptsT[cur_ ^ 1];
+  const bool free_cams = st->free_cams != 0;
+  const double lam = st->lam;
+  stage_campre(ps.campre[cur_], s_cam, C);
+  stage_campre(ps.campre[cur_ ^ 1], s_camn, C);
+  for (int i = threadIdx.x; i < C * NCP; i += PM_BLOCK) s_dc[i] = (T)delta_c[i];
+  __syncthreads();
+  const int q = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const bool cam_ok = c < C;
+  T dc[NCP];
+#pragma unroll
+  for (int e = 0; e < NCP; ++e) dc[e] = cam_ok ? s_dc[c * NCP + e] : (T)0;
+  const T* cp = s_cam + (cam_ok ? c : 0) * CAMPRE;
+  const T* cpn = s_camn + (cam_ok ? c : 0) * CAMPRE;
+  double sq = 0, pred = 0, dx2 = 0, x2 = 0;
+  const int nch = (N + 15) / 16;
+  for (int ch = blockIdx.x; ch < nch; ch += gridDim.x) {
+    const int p = ch * 16 + q;
+    const bool pt_ok = p < N;
+    const bool valid = pt_ok && cam_ok;
+    const size_t pp = (size_t)(pt_ok ? p : 0);
+    typename Vec2<T>::type m; m.x = 0; m.y = 0;
+    T ww = (T)1;
+    if (valid) { m = uv[pp * C + c]; if (w) ww = w[pp * C + c]; }
+    // every lane of the row reads the point's data (same addresses: one transaction) and solves for its step
+    // redundantly.  (Requesting the next chunk's operands one chunk ahead was measured: no gain, the kernel is
+    // issue-bound at three workgroups per CU and the extra registers cost one of them.)
+    T f[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) f[k] = pf[pp * PF + k];
+    const double g0 = gp[pp * 3], g1 = gp[pp * 3 + 1], g2 = gp[pp * 3 + 2];
+    const double dd0 = fmax_pos(D2p[pp * 3]), dd1 = fmax_pos(D2p[pp * 3 + 1]), dd2 = fmax_pos(D2p[pp * 3 + 2]);
+    const double X0 = pts[pp * 3], X1 = pts[pp * 3 + 1], X2 = pts[pp * 3 + 2];
+    T t0 = 0, t1 = 0, t2 = 0;
+    if (free_cams && valid) {
+      T r[2], Jc[2][NCP], Jp[2][3];
+      obs_resjac<T>(cp, ptsT[pp * 3], ptsT[pp * 3 + 1], ptsT[pp * 3 + 2], m.x, m.y, ww, r, Jc, Jp);
+      T s0 = 0, s1 = 0;
+#pragma unroll
+      for (int e = 0; e < NCP; ++e) { s0 += Jc[0][e] * dc[e]; s1 += Jc[1][e] * dc[e]; }
+      t0 = Jp[0][0] * s0 + Jp[1][0] * s1;
+      t1 = Jp[0][1] * s0 + Jp[1][1] * s1;
+      t2 = Jp[0][2] * s0 + Jp[1][2] * s1;
+    }
+    const double T0 = (double)row16_sum(t0), T1 = (double)row16_sum(t1), T2 = (double)row16_sum(t2);
+    double e0 = 0, e1 = 0, e2 = 0;
+    if (f[9] != (T)0) {     // delta = -(V + lam D)^-1 (g + t) = -L^-T ( z + L^-1 t )
+      const double l0 = f[0], l1 = f[1], l2 = f[2], l3 = f[3], l4 = f[4], l5 = f[5];
+      const double y0 = -((double)f[6] + l0 * T0);
+      const double y1 = -((double)f[7] + l1 * T0 + l2 * T1);
+      const double y2 = -((double)f[8] + l3 * T0 + l4 * T1 + l5 * T2);
+      e0 = l0 * y0 + l1 * y1 + l3 * y2;
+      e1 = l2 * y1 + l4 * y2;
+      e2 = l5 * y2;
+    }
+    const double n0 = X0 + e0, n1 = X1 + e1, n2 = X2 + e2;
+    if (pt_ok && c == 0) {
+      pts_new[pp * 3] = n0; pts_new[pp * 3 + 1] = n1; pts_new[pp * 3 + 2] = n2;
+      ptsT_new[pp * 3] = (T)n0; ptsT_new[pp * 3 + 1] = (T)n1; ptsT_new[pp * 3 + 2] = (T)n2;
+      pred += 0.5 * (e0 * (lam * dd0 * e0 - g0) + e1 * (lam * dd1 * e1 - g1) + e2 * (lam * dd2 * e2 - g2));
+      dx2 += e0 * e0 + e1 * e1 + e2 * e2;
+      x2 += X0 * X0 + X1 * X1 + X2 * X2;
+    }
+    if (valid) {
+      T u, v;
+      obs_project<T>(cpn, (T)n0, (T)n1, (T)n2, u, v);
+      const T r0 = ww * (u - m.x), r1 = ww * (v - m.y);
+      sq += (double)r0 * r0 + (double)r1 * r1;
+    }
+  }
+  const double c_new = block_sum(sq, s_scr);
+  const double b_pred = block_sum(pred, s_scr);
+  const double b_dx2 = block_sum(dx2, s_scr);
+  const double b_x2 = block_sum(x2, s_scr);
+  if (threadIdx.x == 0) {
+    trial_part[blockIdx.x] = 0.5 * c_new;
+    trial_part[nparts + blockIdx.x] = b_pred;
+    trial_part[2 * nparts + blockIdx.x] = b_dx2;
+    trial_part[3 * nparts + blockIdx.x] = b_x2;
+  }
+}
+
 // ------------------------------------------------------------------ accept / reject / terminate
 // One iteration-log row per trial step, same columns scipy prints with verbose=2 (layout = sba_lm_iter_log).
 struct LMLogRow { int iteration; int accepted; long long nfev; double cost, cost_reduction, step_norm, optimality, lambda, rho; };
