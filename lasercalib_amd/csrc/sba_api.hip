@@ -108,7 +108,7 @@ struct Engine : EngineBase {
   bool dense_one_group = false;      // dense and <= 16 cameras: lane = (point, camera) kernels apply
   int nbs_dense = 1;                 // workgroups of k_backsub_dense
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
-  DevBuf<T> Upart2;
+  DevBuf<double> gdpart;
   std::vector<int64_t> perm;          // pm position -> caller's observation index
   int nblk = 0, nchunk = 0, ngroups = 0, npairs = 0, ksplit = 1;
   int n = 0;                          // 11*C
@@ -347,7 +347,7 @@ struct Engine : EngineBase {
     dense_one_group = dense && C <= GROUP_CAMS && N > 0 && !getenv("SBA_NO_DENSE");
     nbs_dense = std::max(1, std::min((N + 15) / 16, getenv("SBA_BS_WGS") ? atoi(getenv("SBA_BS_WGS")) : (sizeof(T) == 4 ? 768 : 512)));
     fused_ok = dense_one_group && sizeof(T) == 4 && !getenv("SBA_NO_FUSED");
-    if (fused_ok) Upart2.alloc((size_t)ksplit * C * UPK);
+    if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * GROUP_ROWS);
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1));
     trial_part.alloc((size_t)4 * std::max(nblk, 1));
     sync();   // the staging vectors go out of scope now
@@ -421,7 +421,7 @@ struct Engine : EngineBase {
       if (fused()) {
         hipLaunchKernelGGL(k_schur_fused, dim3(ksplit), dim3(SCHUR_THREADS), SchurFusedCfg<float>::LDS_BYTES, stream,
                            ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, N, ksplit, D2p.p, gp.p, pfac.p,
-                           slabs.p, bpart.p, Upart2.p, cost_part.p, gmax_part.p);
+                           slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p);
         return;
       }
     }
@@ -722,7 +722,7 @@ struct Engine : EngineBase {
       const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 63) / 64 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, npairs, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? Upart2.p : (const T*)nullptr);
+                         fused() ? gdpart.p : (const double*)nullptr);
     }
     prof_end(KP_REDUCE);
     return SBA_OK;

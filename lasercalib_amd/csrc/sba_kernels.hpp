@@ -1017,7 +1017,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
     const ParamSets<float> ps, const LMState* __restrict__ st, int C,
     const float2* __restrict__ uv /* canonical dense order: observation (p, c) at p*C + c */, const float* __restrict__ w,
     int N, int ksplit, double* __restrict__ D2p, double* __restrict__ gp, float* __restrict__ pf, float* __restrict__ slabs,
-    double* __restrict__ bpart, float* __restrict__ Upart2, double* __restrict__ cost_part, double* __restrict__ gmax_part) {
+    double* __restrict__ bpart, double* __restrict__ gdpart /* [ksplit][2][176]: g_c and diag U_c partials */,
+    double* __restrict__ cost_part, double* __restrict__ gmax_part) {
   extern __shared__ __align__(16) unsigned char smem[];
   using T = float;
   using Cfg = SchurCfg<T, true>;
@@ -1040,6 +1041,17 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
   const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
   const int nchunk = (pend - pbeg + PTS - 1) / PTS;
   const T lam = (T)st->lam;
+  T* s_Ured = s_buf;                                              // [C][UPK] once the panels are done with
+  // fold the 16 point-lanes of every camera: U_c[k] = sum_q s_U[16 q + c][k]
+  auto fold_u = [&]() {
+    for (int o = threadIdx.x; o < C * UPK; o += THREADS) {
+      const int c = o / UPK, k = o - c * UPK;
+      T sum = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += s_U[(q * 16 + c) * UPK + k];
+      s_Ured[o] = sum;
+    }
+  };
   __syncthreads();
 
   if (producer) {
@@ -1140,6 +1152,9 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
     static_for<0, UPK>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * UPK + k] = Uacc[k]; });
     const double cs = wave_sum((double)sq), gm = wave_max((double)gmx);
     if (lane == 0) { s_scr[0][wid] = cs; s_scr[1][wid] = gm; }
+    __syncthreads();
+    fold_u();
+    __syncthreads();
   } else {
     const int cw = wid - NPROD / 64;
     typename Mfma<T>::acc_t acc[TPW];
@@ -1163,18 +1178,45 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
       }
       __syncthreads();
     }
+    __syncthreads();
+    // wait for the camera blocks U_c of this workgroup (folded below by everybody), then take them out of the tiles:
+    // the slab then holds this workgroup's share of  sum Ytilde Ytilde^T - U,  and k_build_exchange's plain sum of the
+    // slabs is -S.  Only tiles on and next to the diagonal contain entries of an 11x11 camera block.
+    fold_u();
+    __syncthreads();
+    constexpr int LO = 0;
+    static_for<0, Cfg::NV>([&](auto vc) {
+      constexpr int V = decltype(vc)::value;
+      if (cw == V) {
+        constexpr int T0 = V * TPW, T1 = (T0 + TPW < Cfg::NTILE) ? T0 + TPW : Cfg::NTILE;
+        static_for<T0, T1>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+          if constexpr (Tc - R <= 1) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int i = 16 * R + Mfma<T>::row_of(lane, rg), j = 16 * Tc + (lane & 15);
+              const int ci_ = i / NCP, cj_ = j / NCP;
+              if (ci_ == cj_ && ci_ < C) {
+                const int a = min(i - ci_ * NCP, j - cj_ * NCP), b = max(i - ci_ * NCP, j - cj_ * NCP);
+                acc[t - T0][rg] -= s_Ured[ci_ * UPK + (a * NCP - (a * (a - 1)) / 2 + (b - a))];
+              }
+            }
+          }
+        });
+      }
+    });
+    (void)LO;
     T* slab = slabs + (size_t)blockIdx.x * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
     schur_store_v<Cfg>(cw, slab, lane, acc);
-    if (ct < GROUP_ROWS) bpart[(size_t)blockIdx.x * GROUP_ROWS + ct] = bacc;
-  }
-  __syncthreads();
-  // fold the 16 point-lanes of every camera: Upart2[wg][c][k] = sum_q s_U[(16 q + c)][k]
-  for (int o = threadIdx.x; o < C * UPK; o += THREADS) {
-    const int c = o / UPK, k = o - c * UPK;
-    T s = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) s += s_U[(q * 16 + c) * UPK + k];
-    Upart2[((size_t)blockIdx.x * C + c) * UPK + k] = s;
+    if (ct < GROUP_ROWS) {
+      const int c = ct / NCP, e = ct - c * NCP;
+      const double gpart = (c < C) ? (double)s_Ured[c * UPK + NCP * (NCP + 1) / 2 + e] : 0.0;
+      const double dpart = (c < C) ? (double)s_Ured[c * UPK + (e * NCP - (e * (e - 1)) / 2)] : 0.0;
+      bpart[(size_t)blockIdx.x * GROUP_ROWS + ct] = bacc - gpart;           // rhs = sum (b - g_c) over the workgroups
+      gdpart[((size_t)blockIdx.x * 2 + 0) * GROUP_ROWS + ct] = gpart;
+      gdpart[((size_t)blockIdx.x * 2 + 1) * GROUP_ROWS + ct] = dpart;
+    }
   }
   if (threadIdx.x == 0) {
     double cs = 0, gm = 0;

@@ -4,6 +4,7 @@
 // (scipy/optimize/_lsq/trf.py:401-560) with an exact damped solve; termination tests and status
 // codes keep scipy's meaning (scipy/optimize/_lsq/common.py:705-717).
 #pragma once
+#include <cstddef>
 #include "sba_kernels.hpp"
 
 namespace sba {
@@ -24,7 +25,8 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     const int32_t* __restrict__ pair_gb, int npairs, const double* __restrict__ U, const double* __restrict__ gc,
     const double* __restrict__ cost_part, int n_cost_part, int C, int free_cams, double* __restrict__ E,
     const LMState* __restrict__ st,
-    const T* __restrict__ Upart2 /* fused linearisation: per-workgroup camera partials [ksplit][C][UPK] instead of U / gc */) {
+    const double* __restrict__ gdpart /* fused linearisation: per-workgroup g_c / diag U partials [ksplit][2][176] (then the
+                                          slabs hold Schur partials - U and bpart holds b - g_c); NULL = classic U / gc */) {
   using M_ = Mfma<T>;
   constexpr int NG = 16;
   __shared__ double s_p[NG][64];
@@ -62,25 +64,14 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     }
     for (; k < ksplit; k += NG) s0 += (double)src[(size_t)k * stride];
     const int ci_ = i / NCP, cj_ = j / NCP;
-    const bool ublock = (i < n && j < n && ci_ == cj_);
-    if (Upart2 && ublock) {          // the camera's own block: S = U - (Schur partials); U summed in the same order
-      const int a = min(i - ci_ * NCP, j - cj_ * NCP), b = max(i - ci_ * NCP, j - cj_ * NCP);
-      const T* up = Upart2 + (size_t)ci_ * UPK + (a * NCP - (a * (a - 1)) / 2 + (b - a));
-      const size_t us = (size_t)C * UPK;
-      double u0 = 0, u1 = 0;
-      int k2 = g;
-      for (; k2 + NG < ksplit; k2 += 2 * NG) { u0 += (double)up[(size_t)k2 * us]; u1 += (double)up[(size_t)(k2 + NG) * us]; }
-      if (k2 < ksplit) u0 += (double)up[(size_t)k2 * us];
-      s0 -= u0 + u1;
-    }
     s_p[g][l64] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && i < n && j < n) {
       double s = 0;
 #pragma unroll
       for (int q = 0; q < NG; ++q) s += s_p[q][l64];
-      double v = -s;
-      if (!Upart2 && ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
+      double v = -s;                 // fused linearisation: the slabs already hold (Schur partials - U)
+      if (!gdpart && ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
       E[(size_t)i * n + j] = v;
       if (!(diag && R == Tc)) E[(size_t)j * n + i] = v;
     }
@@ -90,31 +81,30 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
   double* rhs = E + (size_t)n * n;
   double* dU = rhs + n;
   double* gv = dU + n;
-  if (bid < row_blocks && Upart2) {
-    // fused linearisation: g_c and diag(U) come from the per-workgroup partials too
+  if (bid < row_blocks && gdpart) {
+    // fused linearisation: g_c and diag(U) come from per-workgroup partial rows laid out like bpart
     __shared__ double s_q[2][NG][64];
     const int i = bid * 64 + l64;
-    double b = 0, gsum = 0, dsum = 0;
+    double b0 = 0, b1 = 0, g0 = 0, g1 = 0, d0 = 0, d1 = 0;
     if (i < n) {
-      const int grp = i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;
-      const int c = i / NCP, e = i - c * NCP;
+      const int grp = i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;        // one camera group in this mode: grp == 0
       const double* src = bpart + (size_t)grp * ksplit * GROUP_ROWS + rho;
-      const T* ug = Upart2 + (size_t)c * UPK + NCP * (NCP + 1) / 2 + e;
-      const T* ud = Upart2 + (size_t)c * UPK + (e * NCP - (e * (e - 1)) / 2);
-      const size_t us = (size_t)C * UPK;
-      for (int k = g; k < ksplit; k += NG) {
-        b += src[(size_t)k * GROUP_ROWS];
-        gsum += (double)ug[(size_t)k * us];
-        dsum += (double)ud[(size_t)k * us];
+      const double* gs_ = gdpart + rho;
+      int k = g;
+      for (; k + NG < ksplit; k += 2 * NG) {
+        b0 += src[(size_t)k * GROUP_ROWS]; b1 += src[(size_t)(k + NG) * GROUP_ROWS];
+        g0 += gs_[(size_t)k * 2 * GROUP_ROWS]; g1 += gs_[(size_t)(k + NG) * 2 * GROUP_ROWS];
+        d0 += gs_[((size_t)k * 2 + 1) * GROUP_ROWS]; d1 += gs_[((size_t)(k + NG) * 2 + 1) * GROUP_ROWS];
       }
+      if (k < ksplit) { b0 += src[(size_t)k * GROUP_ROWS]; g0 += gs_[(size_t)k * 2 * GROUP_ROWS]; d0 += gs_[((size_t)k * 2 + 1) * GROUP_ROWS]; }
     }
-    s_p[g][l64] = b; s_q[0][g][l64] = gsum; s_q[1][g][l64] = dsum;
+    s_p[g][l64] = b0 + b1; s_q[0][g][l64] = g0 + g1; s_q[1][g][l64] = d0 + d1;
     __syncthreads();
     if (g == 0 && i < n) {
       double bs = 0, gs = 0, dsv = 0;
 #pragma unroll
       for (int q = 0; q < NG; ++q) { bs += s_p[q][l64]; gs += s_q[0][q][l64]; dsv += s_q[1][q][l64]; }
-      rhs[i] = -gs + bs;
+      rhs[i] = bs;                   // k_schur_fused stored b - g_c
       dU[i] = dsv;
       gv[i] = gs;
     }
@@ -617,13 +607,23 @@ struct LMLogRow { int iteration; int accepted; long long nfev; double cost, cost
 // scal_all: n_ranks x 8 scalars (already gathered), or -- single rank -- nullptr, in which case the block folds the
 // per-block partials itself (what k_trial_scalars does for the multi-rank path) and no separate launch is needed.
 template <typename T>
-__global__ __launch_bounds__(1024) void k_decide(LMState* __restrict__ st,
+__global__ __launch_bounds__(1024) void k_decide(LMState* st,
                                                 const double* __restrict__ scal_all, int n_ranks,
                                                 const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
                                                 int nblk, int n_gmax /* entries of gmax_part (one per linearisation workgroup) */,
                                                 LMLogRow* __restrict__ log, int log_cap) {
   __shared__ double scr[16];
-  if (st->status >= 0) return;
+  // The decision logic is a chain of dependent reads and writes of the state record; done against global memory every
+  // link costs a memory round trip.  The record is staged in LDS by the whole block (its load overlaps the partial
+  // sums), thread 0 works on that copy, writes it back with fire-and-forget stores and publishes `status` last.
+  __shared__ LMState s_st;
+  static_assert(sizeof(LMState) % 4 == 0, "LMState is copied word by word");
+  constexpr int NWORD = sizeof(LMState) / 4;
+  if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
+  __syncthreads();
+  if (s_st.status >= 0) return;
+  LMState* const gst = st;
+  st = &s_st;
   double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
   if (scal_all == nullptr) {
     double a = 0, b = 0, c = 0, d = 0, g = 0;
@@ -693,8 +693,16 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* __restrict__ st,
     row.cost_reduction = actual; row.step_norm = st->step_norm; row.optimality = gmax; row.lambda = st->lam; row.rho = rho;
     log[st->iter - 1] = row;
   }
+  {
+    constexpr int SW = offsetof(LMState, status) / 4;
+    const int* src = reinterpret_cast<const int*>(&s_st);
+    int* dst = reinterpret_cast<int*>(gst);
+#pragma unroll
+    for (int wd = 0; wd < NWORD; ++wd)
+      if (wd != SW) dst[wd] = src[wd];
+  }
   __threadfence();
-  st->status = status;
+  gst->status = status;
 }
 
 }  // namespace sba
