@@ -2,7 +2,7 @@
 """Print VGPR/SGPR/LDS/scratch/occupancy per kernel (hipcc -Rpass-analysis=kernel-resource-usage)."""
 import re, subprocess, sys, os
 here = os.path.dirname(os.path.abspath(__file__))
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-slp-vectorize",
        "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/sba_ru.so", os.path.join(here, "sba_api.hip")]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}

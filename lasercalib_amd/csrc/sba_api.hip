@@ -421,7 +421,15 @@ struct Engine : EngineBase {
       if (fused()) {
         hipLaunchKernelGGL(k_schur_fused, dim3(ksplit), dim3(SCHUR_THREADS), SchurFusedCfg<float>::LDS_BYTES, stream,
                            ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, N, ksplit, D2p.p, gp.p, pfac.p,
-                           slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p);
+                           slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p, schur_debug ? schur_dbg.p : nullptr);
+        if (schur_debug) {
+          std::vector<long long> st(64);
+          HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+          sync();
+          fprintf(stderr, "[schur_fused stamps, cycles since the first producer stamp; per chunk: producer-done consumer-done]\n");
+          for (int i = 0; i < 14; ++i) fprintf(stderr, "  it %2d: P %7lld  C %7lld\n", i, st[2 * i] - st[0], st[2 * i + 1] - st[0]);
+          schur_debug = false;
+        }
         return;
       }
     }

@@ -1018,7 +1018,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
     const float2* __restrict__ uv /* canonical dense order: observation (p, c) at p*C + c */, const float* __restrict__ w,
     int N, int ksplit, double* __restrict__ D2p, double* __restrict__ gp, float* __restrict__ pf, float* __restrict__ slabs,
     double* __restrict__ bpart, double* __restrict__ gdpart /* [ksplit][2][176]: g_c and diag U_c partials */,
-    double* __restrict__ cost_part, double* __restrict__ gmax_part) {
+    double* __restrict__ cost_part, double* __restrict__ gmax_part,
+    long long* __restrict__ dbg /* optional cycle stamps of workgroup 0: [it][producer done, consumer done] */) {
   extern __shared__ __align__(16) unsigned char smem[];
   using T = float;
   using Cfg = SchurCfg<T, true>;
@@ -1141,11 +1142,12 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
           static_for<a, NCP>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             constexpr int k = a * NCP - (a * (a - 1)) / 2 + (b - a);
-            Uacc[k] += Jc[0][a] * Jc[0][b] + Jc[1][a] * Jc[1][b];
+            Uacc[k] = __builtin_fmaf(Jc[1][a], Jc[1][b], __builtin_fmaf(Jc[0][a], Jc[0][b], Uacc[k]));   // two FMAs, no add
           });
-          Uacc[NCP * (NCP + 1) / 2 + a] += Jc[0][a] * r[0] + Jc[1][a] * r[1];
+          Uacc[NCP * (NCP + 1) / 2 + a] = __builtin_fmaf(Jc[1][a], r[1], __builtin_fmaf(Jc[0][a], r[0], Uacc[NCP * (NCP + 1) / 2 + a]));
         });
       }
+      if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && it < 20) dbg[2 * it] = clock64();
       __syncthreads();
     }
     // hand the accumulators over
@@ -1176,6 +1178,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
         }
         schur_consume_v<Cfg, K>(cw, panel + lane_off, panel + lane_off, acc);
       }
+      if (dbg && blockIdx.x == 0 && threadIdx.x == NPROD && it < 20) dbg[2 * it + 1] = clock64();
       __syncthreads();
     }
     __syncthreads();
