@@ -138,7 +138,7 @@ struct Engine : EngineBase {
   bool chol_old = false;
   void* rs_handle = nullptr;
   int rocsolver_min_n = 512;
-  DevBuf<double> chol_sol;
+  DevBuf<double> chol_sol, chol_work;
   DevBuf<int> chol_info;
   bool chol_debug = false;
   bool schur_debug = false;
@@ -197,6 +197,7 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     if (const char* e = getenv("SBA_CHOL")) chol_old = (std::string(e) == "old");
     if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
     if (const char* e = getenv("SBA_ROCSOLVER_MIN_N")) rocsolver_min_n = atoi(e);
@@ -319,7 +320,8 @@ struct Engine : EngineBase {
       int target = 256;
       if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
       // workgroups per k-split: every pair is dealt to TS workgroups (tile split, grid.z of k_schur)
-      const int wg_per_ks = ngroups * SchurSel<T, true>::TS + (npairs - ngroups) * SchurSel<T, false>::TS;
+      // the diagonal and the off-diagonal pairs are two launches, one after the other: each must fill the chip
+      const int wg_per_ks = std::max(ngroups * SchurSel<T, true>::TS, (npairs - ngroups) * SchurSel<T, false>::TS);
       int ks = std::max(1, target / wg_per_ks);
       const int maxks = std::max(1, (N + SCHUR_PTS - 1) / SCHUR_PTS);
       ksplit = std::min(ks, maxks);
@@ -786,6 +788,17 @@ struct Engine : EngineBase {
             rs.dpotrs(rs_handle, ROCBLAS_FILL_UPPER, n_sys, 1, Esys, n_sys, chol_sol.p, n_sys) != 0) {
           err = "rocsolver potrf/potrs failed"; return SBA_ERR_HIP;
         }
+        hipLaunchKernelGGL(k_chol_epilogue<T>, dim3(1), dim3(1024), 0, stream, Esys, C, n_sys, d_state.p, D2c.p, ps_lm(), delta_c.p,
+                           chol_sol.p, chol_info.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
+      } else if (n_sys <= CS_MAX_NB * CB && !chol_old) {
+        // 17 .. 46 cameras: one workgroup, left-looking, finished block columns streamed through L2
+        const int nb = (n_sys + CB - 1) / CB;
+        if (chol_sol.n < (size_t)n_sys) { chol_sol.alloc(n_sys); chol_info.alloc(1); }
+        if (chol_work.n < (size_t)nb * (nb + 1) / 2 * CB * CB) chol_work.alloc((size_t)nb * (nb + 1) / 2 * CB * CB);
+        const size_t lds = ((size_t)2 * nb * CBS + (size_t)nb * CB) * sizeof(double);
+        hipLaunchKernelGGL(k_chol_prepare, dim3((n_sys + 255) / 256), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p, chol_sol.p);
+        hipLaunchKernelGGL(k_cholesky_stream, dim3(1), dim3(CHOLB_THREADS), lds, stream, Esys, n_sys, chol_work.p, chol_sol.p,
+                           chol_info.p, d_state.p);
         hipLaunchKernelGGL(k_chol_epilogue<T>, dim3(1), dim3(1024), 0, stream, Esys, C, n_sys, d_state.p, D2c.p, ps_lm(), delta_c.p,
                            chol_sol.p, chol_info.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       } else {

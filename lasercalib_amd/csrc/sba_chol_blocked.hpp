@@ -368,4 +368,142 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
 #undef CHOL_STAMP
 }
 
+// ------------------------------------------------------------------ streamed Cholesky for 176 < n <= 512
+// The same 16x16 building blocks, left-looking, for systems whose block triangle does not fit the LDS (17 .. 46
+// cameras): only the current block column (panel) lives in LDS; the finished columns are written to a global block
+// workspace W (L2-resident: one workgroup wrote them) and streamed back, as many at a time as the staging buffer
+// holds, to downdate the next panel.  A = damped matrix prepared by k_chol_prepare (full, symmetric, row-major),
+// sol = rhs in / solution out, so the kernel sits between the same prepare / epilogue kernels as the library path.
+constexpr int CS_MAX_NB = 32;
+__device__ inline size_t cs_blk(int r, int c) { return ((size_t)r * (r + 1) / 2 + c) * (CB * CB); }
+
+__global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_stream(
+    const double* __restrict__ A, int n, double* __restrict__ W /* nb(nb+1)/2 blocks of 16x16 */,
+    double* __restrict__ sol, int* __restrict__ info, const LMState* __restrict__ st) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if (st->status >= 0) return;
+  const int nb = (n + CB - 1) / CB, n16 = nb * CB;
+  double* P = reinterpret_cast<double*>(smem);          // [nb][CBS] panel: block i <-> block row j + i
+  double* S = P + (size_t)nb * CBS;                     // [nb][CBS] staging of finished columns
+  double* s_y = S + (size_t)nb * CBS;                   // [n16] rhs -> y -> x
+  __shared__ int s_fail;
+  __shared__ double s_part[32][CB];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int NW = CHOLB_THREADS / 64;
+  for (int i = tid; i < n16; i += CHOLB_THREADS) s_y[i] = (i < n) ? sol[i] : 0.0;
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  for (int j = 0; j < nb && !s_fail; ++j) {
+    const int m = nb - j;
+    // (1) the panel: blocks (j+i, j) of A; the padded tail is the identity
+    for (int e = tid; e < m * CB * CB; e += CHOLB_THREADS) {
+      const int i = e >> 8, ii = (e >> 4) & 15, jj = e & 15;
+      const int I = (j + i) * CB + ii, J = j * CB + jj;
+      P[i * CBS + ii * CLD + jj] = (I < n && J < n) ? A[(size_t)I * n + J] : ((I == J) ? 1.0 : 0.0);
+    }
+    // (2) downdate with the finished block columns, g of them per staging round
+    const int gmax = max(1, nb / m);
+    for (int k0 = 0; k0 < j; k0 += gmax) {
+      const int g = min(gmax, j - k0);
+      __syncthreads();
+      for (int e = tid; e < g * m * CB * CB; e += CHOLB_THREADS) {
+        const int b = e >> 8, ii = (e >> 4) & 15, jj = e & 15;
+        const int kk = b / m, i = b - kk * m;
+        S[b * CBS + ii * CLD + jj] = W[cs_blk(j + i, k0 + kk) + ii * CB + jj];
+      }
+      __syncthreads();
+      for (int i = wid; i < m; i += NW) {
+        double* Dt = P + i * CBS;
+        Mfma<double>::acc_t acc;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[rg] = Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)];
+        for (int kk = 0; kk < g; ++kk) {
+          const double* Pa = S + (kk * m + i) * CBS + (lane & 15) * CLD + (lane >> 4);
+          const double* Pb = S + (kk * m) * CBS + (lane & 15) * CLD + (lane >> 4);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) acc = Mfma<double>::mma(-Pa[4 * ks], Pb[4 * ks], acc);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg];
+      }
+    }
+    __syncthreads();
+    // (3) diagonal tile -> Linv^T
+    if (wid == 0) {
+      if (!chol16_wave(P)) { if (lane == 0) s_fail = 1; }
+    }
+    __syncthreads();
+    if (s_fail) break;
+    // (4) panel solve (MFMA) and forward substitution of the rhs block
+    for (int i = 1 + wid; i < m; i += NW) chol_panel_block(P + i * CBS, P);
+    if (wid == NW - 1) {       // the wave with the fewest panel blocks forward-solves the rhs block: y = Linv rhs
+      const int i = lane & 15, part = lane >> 4;
+      double x = 0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) { const int k = part + 4 * kk; x += P[k * CLD + i] * s_y[j * CB + k]; }
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      __builtin_amdgcn_wave_barrier();
+      if (part == 0) s_y[j * CB + i] = x;
+    }
+    __syncthreads();
+    // rhs tail and write-back of the finished column
+    for (int t = tid; t < (m - 1) * CB; t += CHOLB_THREADS) {
+      const double* row = P + (1 + (t >> 4)) * CBS + (t & 15) * CLD;
+      double s0 = 0, s1 = 0;
+#pragma unroll
+      for (int k = 0; k < CB; k += 2) { s0 += row[k] * s_y[j * CB + k]; s1 += row[k + 1] * s_y[j * CB + k + 1]; }
+      s_y[(j + 1) * CB + t] -= s0 + s1;
+    }
+    for (int e = tid; e < m * CB * CB; e += CHOLB_THREADS) {
+      const int i = e >> 8, ii = (e >> 4) & 15, jj = e & 15;
+      W[cs_blk(j + i, j) + ii * CB + jj] = P[i * CBS + ii * CLD + jj];
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  __syncthreads();
+  const bool fail = s_fail != 0;
+  // back substitution, left-looking: x_b = Linv_b^T ( y_b - sum_{r>b} L(r,b)^T x_r ), column b streamed from W
+  if (!fail) {
+    for (int b = nb - 1; b >= 0; --b) {
+      const int m = nb - b;
+      for (int e = tid; e < m * CB * CB; e += CHOLB_THREADS) {
+        const int i = e >> 8, ii = (e >> 4) & 15, jj = e & 15;
+        S[i * CBS + ii * CLD + jj] = W[cs_blk(b + i, b) + ii * CB + jj];
+      }
+      __syncthreads();
+      {
+        const int jcol = tid & 15, part = tid >> 4;          // 32 parts over the (m-1)*16 rows below the diagonal block
+        double s0 = 0;
+        for (int rr = part; rr < (m - 1) * CB; rr += 32)
+          s0 += S[(1 + (rr >> 4)) * CBS + (rr & 15) * CLD + jcol] * s_y[(b + 1) * CB + rr];
+        s_part[part][jcol] = s0;
+      }
+      __syncthreads();
+      if (wid == 0) {
+        const int jcol = lane & 15, part = lane >> 4;
+        if (lane < CB) {
+          double v = 0;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) v += s_part[q][lane];
+          s_y[b * CB + lane] -= v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double* LiT = S + jcol * CLD;                  // row jcol of Linv^T (block 0 of the staged column)
+        double x = 0;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) { const int i = part + 4 * ii; x += LiT[i] * s_y[b * CB + i]; }
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (part == 0) s_y[b * CB + jcol] = x;
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += CHOLB_THREADS) sol[i] = fail ? 0.0 : s_y[i];
+  if (tid == 0) *info = fail ? 1 : 0;
+}
+
 }  // namespace sba

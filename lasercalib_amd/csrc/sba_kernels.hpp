@@ -755,6 +755,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
           const int o_lo = pt_start[p0], o_hi = pt_start[p1];
           for (int o = o_lo + threadIdx.x; o < o_hi; o += NPROD) {
             const int c = ci[o];
+            // several camera groups: most observations belong to other pairs -- drop them before touching anything else
+            if (!((c >= camA0 && c < camA0 + nA) || (!DIAG && c >= camB0 && c < camB0 + nB))) continue;
             const int pp = pi[o];
             T f[PF];
 #pragma unroll
@@ -908,6 +910,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
       const int o_lo = pt_start[p0], o_hi = pt_start[p1];
       for (int o = o_lo + threadIdx.x; o < o_hi; o += THREADS) {
         const int c = ci[o];
+        if (!((c >= camA0 && c < camA0 + nA) || (!DIAG && c >= camB0 && c < camB0 + nB))) continue;
         const int pp = pi[o];
         T f[PF];
 #pragma unroll

@@ -5,7 +5,8 @@ import numpy as np
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig
 C, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (16, 50000)
-rig = make_rig(C, N, seed=0)
+VIS = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+rig = make_rig(C, N, seed=0, visibility=VIS)
 for dtype in ("f64", "f32"):
     t = time.time()
     prob = _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], dtype=dtype)
