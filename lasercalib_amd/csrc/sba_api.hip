@@ -192,6 +192,10 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -438,10 +442,17 @@ struct Engine : EngineBase {
     if (N > 0)
       hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
     // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
+    // a camera count that is not a multiple of 16 leaves the last group's panel mostly empty: the PARTIAL
+    // instantiations skip the MFMAs of empty tiles (kept apart so that the full-group kernels pay nothing for it)
+    // (f64 only: the f32 consumers are paced by their producers and lose more to the per-tile branches than they save)
+    if (C % GROUP_CAMS != 0 && SCHUR_SYM<T>) launch_schur_kernels<true>();
+    else launch_schur_kernels<false>();
+  }
+  template <bool PARTIAL> void launch_schur_kernels() {
     using CfgD = SchurSel<T, true>;
     using CfgO = SchurSel<T, false>;
     if constexpr (SCHUR_SYM<T>) {
-      hipLaunchKernelGGL((k_schur_sym<T, true>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
+      hipLaunchKernelGGL((k_schur_sym<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
                          stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
                          pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p, schur_debug ? schur_dbg.p : nullptr);
       if (schur_debug) {
@@ -454,13 +465,13 @@ struct Engine : EngineBase {
         schur_debug = false;
       }
       if (npairs > ngroups)
-        hipLaunchKernelGGL((k_schur_sym<T, false>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
+        hipLaunchKernelGGL((k_schur_sym<T, false, PARTIAL>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
                            CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
                            has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
                            pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
       return;
     }
-    hipLaunchKernelGGL((k_schur<T, true>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
+    hipLaunchKernelGGL((k_schur<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
                        stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
                        pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,
                        schur_debug ? schur_dbg.p : nullptr);
@@ -474,7 +485,7 @@ struct Engine : EngineBase {
       schur_debug = false;
     }
     if (npairs > ngroups)
-      hipLaunchKernelGGL((k_schur<T, false>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
+      hipLaunchKernelGGL((k_schur<T, false, PARTIAL>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
                          CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
                          has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
                          pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);

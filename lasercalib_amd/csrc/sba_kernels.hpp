@@ -537,10 +537,11 @@ template <typename T, bool DIAG> using SchurSel = std::conditional_t<SCHUR_SYM<T
 // with V a compile-time constant one k-step needs only the distinct 16-row fragments (<= 11 for a diagonal pair, whose
 // A and B operands are the same panel fragments; <= 3 + 11 otherwise), all MFMAs of a k-step are independent, and the
 // next k-step's fragments are fetched while they issue.
-template <typename Cfg, int V, int K>
+template <typename Cfg, int V, int K, bool PARTIAL = false>
 __device__ inline void schur_consume(const typename Cfg::elem* __restrict__ pla /* panelA + lane offset */,
                                      const typename Cfg::elem* __restrict__ plb,
-                                     typename Mfma<typename Cfg::elem>::acc_t (&acc)[Cfg::TPW]) {
+                                     typename Mfma<typename Cfg::elem>::acc_t (&acc)[Cfg::TPW],
+                                     int usedA = GROUP_TILES, int usedB = GROUP_TILES /* PARTIAL: 16-row tiles that hold cameras */) {
   using T = typename Cfg::elem;
   using M_ = Mfma<T>;
   constexpr bool DIAG = Cfg::diag;
@@ -568,7 +569,9 @@ __device__ inline void schur_consume(const typename Cfg::elem* __restrict__ pla 
       static_for<LO, HI>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int R = schur_tile_R(DIAG, t), Tc = schur_tile_T(DIAG, t);
-        acc[t - LO] = M_::mma(fa[cur][R], DIAG ? fa[cur][Tc] : fb[cur][Tc], acc[t - LO]);
+        // PARTIAL kernels (camera count not a multiple of 16): the last group leaves whole tiles empty -- skip them
+        if (!PARTIAL || (R < usedA && Tc < usedB))
+          acc[t - LO] = M_::mma(fa[cur][R], DIAG ? fa[cur][Tc] : fb[cur][Tc], acc[t - LO]);
       });
     }
   }
@@ -586,12 +589,13 @@ __device__ inline void schur_store(typename Cfg::elem* __restrict__ slab, int la
 }
 
 // dispatch on the (runtime) virtual wave index; NV <= 16
-template <typename Cfg, int K, int V = 0>
+template <typename Cfg, int K, bool PARTIAL = false, int V = 0>
 __device__ inline void schur_consume_v(int v, const typename Cfg::elem* pla, const typename Cfg::elem* plb,
-                                       typename Mfma<typename Cfg::elem>::acc_t (&acc)[Cfg::TPW]) {
+                                       typename Mfma<typename Cfg::elem>::acc_t (&acc)[Cfg::TPW],
+                                       int usedA = GROUP_TILES, int usedB = GROUP_TILES) {
   if constexpr (V < Cfg::NV) {
-    if (v == V) schur_consume<Cfg, V, K>(pla, plb, acc);
-    else schur_consume_v<Cfg, K, V + 1>(v, pla, plb, acc);
+    if (v == V) schur_consume<Cfg, V, K, PARTIAL>(pla, plb, acc, usedA, usedB);
+    else schur_consume_v<Cfg, K, PARTIAL, V + 1>(v, pla, plb, acc, usedA, usedB);
   }
 }
 template <typename Cfg, int V = 0>
@@ -654,7 +658,7 @@ __device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict
 }
 
 // ------------------------------------------------------------------ K4: the kernel.  grid = (ksplit, pairs of this kind, TS)
-template <typename T, bool DIAG>
+template <typename T, bool DIAG, bool PARTIAL = false>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
     const ParamSets<T> ps, const LMState* __restrict__ st, int C,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
@@ -674,6 +678,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
   const int ga = pair_ga[pair], gb = pair_gb[pair];
   const int camA0 = ga * GROUP_CAMS, camB0 = gb * GROUP_CAMS;
   const int nA = min(GROUP_CAMS, C - camA0), nB = min(GROUP_CAMS, C - camB0);
+  const int usedA = (nA * NCP + 15) / 16, usedB = DIAG ? usedA : (nB * NCP + 15) / 16;
   T* s_buf = reinterpret_cast<T*>(smem);                          // [2][BUF]: panelA [K][176], (panelB), z [K]
   T* s_cam = s_buf + 2 * BUF;                                     // [32][CAMPRE] : group A then group B
   for (int i = threadIdx.x; i < 2 * BUF; i += THREADS) s_buf[i] = (T)0;
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
         for (int k = 0; k < K; k += 2) { s0 += panelA[k * GROUP_ROWS + ct] * s_z[k]; s1 += panelA[(k + 1) * GROUP_ROWS + ct] * s_z[k + 1]; }
         bacc += (double)(s0 + s1);
       }
-      schur_consume_v<Cfg, K>(vw, panelA + lane_off, panelB + lane_off, acc);
+      schur_consume_v<Cfg, K, PARTIAL>(vw, panelA + lane_off, panelB + lane_off, acc, usedA, usedB);
     }
     if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && it < 20) {
       if (threadIdx.x == 0) dbg[3 * it + 0] = clock64();
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
 }
 
 // ------------------------------------------------------------------ K4 (symmetric): grid = (ksplit, pairs of this kind, TS)
-template <typename T, bool DIAG>
+template <typename T, bool DIAG, bool PARTIAL = false>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
     const ParamSets<T> ps, const LMState* __restrict__ st, int C,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
@@ -833,6 +838,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
   const int ga = pair_ga[pair], gb = pair_gb[pair];
   const int camA0 = ga * GROUP_CAMS, camB0 = gb * GROUP_CAMS;
   const int nA = min(GROUP_CAMS, C - camA0), nB = min(GROUP_CAMS, C - camB0);
+  const int usedA = (nA * NCP + 15) / 16, usedB = DIAG ? usedA : (nB * NCP + 15) / 16;
   T* panelA = reinterpret_cast<T*>(smem);                         // [K][176]
   T* panelB = DIAG ? panelA : panelA + K * GROUP_ROWS;
   T* s_z = panelA + Cfg::NPANEL * K * GROUP_ROWS;                 // [K]
@@ -935,7 +941,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
       }
       bacc += (double)(s0 + s1);
     }
-    schur_consume_v<Cfg, K>(vw, panelA + lane_off, panelB + lane_off, acc);
+    schur_consume_v<Cfg, K, PARTIAL>(vw, panelA + lane_off, panelB + lane_off, acc, usedA, usedB);
     __syncthreads();
     if (stamp) dbg[3 * it + 2] = clock64();
     if (!dense) {
