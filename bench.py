@@ -36,8 +36,8 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # f32-in MFMA = vector rate 157
 # HBM bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_*: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
 # 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).  Valid for the default workload only
 # (16 cams x 50k points, f32, one GPU); other shapes report null.
-PMC_TRAFFIC_BYTES_16x50k_F32 = {"schur": 26.58e6, "resjac": 104.62e6, "linearize_points": 20.30e6,
-                                "linearize_cams": 15.53e6, "backsub": 22.26e6, "residual": 13.12e6}
+PMC_TRAFFIC_BYTES_16x50k_F32 = {"schur_fused": 30.56e6, "schur": 26.58e6, "resjac": 104.62e6, "linearize_points": 19.93e6,
+                                "linearize_cams": 15.52e6, "backsub": 14.54e6, "residual": 13.12e6}
 
 
 def parse():
