@@ -806,10 +806,20 @@ struct Engine : EngineBase {
         const int nb = (n_sys + CB - 1) / CB;
         if (chol_sol.n < (size_t)n_sys) { chol_sol.alloc(n_sys); chol_info.alloc(1); }
         if (chol_work.n < (size_t)nb * (nb + 1) / 2 * CB * CB) chol_work.alloc((size_t)nb * (nb + 1) / 2 * CB * CB);
-        const size_t lds = ((size_t)2 * nb * CBS + (size_t)nb * CB) * sizeof(double);
+        // panel (nb blocks) + rhs + as much staging as the 150 KB budget leaves (fewer, larger streaming rounds)
+        const size_t fixed = ((size_t)nb * CBS + (size_t)nb * CB) * sizeof(double);
+        const int scap = std::min(64, std::max(nb, (int)((150 * 1024 - fixed) / (CBS * sizeof(double)))));
+        const size_t lds = fixed + (size_t)scap * CBS * sizeof(double);
         hipLaunchKernelGGL(k_chol_prepare, dim3((n_sys + 255) / 256), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p, chol_sol.p);
         hipLaunchKernelGGL(k_cholesky_stream, dim3(1), dim3(CHOLB_THREADS), lds, stream, Esys, n_sys, chol_work.p, chol_sol.p,
-                           chol_info.p, d_state.p);
+                           chol_info.p, d_state.p, scap, chol_debug ? (chol_dbg.n ? chol_dbg.p : (chol_dbg.alloc(64), chol_dbg.p)) : nullptr);
+        if (chol_debug) {
+          std::vector<long long> st(8);
+          HIPCHK(hipMemcpyAsync(st.data(), chol_dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+          sync();
+          fprintf(stderr, "[chol_stream cycles] update %lld  factor %lld  solve %lld  write-back %lld  back-substitution %lld\n", st[0], st[1], st[2], st[3], st[4]);
+          chol_debug = false;
+        }
         hipLaunchKernelGGL(k_chol_epilogue<T>, dim3(1), dim3(1024), 0, stream, Esys, C, n_sys, d_state.p, D2c.p, ps_lm(), delta_c.p,
                            chol_sol.p, chol_info.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       } else {

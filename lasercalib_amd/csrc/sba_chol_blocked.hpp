@@ -375,41 +375,93 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
 // holds, to downdate the next panel.  A = damped matrix prepared by k_chol_prepare (full, symmetric, row-major),
 // sol = rhs in / solution out, so the kernel sits between the same prepare / epilogue kernels as the library path.
 constexpr int CS_MAX_NB = 32;
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt (its release fence cannot tell loads
+// from stores on gfx9), which would expose the latency of the global loads deliberately left in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ inline size_t cs_blk(int r, int c) { return ((size_t)r * (r + 1) / 2 + c) * (CB * CB); }
 
 __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_stream(
     const double* __restrict__ A, int n, double* __restrict__ W /* nb(nb+1)/2 blocks of 16x16 */,
-    double* __restrict__ sol, int* __restrict__ info, const LMState* __restrict__ st) {
+    double* __restrict__ sol, int* __restrict__ info, const LMState* __restrict__ st,
+    int scap /* blocks the staging buffer holds (>= nb): the launch gives it whatever LDS is left */,
+    long long* __restrict__ dbg /* optional: cycles per phase [update, factor, solve, write-back, back substitution] */) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (st->status >= 0) return;
   const int nb = (n + CB - 1) / CB, n16 = nb * CB;
   double* P = reinterpret_cast<double*>(smem);          // [nb][CBS] panel: block i <-> block row j + i
-  double* S = P + (size_t)nb * CBS;                     // [nb][CBS] staging of finished columns
-  double* s_y = S + (size_t)nb * CBS;                   // [n16] rhs -> y -> x
+  double* S = P + (size_t)nb * CBS;                     // [scap][CBS] staging of finished columns
+  double* s_y = S + (size_t)scap * CBS;                 // [n16] rhs -> y -> x
   __shared__ int s_fail;
   __shared__ double s_part[32][CB];
+  __shared__ int s_src[72];                              // source block offsets of a staging round (scap <= 64)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   constexpr int NW = CHOLB_THREADS / 64;
   for (int i = tid; i < n16; i += CHOLB_THREADS) s_y[i] = (i < n) ? sol[i] : 0.0;
   if (tid == 0) s_fail = 0;
   __syncthreads();
+  // the next panel's entries of A (and, on the way back, the next column of L) are requested one step ahead into
+  // registers, so the fabric / L2 latency of a panel sits behind the factorisation of the previous one
+  constexpr int MAXPRE = CS_MAX_NB * CB * CB / CHOLB_THREADS;     // 16 values per thread at 32 block rows
+  double pre[MAXPRE];
+  auto fetch_panel = [&](int jc) {
+    const int mm = nb - jc;
+#pragma unroll
+    for (int u = 0; u < MAXPRE; ++u) {
+      const int e = tid + u * CHOLB_THREADS;
+      pre[u] = 0;
+      if (e < mm * CB * CB) {
+        const int i = e >> 8, ii = (e >> 4) & 15, jj = e & 15;
+        const int I = (jc + i) * CB + ii, J = jc * CB + jj;
+        pre[u] = (I < n && J < n) ? A[(size_t)I * n + J] : ((I == J) ? 1.0 : 0.0);     // padded tail = identity
+      }
+    }
+  };
+  auto fetch_column = [&](int bc) {
+    const int mm = nb - bc;
+#pragma unroll
+    for (int u = 0; u < MAXPRE; ++u) {
+      const int e = tid + u * CHOLB_THREADS;
+      pre[u] = 0;
+      if (e < mm * CB * CB) pre[u] = W[cs_blk(bc + (e >> 8), bc) + (e & 255)];
+    }
+  };
+  auto commit = [&](double* dst, int mm) {
+#pragma unroll
+    for (int u = 0; u < MAXPRE; ++u) {
+      const int e = tid + u * CHOLB_THREADS;
+      if (e < mm * CB * CB) dst[(e >> 8) * CBS + ((e >> 4) & 15) * CLD + (e & 15)] = pre[u];
+    }
+  };
+  long long ph[5] = {0, 0, 0, 0, 0}, t_prev = clock64();
+  auto lap = [&](int k) { const long long t = clock64(); ph[k] += t - t_prev; t_prev = t; };
+  fetch_panel(0);
   for (int j = 0; j < nb && !s_fail; ++j) {
     const int m = nb - j;
-    // (1) the panel: blocks (j+i, j) of A; the padded tail is the identity
-    for (int e = tid; e < m * CB * CB; e += CHOLB_THREADS) {
-      const int i = e >> 8, ii = (e >> 4) & 15, jj = e & 15;
-      const int I = (j + i) * CB + ii, J = j * CB + jj;
-      P[i * CBS + ii * CLD + jj] = (I < n && J < n) ? A[(size_t)I * n + J] : ((I == J) ? 1.0 : 0.0);
-    }
+    // (1) the panel: blocks (j+i, j) of A, requested during the previous step
+    commit(P, m);
     // (2) downdate with the finished block columns, g of them per staging round
-    const int gmax = max(1, nb / m);
+    const int gmax = max(1, scap / m);
     for (int k0 = 0; k0 < j; k0 += gmax) {
       const int g = min(gmax, j - k0);
       __syncthreads();
-      for (int e = tid; e < g * m * CB * CB; e += CHOLB_THREADS) {
-        const int b = e >> 8, ii = (e >> 4) & 15, jj = e & 15;
-        const int kk = b / m, i = b - kk * m;
-        S[b * CBS + ii * CLD + jj] = W[cs_blk(j + i, k0 + kk) + ii * CB + jj];
+      if (tid < g * m) { const int kk = tid / m, i = tid - kk * m; s_src[tid] = (int)cs_blk(j + i, k0 + kk); }
+      __syncthreads();
+      {
+        // eight loads in flight per thread before the first LDS store: one L2 round trip per batch, not per element
+        const int tot = g * m * CB * CB;
+        for (int e0 = tid; e0 < tot; e0 += 8 * CHOLB_THREADS) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * CHOLB_THREADS;
+            v[u] = (e < tot) ? W[s_src[e >> 8] + (e & 255)] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * CHOLB_THREADS;
+            if (e < tot) S[(e >> 8) * CBS + ((e >> 4) & 15) * CLD + (e & 15)] = v[u];
+          }
+        }
       }
       __syncthreads();
       for (int i = wid; i < m; i += NW) {
@@ -417,22 +469,47 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_stream(
         Mfma<double>::acc_t acc;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) acc[rg] = Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)];
-        for (int kk = 0; kk < g; ++kk) {
-          const double* Pa = S + (kk * m + i) * CBS + (lane & 15) * CLD + (lane >> 4);
-          const double* Pb = S + (kk * m) * CBS + (lane & 15) * CLD + (lane >> 4);
+        // two independent accumulation chains (even / odd staged columns): the operand reads of one pair are in
+        // flight while the other pair's MFMAs issue, and the dependent-MFMA latency is halved
+        Mfma<double>::acc_t acc1 = {0, 0, 0, 0};
+        const int po = (lane & 15) * CLD + (lane >> 4);
+        int kk = 0;
+        for (; kk + 1 < g; kk += 2) {
+          const double* Pa0 = S + (kk * m + i) * CBS + po;
+          const double* Pb0 = S + (kk * m) * CBS + po;
+          const double* Pa1 = S + ((kk + 1) * m + i) * CBS + po;
+          const double* Pb1 = S + ((kk + 1) * m) * CBS + po;
+          double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) { a0[ks] = Pa0[4 * ks]; b0[ks] = Pb0[4 * ks]; a1[ks] = Pa1[4 * ks]; b1[ks] = Pb1[4 * ks]; }
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            acc = Mfma<double>::mma(-a0[ks], b0[ks], acc);
+            acc1 = Mfma<double>::mma(-a1[ks], b1[ks], acc1);
+          }
+        }
+        if (kk < g) {
+          const double* Pa = S + (kk * m + i) * CBS + po;
+          const double* Pb = S + (kk * m) * CBS + po;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) acc = Mfma<double>::mma(-Pa[4 * ks], Pb[4 * ks], acc);
         }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[rg] += acc1[rg];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg];
       }
     }
     __syncthreads();
+    lap(0);
+    // behind the staging loads in program order (vmcnt is in-order), ahead of factor + solve + write-back
+    if (j + 1 < nb) fetch_panel(j + 1);
     // (3) diagonal tile -> Linv^T
     if (wid == 0) {
       if (!chol16_wave(P)) { if (lane == 0) s_fail = 1; }
     }
-    __syncthreads();
+    lds_barrier();
+    lap(1);
     if (s_fail) break;
     // (4) panel solve (MFMA) and forward substitution of the rhs block
     for (int i = 1 + wid; i < m; i += NW) chol_panel_block(P + i * CBS, P);
@@ -446,7 +523,8 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_stream(
       __builtin_amdgcn_wave_barrier();
       if (part == 0) s_y[j * CB + i] = x;
     }
-    __syncthreads();
+    lds_barrier();
+    lap(2);
     // rhs tail and write-back of the finished column
     for (int t = tid; t < (m - 1) * CB; t += CHOLB_THREADS) {
       const double* row = P + (1 + (t >> 4)) * CBS + (t & 15) * CLD;
@@ -459,20 +537,20 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_stream(
       const int i = e >> 8, ii = (e >> 4) & 15, jj = e & 15;
       W[cs_blk(j + i, j) + ii * CB + jj] = P[i * CBS + ii * CLD + jj];
     }
-    __threadfence();
+    // read back only by this workgroup: the barrier's workgroup-scope release is all the ordering it needs
     __syncthreads();
+    lap(3);
   }
   __syncthreads();
   const bool fail = s_fail != 0;
   // back substitution, left-looking: x_b = Linv_b^T ( y_b - sum_{r>b} L(r,b)^T x_r ), column b streamed from W
   if (!fail) {
+    fetch_column(nb - 1);
     for (int b = nb - 1; b >= 0; --b) {
       const int m = nb - b;
-      for (int e = tid; e < m * CB * CB; e += CHOLB_THREADS) {
-        const int i = e >> 8, ii = (e >> 4) & 15, jj = e & 15;
-        S[i * CBS + ii * CLD + jj] = W[cs_blk(b + i, b) + ii * CB + jj];
-      }
+      commit(S, m);
       __syncthreads();
+      if (b > 0) fetch_column(b - 1);
       {
         const int jcol = tid & 15, part = tid >> 4;          // 32 parts over the (m-1)*16 rows below the diagonal block
         double s0 = 0;
@@ -502,6 +580,8 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_stream(
       __syncthreads();
     }
   }
+  lap(4);
+  if (dbg && tid == 0) { for (int k = 0; k < 5; ++k) dbg[k] = ph[k]; }
   for (int i = tid; i < n; i += CHOLB_THREADS) sol[i] = fail ? 0.0 : s_y[i];
   if (tid == 0) *info = fail ? 1 : 0;
 }
