@@ -198,11 +198,19 @@ def main():
             # heaviest streaming or MFMA kernel instead and list these in kernel_us
             dominant = max(("schur", "linearize_cams", "linearize_points", "backsub"), key=lambda k: kt[k])
         if dominant == "schur":
-            flops = (n * (n + 1) / 2) * 3 * shard["pts"].shape[0] * 2          # symmetric S: n(n+1)/2 entries x K=3N x 2
+            Nloc = shard["pts"].shape[0]
+            flops_mfma = (n * (n + 1) / 2) * 3 * Nloc * 2                      # symmetric S: n(n+1)/2 entries x K=3N x 2
+            # the fused kernel also carries the whole linearisation on the VALU; on gfx950 f32 VALU and f32 MFMA share
+            # the SIMD issue (tools/micro/mix_rate.hip: their times add) and have the same 157.3 TF peak, so its
+            # algorithmic flops (60 residual + 330 Jacobian + 480 block accumulation per observation,
+            # 50 + 198 C per point for the 3x3 factor and Y = W V^-1) sit under the same roof
+            flops_valu = (870.0 * M_local + (50.0 + 198.0 * C) * Nloc) if fused else 0.0
+            flops = flops_mfma + flops_valu
             ach = flops / (kt["schur"] * 1e-6) / 1e12
             roof = {"kernel": "k_schur_fused" if fused else ("k_schur_sym" if a.dtype == "f64" else "k_schur"), "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[a.dtype],
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype], "traffic": traffic("schur_fused" if fused else "schur"),
-                    "algorithmic_flops_per_launch": flops, "launch_us": kt["schur"]}
+                    "algorithmic_flops_per_launch": flops, "mfma_flops": flops_mfma, "valu_flops": flops_valu,
+                    "mfma_only_frac": flops_mfma / (kt["schur"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS[a.dtype], "launch_us": kt["schur"]}
         else:
             by = algorithmic_bytes_per_obs(dominant, s, C, shard["pts"].shape[0], M_local) * M_local
             ach = by / (kt[dominant] * 1e-6) / 1e9
