@@ -189,15 +189,18 @@ struct Engine : EngineBase {
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) HIPCHK(hipEventCreate(&pev[k][j]));
     d_state.alloc(1);
     // kernels whose dynamic LDS can exceed the 64 KB default
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_sym<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    // only the Schur flavours this dtype launches are instantiated (f32: producer/consumer + fused; f64: symmetric + PARTIAL)
+    auto big_lds = [&](const void* fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); };
+    if constexpr (SCHUR_SYM<T>) {
+      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, false>)));
+      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, false, false>)));
+      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, true>)));
+      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, false, true>)));
+    } else {
+      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, true, false>)));
+      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, false, false>)));
+      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
+    }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -445,8 +448,10 @@ struct Engine : EngineBase {
     // a camera count that is not a multiple of 16 leaves the last group's panel mostly empty: the PARTIAL
     // instantiations skip the MFMAs of empty tiles (kept apart so that the full-group kernels pay nothing for it)
     // (f64 only: the f32 consumers are paced by their producers and lose more to the per-tile branches than they save)
-    if (C % GROUP_CAMS != 0 && SCHUR_SYM<T>) launch_schur_kernels<true>();
-    else launch_schur_kernels<false>();
+    if constexpr (SCHUR_SYM<T>) {
+      if (C % GROUP_CAMS != 0) { launch_schur_kernels<true>(); return; }
+    }
+    launch_schur_kernels<false>();
   }
   template <bool PARTIAL> void launch_schur_kernels() {
     using CfgD = SchurSel<T, true>;
@@ -470,7 +475,7 @@ struct Engine : EngineBase {
                            has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
                            pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
       return;
-    }
+    } else {
     hipLaunchKernelGGL((k_schur<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
                        stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
                        pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,
@@ -489,6 +494,7 @@ struct Engine : EngineBase {
                          CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
                          has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
                          pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
+    }
   }
   // dense visibility with one camera group: the row-reduction kernel (any dtype); its partial rows are per workgroup
   bool backsub_dense() const { return dense_one_group; }
