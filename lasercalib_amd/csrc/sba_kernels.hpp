@@ -10,6 +10,8 @@
 //       accumulation with no cross-lane traffic.
 //   parameters: cams (C x 11, f64 master), pts (N x 3, f64 master) + T-typed shadow of the points,
 //       CamPre table (C x 25, T) rebuilt by k_cam_prep whenever the cameras change.
+//   dense rigs (every camera sees every point once) are stored in canonical order, observation (p, c) at p*C + c: with
+//       <= 16 cameras a 16-lane DPP row then holds all observations of one point and lane % 16 is the camera.
 //
 // wavefront = 64 everywhere; workgroup sizes are multiples of 64.
 #pragma once
@@ -465,10 +467,14 @@ __global__ void k_point_factor(const double* __restrict__ V, const double* __res
 //       the [K = 3*PTS][176] panel of the camera group(s), plus z = L^-1 g_p for the right-hand side;
 //   consumer waves: rhs += panel^T z, then 16x16x4 MFMAs accumulate panel products into their output tiles.
 // Partials go to slabs; k_build_exchange sums them in a fixed order (deterministic, no atomics).
-//   DIAG  (ga == gb): one panel, 66 upper-triangular tiles over 4 consumer waves  (grid = (ksplit, ngroups))
-//   !DIAG (ga <  gb): two panels, 121 tiles over 8 consumer waves                (grid = (ksplit, npairs - ngroups))
+//   DIAG  (ga == gb): one panel, 66 upper-triangular tiles   (grid = (ksplit, ngroups, TS))
+//   !DIAG (ga <  gb): two panels, 121 tiles                  (grid = (ksplit, npairs - ngroups, TS))
+//   The tiles of a pair are dealt to TS workgroups (grid.z) so that a consumer wave never holds more than ~72 accumulator
+//   VGPRs; every workgroup of a split still builds the whole panel.
 //   slab layout: [pair][ks][tile (121 slots)][reg 4][lane 64]   (acc type T)
 //   bpart layout: [ga][ks][176] doubles (only diagonal pairs contribute)
+// Flavours: k_schur (f32: 4 producer + 4 consumer waves), k_schur_sym (f64: all 8 waves produce, then all 8 consume),
+// k_schur_fused (f32, dense visibility, one group: the linearisation rides in the producers) -- see DESIGN.md 4.
 constexpr int SCHUR_THREADS = 512;                           // 4 producer waves + 4 consumer waves
 template <typename T, bool DIAG> struct SchurCfg {
   using elem = T;
