@@ -107,6 +107,9 @@ struct Engine : EngineBase {
   bool dense = false;                // every point is observed by every camera exactly once
   bool dense_one_group = false;      // dense and <= 16 cameras: lane = (point, camera) kernels apply
   int nbs_dense = 1;                 // workgroups of k_backsub_dense
+  bool fused_masked = false;         // the fused kernel runs with the visibility mask
+  bool masked_ok = false;            // one group, no duplicate (point, camera) pairs, not dense: visibility mask available
+  DevBuf<uint16_t> vis_mask;
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
   DevBuf<double> gdpart;
   std::vector<int64_t> perm;          // pm position -> caller's observation index
@@ -250,22 +253,31 @@ struct Engine : EngineBase {
       std::vector<int32_t> fill(ptstart.begin(), ptstart.end() - 1);
       for (int64_t i = 0; i < M; ++i) perm[fill[pi_h[i]]++] = i;
     }
-    if (dense) {
-      // dense = every camera sees every point exactly once; put the observations of a point in camera order
-      // (observation (p, c) at p*C + c), which is what get_points3d.py:78-86 emits anyway
+    // One camera group: put the observations of every point in camera order (what get_points3d.py:78-86 emits anyway) and
+    // record which cameras see it.  Without duplicate (point, camera) pairs the lane = (point, camera) kernels apply:
+    // dense = every camera sees every point (observation (p, c) at p*C + c), else through the visibility mask.
+    std::vector<uint16_t> vmask;
+    bool nodup = (C <= GROUP_CAMS);
+    if (nodup) {
+      vmask.assign(N, 0);
       std::vector<int64_t> slot(C);
-      for (int p = 0; p < N && dense; ++p) {
+      for (int p = 0; p < N && nodup; ++p) {
         std::fill(slot.begin(), slot.end(), (int64_t)-1);
-        for (int k = 0; k < C; ++k) {
-          const int64_t i = perm[(size_t)p * C + k];
-          if (slot[ci_h[i]] >= 0) { dense = false; break; }
+        const int a = ptstart[p], b = ptstart[p + 1];
+        for (int k = a; k < b; ++k) {
+          const int64_t i = perm[k];
+          if (slot[ci_h[i]] >= 0) { nodup = false; break; }
           slot[ci_h[i]] = i;
+          vmask[p] |= (uint16_t)(1u << ci_h[i]);
         }
-        if (!dense) break;
-        for (int k = 0; k < C; ++k)
-          if (perm[(size_t)p * C + k] != slot[k]) { perm[(size_t)p * C + k] = slot[k]; identity_perm = false; }
+        if (!nodup) break;
+        int k = a;
+        for (int c = 0; c < C; ++c)
+          if (slot[c] >= 0) { if (perm[k] != slot[c]) { perm[k] = slot[c]; identity_perm = false; } ++k; }
       }
     }
+    dense = dense && nodup;
+    masked_ok = nodup && !dense;
     has_w = (w_h != nullptr);
     std::vector<T2> uvp(M);
     std::vector<T> wp(has_w ? M : 0);
@@ -355,7 +367,12 @@ struct Engine : EngineBase {
     const int nres_blocks = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
     dense_one_group = dense && C <= GROUP_CAMS && N > 0 && !getenv("SBA_NO_DENSE");
     nbs_dense = std::max(1, std::min((N + 15) / 16, getenv("SBA_BS_WGS") ? atoi(getenv("SBA_BS_WGS")) : (sizeof(T) == 4 ? 768 : 512)));
-    fused_ok = dense_one_group && sizeof(T) == 4 && !getenv("SBA_NO_FUSED");
+    // the fused linearise+Schur kernel also serves sparse one-group rigs through the visibility mask; its producer cost
+    // does not shrink with the number of observations, so below ~35 % visibility the three-pass path is used
+    const bool masked_fused = masked_ok && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
+    fused_ok = (dense_one_group || masked_fused) && sizeof(T) == 4 && !getenv("SBA_NO_FUSED");
+    fused_masked = fused_ok && !dense_one_group;
+    if (fused_masked) vis_mask.upload(vmask, stream);
     if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * GROUP_ROWS);
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1));
     trial_part.alloc((size_t)4 * std::max(nblk, 1));
@@ -429,7 +446,8 @@ struct Engine : EngineBase {
     if constexpr (sizeof(T) == 4) {
       if (fused()) {
         hipLaunchKernelGGL(k_schur_fused, dim3(ksplit), dim3(SCHUR_THREADS), SchurFusedCfg<float>::LDS_BYTES, stream,
-                           ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, N, ksplit, D2p.p, gp.p, pfac.p,
+                           ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
+                           N, ksplit, D2p.p, gp.p, pfac.p,
                            slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p, schur_debug ? schur_dbg.p : nullptr);
         if (schur_debug) {
           std::vector<long long> st(64);

@@ -1030,7 +1030,9 @@ __device__ __forceinline__ bool chol3_inv_fast(const float v[6], float li[6]) {
 
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
     const ParamSets<float> ps, const LMState* __restrict__ st, int C,
-    const float2* __restrict__ uv /* canonical dense order: observation (p, c) at p*C + c */, const float* __restrict__ w,
+    const float2* __restrict__ uv /* observations of a point in camera order; dense rigs: (p, c) at p*C + c */,
+    const float* __restrict__ w, const int32_t* __restrict__ pt_start, const uint16_t* __restrict__ vis /* per point: bit c
+    = camera c sees it; NULL = every camera sees every point */,
     int N, int ksplit, double* __restrict__ D2p, double* __restrict__ gp, float* __restrict__ pf, float* __restrict__ slabs,
     double* __restrict__ bpart, double* __restrict__ gdpart /* [ksplit][2][176]: g_c and diag U_c partials */,
     double* __restrict__ cost_part, double* __restrict__ gmax_part,
@@ -1077,28 +1079,41 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
     T Uacc[UPK];
     static_for<0, UPK>([&](auto kc) { Uacc[decltype(kc)::value] = (T)0; });
     T sq = 0, gmx = 0;
-    // operands of the next chunk, requested one chunk ahead
+    // operands of the next chunk, requested one chunk ahead; with sparse visibility the observation index of lane
+    // (q, c) is pt_start[p] + popcount(vis[p] below bit c), so the point's mask and offset travel two chunks ahead
     float2 n_uv = make_float2(0.f, 0.f);
     T n_w = 1, n_X[3] = {0, 0, 0};
     double n_D[3] = {0, 0, 0};
-    bool n_valid = false;
-    auto request = [&](int chunk) {
+    bool n_valid = false, n_pt = false;
+    unsigned i_mask = 0; int i_start = 0; bool i_pt = false;      // index stage (chunk + 2)
+    auto request_index = [&](int chunk) {
       const int p = pbeg + chunk * PTS + q;
-      n_valid = chunk < nchunk && p < pend && cam_ok;
-      if (n_valid) {
-        const size_t o = (size_t)p * C + c;
-        n_uv = uv[o];
-        n_w = w ? w[o] : (T)1;
+      i_pt = chunk < nchunk && p < pend;
+      i_mask = 0xffffu; i_start = 0;
+      if (i_pt && vis) { i_mask = vis[p]; i_start = pt_start[p]; }
+    };
+    auto request = [&](int chunk) {              // consumes the index stage of `chunk`, then refills it for chunk + 1
+      const int p = pbeg + chunk * PTS + q;
+      n_pt = i_pt;
+      n_valid = i_pt && cam_ok && ((i_mask >> c) & 1u);
+      if (n_pt) {                                // every lane of the row needs the point (row sums are taken by all 16)
         n_X[0] = ptsT[3 * (size_t)p]; n_X[1] = ptsT[3 * (size_t)p + 1]; n_X[2] = ptsT[3 * (size_t)p + 2];
         n_D[0] = D2p[3 * (size_t)p]; n_D[1] = D2p[3 * (size_t)p + 1]; n_D[2] = D2p[3 * (size_t)p + 2];
       }
+      if (n_valid) {
+        const size_t o = vis ? (size_t)i_start + __builtin_popcount(i_mask & ((1u << c) - 1u)) : (size_t)p * C + c;
+        n_uv = uv[o];
+        n_w = w ? w[o] : (T)1;
+      }
+      request_index(chunk + 1);
     };
+    request_index(0);
     request(0);
     for (int it = 0; it <= nchunk; ++it) {
       if (it < nchunk) {
         T* panel = s_buf + (it & 1) * BUF;
         T* s_z = panel + K * GROUP_ROWS;
-        const bool valid = n_valid;
+        const bool valid = n_valid, have_pt = n_pt;
         const float2 m = n_uv;
         const T ww = n_w, X0 = n_X[0], X1 = n_X[1], X2 = n_X[2];
         const double D0 = n_D[0], D1 = n_D[1], D2 = n_D[2];
@@ -1128,7 +1143,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
         T f[PF];
         T li[6];
         T vd[6] = {v6[0] + lam * (T)fmax_pos(E0), v6[1], v6[2], v6[3] + lam * (T)fmax_pos(E1), v6[4], v6[5] + lam * (T)fmax_pos(E2)};
-        const bool okp = valid && chol3_inv_fast(vd, li);
+        const bool okp = have_pt && chol3_inv_fast(vd, li);
 #pragma unroll
         for (int k = 0; k < PF; ++k) f[k] = (T)0;
         if (okp) {
@@ -1139,7 +1154,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
           f[8] = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
           f[9] = (T)1;
         }
-        if (valid && c == 0) {
+        if (have_pt && c == 0) {
           D2p[3 * (size_t)p] = E0; D2p[3 * (size_t)p + 1] = E1; D2p[3 * (size_t)p + 2] = E2;
           gp[3 * (size_t)p] = (double)g3[0]; gp[3 * (size_t)p + 1] = (double)g3[1]; gp[3 * (size_t)p + 2] = (double)g3[2];
           float4* o4 = reinterpret_cast<float4*>(pf + (size_t)p * PF);

@@ -460,12 +460,14 @@ def test_full_size_16x50k_properties(dtype):
 
 
 # ----------------------------------------------------------------------------- dense fast path == general path
-@pytest.mark.parametrize("dtype,C,N,rtol", [("f32", 16, 333, 2e-5), ("f32", 5, 77, 2e-5), ("f64", 16, 333, 1e-9), ("f64", 3, 40, 1e-9)])
-def test_dense_kernels_match_general_kernels(monkeypatch, dtype, C, N, rtol):
-    """Dense visibility with one camera group runs k_schur_fused (f32) / k_backsub_dense; SBA_NO_DENSE forces the
-    general kernels.  Same problem, observation order shuffled (the upload must restore (point, camera) order), with
-    weights: reduced system, trial scalars and the whole solve must agree to rounding."""
-    rig = make_rig(C, N, seed=21)
+@pytest.mark.parametrize("dtype,C,N,vis,rtol", [("f32", 16, 333, 1.0, 2e-5), ("f32", 5, 77, 1.0, 2e-5), ("f64", 16, 333, 1.0, 1e-9),
+                                                 ("f64", 3, 40, 1.0, 1e-9), ("f32", 16, 333, 0.5, 2e-5), ("f32", 9, 120, 0.7, 2e-5)])
+def test_dense_kernels_match_general_kernels(monkeypatch, dtype, C, N, vis, rtol):
+    """One camera group runs k_schur_fused in f32 (dense rigs directly, sparse ones through the per-point visibility
+    mask) and k_backsub_dense on dense rigs; SBA_NO_DENSE forces the general kernels.  Same problem, observation order
+    shuffled (the upload must restore (point, camera) order), with weights: reduced system, trial scalars and the whole
+    solve must agree to rounding."""
+    rig = make_rig(C, N, seed=21, visibility=vis)
     rng = np.random.default_rng(5)
     perm = rng.permutation(rig["camera_ind"].size)
     uv, ci, pi = rig["points_2d"][perm], rig["camera_ind"][perm], rig["point_ind"][perm]

@@ -48,3 +48,6 @@ if __name__ == "__main__":
     run(16, 200, 1.0, "f32")     # dense, one group: fused linearise + Schur kernel
     run(6, 101, 1.0, "f32")
     run(16, 37, 1.0, "f32")
+    run(16, 300, 0.5, "f32")     # sparse, one group: fused kernel through the visibility mask
+    run(12, 150, 0.6, "f32")
+    run(7, 90, 0.4, "f32")
