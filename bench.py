@@ -158,7 +158,7 @@ def main():
             prob.lm_begin(opts)
             done = 0
             while done < iters:
-                for _ in range(min(8, iters - done)):       # 8 steps enqueued between two host polls
+                for _ in range(min(32, iters - done)):      # 32 steps enqueued between two host polls
                     prob.lm_linearize()
                     prob.lm_form_reduced(E.data_ptr())
                     dist.all_reduce(E)
