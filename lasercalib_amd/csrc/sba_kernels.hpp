@@ -495,6 +495,12 @@ template <typename T, bool DIAG> struct SchurCfg {
   static constexpr size_t LDS_BYTES = (size_t)(2 * BUF + 2 * GROUP_CAMS * CAMPRE) * sizeof(T);
 };
 
+// tiles [schur_lo(v), schur_lo(v+1)) of virtual wave v when ntile tiles are dealt to nv waves as evenly as possible
+// (the first ntile % nv waves take one more); waves v and v + 4 share a SIMD, so the larger shares go to v = 0, 1, ...
+__host__ __device__ constexpr int schur_lo(int ntile, int nv, int v) {
+  const int base = ntile / nv, extra = ntile % nv;
+  return v * base + (v < extra ? v : extra);
+}
 // row-major enumeration of a pair's tiles: upper triangle (R <= Tc) for a diagonal pair, all 11x11 otherwise
 __host__ __device__ constexpr int schur_tile_R(bool diag, int t) {
   if (!diag) return t / GROUP_TILES;
@@ -551,7 +557,7 @@ __device__ inline void schur_consume(const typename Cfg::elem* __restrict__ pla 
   using T = typename Cfg::elem;
   using M_ = Mfma<T>;
   constexpr bool DIAG = Cfg::diag;
-  constexpr int LO = V * Cfg::TPW, HI = (LO + Cfg::TPW < Cfg::NTILE) ? LO + Cfg::TPW : Cfg::NTILE;
+  constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
   if constexpr (LO < HI) {
     constexpr int RMIN = schur_tile_R(DIAG, LO), RMAX = schur_tile_R(DIAG, HI - 1);
     T fa[2][GROUP_TILES], fb[2][GROUP_TILES];
@@ -586,7 +592,7 @@ __device__ inline void schur_consume(const typename Cfg::elem* __restrict__ pla 
 template <typename Cfg, int V>
 __device__ inline void schur_store(typename Cfg::elem* __restrict__ slab, int lane,
                                    const typename Mfma<typename Cfg::elem>::acc_t (&acc)[Cfg::TPW]) {
-  constexpr int LO = V * Cfg::TPW, HI = (LO + Cfg::TPW < Cfg::NTILE) ? LO + Cfg::TPW : Cfg::NTILE;
+  constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
 #pragma unroll
   for (int t = LO; t < HI; ++t) {
 #pragma unroll
@@ -1221,7 +1227,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
     static_for<0, Cfg::NV>([&](auto vc) {
       constexpr int V = decltype(vc)::value;
       if (cw == V) {
-        constexpr int T0 = V * TPW, T1 = (T0 + TPW < Cfg::NTILE) ? T0 + TPW : Cfg::NTILE;
+        constexpr int T0 = schur_lo(Cfg::NTILE, Cfg::NV, V), T1 = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
         static_for<T0, T1>([&](auto tc) {
           constexpr int t = decltype(tc)::value;
           constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
