@@ -764,7 +764,7 @@ struct Engine : EngineBase {
     prof_begin(KP_REDUCE);
     {
       const int fc = (int)h_state->free_cams;
-      const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 63) / 64 : 0) + 1;
+      const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 15) / 16 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, npairs, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
                          fused() ? gdpart.p : (const double*)nullptr);

@@ -17,7 +17,7 @@ constexpr int CHOL_LDS_MAX_N = 176;    // packed lower triangle of 176x176 doubl
 //   blocks [0, 4*NT*npairs):   S(i,j) = [same camera] U(i,j) - sum_ks slab      (NT = 121 tile slots per pair)
 //       block = (pair, tile, quarter of the tile's 256 entries); 1024 threads = 16 k-split groups x 64 entries,
 //       group g sums slabs g, g+16, ...; the groups are folded through LDS in a fixed order (deterministic).
-//   blocks [.., +nrow_blocks): rhs = -gc + sum_ks bpart ; diagU ; gc           (64 rows x 4 k-split groups)
+//   blocks [.., +nrow_blocks): rhs = -gc + sum_ks bpart ; diagU ; gc           (16 rows x 64 k-split groups)
 //   last block:                cost = sum cost_part
 template <typename T>
 __global__ __launch_bounds__(1024) void k_build_exchange(
@@ -28,27 +28,29 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     const double* __restrict__ gdpart /* fused linearisation: per-workgroup g_c / diag U partials [ksplit][2][176] (then the
                                           slabs hold Schur partials - U and bpart holds b - g_c); NULL = classic U / gc */) {
   using M_ = Mfma<T>;
-  constexpr int NG = 16;
-  __shared__ double s_p[NG][64];
+  // tiles: 64 entries x 16 k-split groups per block (256-byte segments per group load; 16 entries x 64 groups was
+  // measured slower: 64-byte segments, four times the blocks).  Rows: 16 rows x 64 groups, see below.
+  constexpr int EPB = 64, NG = 1024 / EPB, BPT = 256 / EPB;       // entries per block, groups, blocks per tile
+  __shared__ double s_p[NG][EPB];
   if (st->status >= 0) return;
   __shared__ double scr[16];
   constexpr int NT = GROUP_TILES * GROUP_TILES;
   const int n = C * NCP;
-  const int tile_blocks = free_cams ? 4 * NT * npairs : 0;
-  const int row_blocks = free_cams ? (n + 63) / 64 : 0;
-  const int g = threadIdx.x >> 6, l64 = threadIdx.x & 63;
+  const int tile_blocks = free_cams ? BPT * NT * npairs : 0;
+  const int row_blocks = free_cams ? (n + 15) / 16 : 0;
+  const int g = threadIdx.x / EPB, l16 = threadIdx.x & (EPB - 1);
   int bid = blockIdx.x;
   if (bid < tile_blocks) {
-    const int pair = bid / (4 * NT);
-    const int rem = bid - pair * 4 * NT;
-    const int t = rem >> 2, quarter = rem & 3;
+    const int pair = bid / (BPT * NT);
+    const int rem = bid - pair * BPT * NT;
+    const int t = rem / BPT, part = rem - t * BPT;
     const int ga = pair_ga[pair], gb = pair_gb[pair];
     const bool diag = (ga == gb);
     const int ntile = diag ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : NT;
     if (t >= ntile) return;
     int R, Tc;
     schur_tile_rc(diag, t, R, Tc);
-    const int e = quarter * 64 + l64;                 // entry of the tile's register dump: reg = e>>6, lane = e&63
+    const int e = part * EPB + l16;                   // entry of the tile's register dump: reg = e>>6, lane = e&63
     const int rg = e >> 6, lane = e & 63;
     const int i = ga * GROUP_ROWS + 16 * R + M_::row_of(lane, rg);
     const int j = gb * GROUP_ROWS + 16 * Tc + (lane & 15);
@@ -64,12 +66,12 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     }
     for (; k < ksplit; k += NG) s0 += (double)src[(size_t)k * stride];
     const int ci_ = i / NCP, cj_ = j / NCP;
-    s_p[g][l64] = (s0 + s1) + (s2 + s3);
+    s_p[g][l16] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && i < n && j < n) {
       double s = 0;
 #pragma unroll
-      for (int q = 0; q < NG; ++q) s += s_p[q][l64];
+      for (int q = 0; q < NG; ++q) s += s_p[q][l16];
       double v = -s;                 // fused linearisation: the slabs already hold (Schur partials - U)
       if (!gdpart && ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
       E[(size_t)i * n + j] = v;
@@ -81,57 +83,44 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
   double* rhs = E + (size_t)n * n;
   double* dU = rhs + n;
   double* gv = dU + n;
-  if (bid < row_blocks && gdpart) {
-    // fused linearisation: g_c and diag(U) come from per-workgroup partial rows laid out like bpart
-    __shared__ double s_q[2][NG][64];
-    const int i = bid * 64 + l64;
-    double b0 = 0, b1 = 0, g0 = 0, g1 = 0, d0 = 0, d1 = 0;
-    if (i < n) {
-      const int grp = i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;        // one camera group in this mode: grp == 0
-      const double* src = bpart + (size_t)grp * ksplit * GROUP_ROWS + rho;
-      const double* gs_ = gdpart + rho;
-      int k = g;
-      for (; k + NG < ksplit; k += 2 * NG) {
-        b0 += src[(size_t)k * GROUP_ROWS]; b1 += src[(size_t)(k + NG) * GROUP_ROWS];
-        g0 += gs_[(size_t)k * 2 * GROUP_ROWS]; g1 += gs_[(size_t)(k + NG) * 2 * GROUP_ROWS];
-        d0 += gs_[((size_t)k * 2 + 1) * GROUP_ROWS]; d1 += gs_[((size_t)(k + NG) * 2 + 1) * GROUP_ROWS];
-      }
-      if (k < ksplit) { b0 += src[(size_t)k * GROUP_ROWS]; g0 += gs_[(size_t)k * 2 * GROUP_ROWS]; d0 += gs_[((size_t)k * 2 + 1) * GROUP_ROWS]; }
-    }
-    s_p[g][l64] = b0 + b1; s_q[0][g][l64] = g0 + g1; s_q[1][g][l64] = d0 + d1;
-    __syncthreads();
-    if (g == 0 && i < n) {
-      double bs = 0, gs = 0, dsv = 0;
-#pragma unroll
-      for (int q = 0; q < NG; ++q) { bs += s_p[q][l64]; gs += s_q[0][q][l64]; dsv += s_q[1][q][l64]; }
-      rhs[i] = bs;                   // k_schur_fused stored b - g_c
-      dU[i] = dsv;
-      gv[i] = gs;
-    }
-    return;
-  }
   if (bid < row_blocks) {
-    const int i = bid * 64 + l64;
-    double b = 0;
+    // 16 rows x 64 k-split groups per block: a thread adds at most ksplit/64 partials per array, so the dependent
+    // chain of fabric round trips is 4 long at 256 k-splits (it was 16 with 64 rows x 16 groups)
+    constexpr int RB = 16, RG = 1024 / RB;
+    __shared__ double s_r[3][RG][RB];
+    const int lr = threadIdx.x & (RB - 1), gr = threadIdx.x / RB;
+    const int i = bid * RB + lr;
+    double b0 = 0, g0 = 0, d0 = 0;
     if (i < n) {
       const int grp = i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;
       const double* src = bpart + (size_t)grp * ksplit * GROUP_ROWS + rho;
-      double b0 = 0, b1 = 0;
-      int k = g;
-      for (; k + NG < ksplit; k += 2 * NG) { b0 += src[(size_t)k * GROUP_ROWS]; b1 += src[(size_t)(k + NG) * GROUP_ROWS]; }
-      if (k < ksplit) b0 += src[(size_t)k * GROUP_ROWS];
-      b = b0 + b1;
+      if (gdpart) {        // fused linearisation: g_c and diag(U) are per-workgroup partial rows laid out like bpart (one group)
+        const double* gs_ = gdpart + rho;
+        for (int k = gr; k < ksplit; k += RG) {
+          b0 += src[(size_t)k * GROUP_ROWS];
+          g0 += gs_[(size_t)k * 2 * GROUP_ROWS];
+          d0 += gs_[((size_t)k * 2 + 1) * GROUP_ROWS];
+        }
+      } else {
+        for (int k = gr; k < ksplit; k += RG) b0 += src[(size_t)k * GROUP_ROWS];
+      }
     }
-    s_p[g][l64] = b;
+    s_r[0][gr][lr] = b0; s_r[1][gr][lr] = g0; s_r[2][gr][lr] = d0;
     __syncthreads();
-    if (g == 0 && i < n) {
-      double bs = 0;
-#pragma unroll
-      for (int q = 0; q < NG; ++q) bs += s_p[q][l64];
-      const int c = i / NCP, e = i - c * NCP;
-      rhs[i] = -gc[i] + bs;
-      dU[i] = U[(size_t)c * 121 + e * NCP + e];
-      gv[i] = gc[i];
+    if (gr == 0 && i < n) {
+      double bs = 0, gs = 0, dsv = 0;
+#pragma unroll 8
+      for (int q = 0; q < RG; ++q) { bs += s_r[0][q][lr]; gs += s_r[1][q][lr]; dsv += s_r[2][q][lr]; }
+      if (gdpart) {
+        rhs[i] = bs;                   // k_schur_fused stored b - g_c
+        dU[i] = dsv;
+        gv[i] = gs;
+      } else {
+        const int c = i / NCP, e = i - c * NCP;
+        rhs[i] = -gc[i] + bs;
+        dU[i] = U[(size_t)c * 121 + e * NCP + e];
+        gv[i] = gc[i];
+      }
     }
     return;
   }
