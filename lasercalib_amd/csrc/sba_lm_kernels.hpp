@@ -608,6 +608,16 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* st,
   __shared__ LMState s_st;
   static_assert(sizeof(LMState) % 4 == 0, "LMState is copied word by word");
   constexpr int NWORD = sizeof(LMState) / 4;
+  // the loads of the partials are issued together with the copy of the record (one fabric round trip, not two); they are
+  // harmless when the solve has already terminated
+  double a = 0, b = 0, c = 0, d = 0, g = 0;
+  if (scal_all == nullptr) {
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+      const double t0 = trial_part[i], t1 = trial_part[nblk + i], t2 = trial_part[2 * nblk + i], t3 = trial_part[3 * nblk + i];
+      a += t0; b += t1; c += t2; d += t3;
+    }
+    for (int i = threadIdx.x; i < n_gmax; i += blockDim.x) g = fmax(g, gmax_part[i]);
+  }
   if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
   __syncthreads();
   if (s_st.status >= 0) return;
@@ -615,13 +625,6 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* st,
   st = &s_st;
   double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
   if (scal_all == nullptr) {
-    double a = 0, b = 0, c = 0, d = 0, g = 0;
-    // 1024 threads, all five loads of an index independent: a few rounds of memory latency in total
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
-      const double t0 = trial_part[i], t1 = trial_part[nblk + i], t2 = trial_part[2 * nblk + i], t3 = trial_part[3 * nblk + i];
-      a += t0; b += t1; c += t2; d += t3;
-    }
-    for (int i = threadIdx.x; i < n_gmax; i += blockDim.x) g = fmax(g, gmax_part[i]);
     cost_new = block_sum(a, scr); pred = block_sum(b, scr); dx2 = block_sum(c, scr); x2 = block_sum(d, scr);
     gmax = block_max(g, scr);
     failv = (double)st->chol_fail;
@@ -690,7 +693,8 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* st,
     for (int wd = 0; wd < NWORD; ++wd)
       if (wd != SW) dst[wd] = src[wd];
   }
-  __threadfence();
+  // no fence: every reader of the record (the next kernels of the stream, the host's copy in lm_poll) is ordered after
+  // this kernel by the stream itself
   gst->status = status;
 }
 
