@@ -108,6 +108,7 @@ struct Engine : EngineBase {
   bool dense_one_group = false;      // dense and <= 16 cameras: lane = (point, camera) kernels apply
   int nbs_dense = 1;                 // workgroups of k_backsub_dense
   bool fused_masked = false;         // the fused kernel runs with the visibility mask
+  bool lin_pts_ok = false;           // f64, one group: the point linearisation runs inside k_schur_sym (LIN)
   bool masked_ok = false;            // one group, no duplicate (point, camera) pairs, not dense: visibility mask available
   DevBuf<uint16_t> vis_mask;
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
@@ -199,6 +200,7 @@ struct Engine : EngineBase {
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, false, false>)));
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, true>)));
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, false, true>)));
+      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, false, true>)));
     } else {
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, true, false>)));
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, false, false>)));
@@ -372,7 +374,8 @@ struct Engine : EngineBase {
     const bool masked_fused = masked_ok && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
     fused_ok = (dense_one_group || masked_fused) && sizeof(T) == 4 && !getenv("SBA_NO_FUSED");
     fused_masked = fused_ok && !dense_one_group;
-    if (fused_masked) vis_mask.upload(vmask, stream);
+    lin_pts_ok = (dense_one_group || masked_fused) && SCHUR_SYM<T> && !getenv("SBA_NO_FUSED");
+    if (fused_masked || (lin_pts_ok && !dense_one_group)) vis_mask.upload(vmask, stream);
     if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * GROUP_ROWS);
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1));
     trial_part.alloc((size_t)4 * std::max(nblk, 1));
@@ -441,7 +444,8 @@ struct Engine : EngineBase {
   }
   // the linearisation is folded into the Schur kernel (k_schur_fused) whenever the cameras are free
   bool fused() const { return fused_ok && h_state && h_state->free_cams; }
-  int n_lin_parts() const { return fused() ? ksplit : nblk; }       // entries of cost_part / gmax_part
+  bool lin_pts() const { return lin_pts_ok && h_state && h_state->free_cams; }   // f64: points linearised inside k_schur_sym
+  int n_lin_parts() const { return (fused() || lin_pts()) ? ksplit : nblk; }       // entries of cost_part / gmax_part
   void launch_schur() {
     if constexpr (sizeof(T) == 4) {
       if (fused()) {
@@ -457,6 +461,16 @@ struct Engine : EngineBase {
           for (int i = 0; i < 14; ++i) fprintf(stderr, "  it %2d: P %7lld  C %7lld\n", i, st[2 * i] - st[0], st[2 * i + 1] - st[0]);
           schur_debug = false;
         }
+        return;
+      }
+    }
+    if constexpr (SCHUR_SYM<T>) {
+      if (lin_pts()) {
+        using CfgD = SchurSel<T, true>;
+        hipLaunchKernelGGL((k_schur_sym<T, true, false, true>), dim3(ksplit, 1, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
+                           stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
+                           pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, 1, slabs.p, bpart.p, (long long*)nullptr,
+                           dense_one_group ? (const uint16_t*)nullptr : vis_mask.p, D2p.p, gp.p, cost_part.p, gmax_part.p);
         return;
       }
     }
@@ -742,9 +756,11 @@ struct Engine : EngineBase {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     if (sq_mode()) { launch_sq_linearize(d_state.p); return SBA_OK; }
     if (fused()) return SBA_OK;          // k_schur_fused linearises
-    prof_begin(KP_LINP);
-    launch_linearize_points(d_state.p);
-    prof_end(KP_LINP);
+    if (!lin_pts()) {                    // (f64 one-group rigs: k_schur_sym<LIN> linearises the points)
+      prof_begin(KP_LINP);
+      launch_linearize_points(d_state.p);
+      prof_end(KP_LINP);
+    }
     if (h_state->free_cams) { prof_begin(KP_LINC); launch_linearize_cams(d_state.p); prof_end(KP_LINC); }
     return SBA_OK;
   }

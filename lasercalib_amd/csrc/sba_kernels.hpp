@@ -459,6 +459,51 @@ __global__ void k_point_factor(const double* __restrict__ V, const double* __res
   o[9] = (T)1; o[10] = (T)0; o[11] = (T)0;
 }
 
+// ------------------------------------------------------------------ DPP row reductions (lane = (point, camera) kernels)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, result in every lane: xor 1, xor 2 (quad_perm), then mirror inside 8 and inside 16
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);     // row_half_mirror
+  v += dpp_mov<0x140>(v);     // row_mirror
+  return v;
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+// L^-1 of the 3x3 SPD matrix (v00,v01,v02,v11,v12,v22) with hardware rsq (1 ulp): no sqrt / divide sequences
+__device__ __forceinline__ bool chol3_inv_fast(const float v[6], float li[6]) {
+  if (!(v[0] > 0.f)) return false;
+  const float i00 = __builtin_amdgcn_rsqf(v[0]);
+  const float l10 = v[1] * i00, l20 = v[2] * i00;
+  const float d11 = v[3] - l10 * l10;
+  if (!(d11 > 0.f)) return false;
+  const float i11 = __builtin_amdgcn_rsqf(d11);
+  const float l21 = (v[4] - l20 * l10) * i11;
+  const float d22 = v[5] - l20 * l20 - l21 * l21;
+  if (!(d22 > 0.f)) return false;
+  const float i22 = __builtin_amdgcn_rsqf(d22);
+  li[0] = i00;
+  li[1] = -l10 * i00 * i11;
+  li[2] = i11;
+  li[3] = (-l20 * i00 - l21 * li[1]) * i22;
+  li[4] = -l21 * i11 * i22;
+  li[5] = i22;
+  return isfinite(i22) && isfinite(i11) && isfinite(i00);
+}
+
 // ------------------------------------------------------------------ K4: Schur complement partials (MFMA)
 // Pair (ga, gb), ga <= gb, of camera groups (16 cameras = 176 rows each).  Each workgroup walks its slice of
 // the point list in chunks of PTS points and is split into two roles that overlap through a double-buffered
@@ -831,14 +876,16 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
 }
 
 // ------------------------------------------------------------------ K4 (symmetric): grid = (ksplit, pairs of this kind, TS)
-template <typename T, bool DIAG, bool PARTIAL = false>
+template <typename T, bool DIAG, bool PARTIAL = false, bool LIN = false>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
     const ParamSets<T> ps, const LMState* __restrict__ st, int C,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start, int N,
     const T* __restrict__ pf, const int32_t* __restrict__ pair_ga, const int32_t* __restrict__ pair_gb,
     int pair0, int ksplit, int dense, T* __restrict__ slabs, double* __restrict__ bpart,
-    long long* __restrict__ dbg /* optional cycle stamps of workgroup (0,0,0): [it][produce done, after barrier, consume done] */) {
+    long long* __restrict__ dbg /* optional cycle stamps of workgroup (0,0,0): [it][produce done, after barrier, consume done] */,
+    const uint16_t* __restrict__ vis = nullptr /* LIN: per-point visibility mask, NULL = dense */, double* __restrict__ D2p = nullptr,
+    double* __restrict__ gp = nullptr, double* __restrict__ cost_part = nullptr, double* __restrict__ gmax_part = nullptr) {
   extern __shared__ __align__(16) unsigned char smem[];
   using Cfg = SchurSymCfg<T, DIAG>;
   constexpr int THREADS = Cfg::THREADS, NCW = Cfg::NCW, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K;
@@ -901,8 +948,44 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
       for (int k = 0; k < PF; ++k) cur_f[k] = pf[(size_t)cur_p * PF + k];
     }
   };
+  // LIN (one camera group, no duplicate (point, camera) pairs): lane (q, c) = (point of the 32-point chunk, camera), as
+  // in k_schur_fused -- the point blocks V_p, g_p are DPP row sums, and scaling, damped factor and z follow in
+  // registers, so k_linearize_points and k_point_factor are not launched (f64 keeps k_linearize_cams: 77 f64
+  // accumulators per lane do not fit beside the MFMA tiles).
+  static_assert(!LIN || DIAG, "the fused point linearisation needs the one-group diagonal pair");
+  const int lq = threadIdx.x >> 4, lc = threadIdx.x & 15;
+  const bool cam_ok = lc < C;
+  const double lam = st->lam;
+  double l_sq = 0, l_gmx = 0;
+  T2 n_uv; n_uv.x = n_uv.y = (T)0;
+  T n_w = (T)1, n_X[3] = {0, 0, 0};
+  double n_D[3] = {0, 0, 0};
+  bool n_valid = false, n_pt = false;
+  unsigned i_mask = 0; int i_start = 0; bool i_pt = false;
+  auto request_index = [&](int chunk) {
+    const int p = pbeg + chunk * PTS + lq;
+    i_pt = chunk < nchunk && p < pend;
+    i_mask = 0xffffu; i_start = 0;
+    if (i_pt && vis) { i_mask = vis[p]; i_start = pt_start[p]; }
+  };
+  auto request = [&](int chunk) {
+    const int p = pbeg + chunk * PTS + lq;
+    n_pt = i_pt;
+    n_valid = i_pt && cam_ok && ((i_mask >> lc) & 1u);
+    if (n_pt) {
+      n_X[0] = ptsT[3 * (size_t)p]; n_X[1] = ptsT[3 * (size_t)p + 1]; n_X[2] = ptsT[3 * (size_t)p + 2];
+      n_D[0] = D2p[3 * (size_t)p]; n_D[1] = D2p[3 * (size_t)p + 1]; n_D[2] = D2p[3 * (size_t)p + 2];
+    }
+    if (n_valid) {
+      const size_t o = vis ? (size_t)i_start + __builtin_popcount(i_mask & ((1u << lc) - 1u)) : (size_t)p * C + lc;
+      n_uv = uv[o];
+      n_w = w ? w[o] : (T)1;
+    }
+    request_index(chunk + 1);
+  };
+  if constexpr (LIN) { request_index(0); request(0); }
   // a chunk holds at most PTS*C observations: one per lane only when all cameras are in this one group (32 x 16 = 512)
-  const bool piped = DIAG && (C <= GROUP_CAMS);
+  const bool piped = !LIN && DIAG && (C <= GROUP_CAMS);
   if (piped) {
     load_idx(0, cur_valid, cur_c, cur_p, cur_uv, cur_w);
     load_point();
@@ -912,12 +995,64 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
   for (int it = 0; it < nchunk; ++it) {
     // ---- produce
     const int p0 = pbeg + it * PTS, p1 = min(pend, p0 + PTS);
-    if (dense && p1 - p0 < PTS)          // partial last chunk of a dense problem: clear the rows no observation will write
+    if (!LIN && dense && p1 - p0 < PTS)   // partial last chunk of a dense problem: clear the rows no observation will write
       for (int i = (p1 - p0) * 3 * GROUP_ROWS + threadIdx.x; i < Cfg::NPANEL * K * GROUP_ROWS; i += THREADS) {
         const int rowi = (i % (K * GROUP_ROWS)) / GROUP_ROWS;
         if (rowi >= 3 * (p1 - p0)) panelA[i] = (T)0;
       }
-    if (piped) {
+    if constexpr (LIN) {
+      const bool valid = n_valid, have_pt = n_pt;
+      const T2 m = n_uv;
+      const T ww = n_w, X0 = n_X[0], X1 = n_X[1], X2 = n_X[2];
+      const double D0 = n_D[0], D1 = n_D[1], D2 = n_D[2];
+      const int p = p0 + lq;
+      request(it + 1);
+      T r[2] = {0, 0}, Jc[2][NCP], Jp[2][3];
+#pragma unroll
+      for (int e = 0; e < NCP; ++e) { Jc[0][e] = 0; Jc[1][e] = 0; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { Jp[0][d] = 0; Jp[1][d] = 0; }
+      if (valid) obs_resjac<T>(s_cam + lc * CAMPRE, X0, X1, X2, m.x, m.y, ww, r, Jc, Jp);
+      l_sq += (double)r[0] * r[0] + (double)r[1] * r[1];
+      double v6[6], g3[3];
+      v6[0] = row16_sum((double)(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]));
+      v6[1] = row16_sum((double)(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]));
+      v6[2] = row16_sum((double)(Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2]));
+      v6[3] = row16_sum((double)(Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1]));
+      v6[4] = row16_sum((double)(Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2]));
+      v6[5] = row16_sum((double)(Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2]));
+      g3[0] = row16_sum((double)(Jp[0][0] * r[0] + Jp[1][0] * r[1]));
+      g3[1] = row16_sum((double)(Jp[0][1] * r[0] + Jp[1][1] * r[1]));
+      g3[2] = row16_sum((double)(Jp[0][2] * r[0] + Jp[1][2] * r[1]));
+      l_gmx = fmax(l_gmx, fmax(fabs(g3[0]), fmax(fabs(g3[1]), fabs(g3[2]))));
+      // point scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
+      const double E0 = fmax(D0, v6[0]), E1 = fmax(D1, v6[3]), E2 = fmax(D2, v6[5]);
+      double vd[6] = {v6[0] + lam * fmax_pos(E0), v6[1], v6[2], v6[3] + lam * fmax_pos(E1), v6[4], v6[5] + lam * fmax_pos(E2)};
+      double li[6];
+      const bool okp = have_pt && chol3_inv<double>(vd, li);
+      T f[PF];
+#pragma unroll
+      for (int k = 0; k < PF; ++k) f[k] = (T)0;
+      if (okp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f[k] = (T)li[k];
+        f[6] = (T)(li[0] * g3[0]);
+        f[7] = (T)(li[1] * g3[0] + li[2] * g3[1]);
+        f[8] = (T)(li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2]);
+        f[9] = (T)1;
+      }
+      if (have_pt && lc == 0) {
+        D2p[3 * (size_t)p] = E0; D2p[3 * (size_t)p + 1] = E1; D2p[3 * (size_t)p + 2] = E2;
+        gp[3 * (size_t)p] = g3[0]; gp[3 * (size_t)p + 1] = g3[1]; gp[3 * (size_t)p + 2] = g3[2];
+        T* o = const_cast<T*>(pf) + (size_t)p * PF;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) o[k] = f[k];
+      }
+      if (cam_ok) {
+        schur_emit_block<T>(panelA, lq, lc * NCP, 1, Jc, Jp, f);
+        if (lc == 0) { s_z[3 * lq + 0] = f[6]; s_z[3 * lq + 1] = f[7]; s_z[3 * lq + 2] = f[8]; }
+      }
+    } else if (piped) {
       if (cur_valid)
         schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, cur_c, cur_p - p0, cur_uv.x, cur_uv.y, cur_w,
                             cur_X[0], cur_X[1], cur_X[2], cur_f);
@@ -956,7 +1091,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
     schur_consume_v<Cfg, K, PARTIAL>(vw, panelA + lane_off, panelB + lane_off, acc, usedA, usedB);
     __syncthreads();
     if (stamp) dbg[3 * it + 2] = clock64();
-    if (!dense) {
+    if (!LIN && !dense) {
       // sparse visibility: not every panel entry is rewritten by the next chunk
       for (int i = threadIdx.x; i < Cfg::NPANEL * K * GROUP_ROWS; i += THREADS) panelA[i] = (T)0;
       __syncthreads();
@@ -964,6 +1099,12 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
   }
   T* slab = slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
   schur_store_v<Cfg>(vw, slab, lane, acc);
+  if constexpr (LIN) {
+    __shared__ double s_lin[SCHUR_THREADS / 64];
+    const double cs = block_sum(l_sq, s_lin);
+    const double gm = block_max(l_gmx, s_lin);
+    if (threadIdx.x == 0) { cost_part[blockIdx.x] = 0.5 * cs; gmax_part[blockIdx.x] = gm; }
+  }
   if (DIAG && blockIdx.z == 0) {
     double* s_rhs = reinterpret_cast<double*>(smem);              // the panel is free now
     if (do_rhs && rhs_half == 1) s_rhs[rhs_row] = bacc;
@@ -989,50 +1130,6 @@ constexpr int UPK = NCP * (NCP + 1) / 2 + NCP;                 // 77
 template <typename T> struct SchurFusedCfg : SchurCfg<T, true> {
   static constexpr size_t LDS_BYTES = SchurCfg<T, true>::LDS_BYTES + (size_t)SchurCfg<T, true>::NPROD * UPK * sizeof(T);
 };
-
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-// sum over the 16 lanes of a DPP row, result in every lane: xor 1, xor 2 (quad_perm), then mirror inside 8 and inside 16
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);     // row_half_mirror
-  v += dpp_mov<0x140>(v);     // row_mirror
-  return v;
-}
-template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum(double v) {
-  v += dpp_mov<0xB1>(v);
-  v += dpp_mov<0x4E>(v);
-  v += dpp_mov<0x141>(v);
-  v += dpp_mov<0x140>(v);
-  return v;
-}
-// L^-1 of the 3x3 SPD matrix (v00,v01,v02,v11,v12,v22) with hardware rsq (1 ulp): no sqrt / divide sequences
-__device__ __forceinline__ bool chol3_inv_fast(const float v[6], float li[6]) {
-  if (!(v[0] > 0.f)) return false;
-  const float i00 = __builtin_amdgcn_rsqf(v[0]);
-  const float l10 = v[1] * i00, l20 = v[2] * i00;
-  const float d11 = v[3] - l10 * l10;
-  if (!(d11 > 0.f)) return false;
-  const float i11 = __builtin_amdgcn_rsqf(d11);
-  const float l21 = (v[4] - l20 * l10) * i11;
-  const float d22 = v[5] - l20 * l20 - l21 * l21;
-  if (!(d22 > 0.f)) return false;
-  const float i22 = __builtin_amdgcn_rsqf(d22);
-  li[0] = i00;
-  li[1] = -l10 * i00 * i11;
-  li[2] = i11;
-  li[3] = (-l20 * i00 - l21 * li[1]) * i22;
-  li[4] = -l21 * i11 * i22;
-  li[5] = i22;
-  return isfinite(i22) && isfinite(i11) && isfinite(i00);
-}
 
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
     const ParamSets<float> ps, const LMState* __restrict__ st, int C,
