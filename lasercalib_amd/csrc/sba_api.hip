@@ -67,16 +67,47 @@ struct HipError { hipError_t e; const char* what; int line; };
     if (_e != hipSuccess) throw HipError{_e, #expr, __LINE__};       \
   } while (0)
 
+// Device memory of one handle comes from a few large slabs (bump allocation, released together when the handle dies):
+// a handle owns ~40 buffers, and at ~80 us per hipMalloc / hipFree they used to cost more wall time than the solve.
+struct Arena {
+  struct Slab { char* base; size_t size, used; };
+  std::vector<Slab> slabs;
+  // slab sizes double from 8 MB to 64 MB: few hipMalloc calls (each large one costs milliseconds on this driver, whatever
+  // its size) without grabbing much more than the handle needs
+  size_t next_size = (size_t)8 << 20;
+  void* take(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (auto& sl : slabs)
+      if (sl.size - sl.used >= bytes) { void* p = sl.base + sl.used; sl.used += bytes; return p; }
+    const size_t sz = std::max(bytes, next_size);
+    void* base = nullptr;
+    HIPCHK(hipMalloc(&base, sz));
+    next_size = std::min(next_size * 2, (size_t)64 << 20);
+    slabs.push_back({static_cast<char*>(base), sz, bytes});
+    return base;
+  }
+  ~Arena() { for (auto& sl : slabs) (void)hipFree(sl.base); }
+};
+thread_local Arena* tl_arena = nullptr;      // set for the duration of a call on a handle (ArenaScope)
+struct ArenaScope {
+  Arena* prev;
+  explicit ArenaScope(Arena* a) : prev(tl_arena) { tl_arena = a; }
+  ~ArenaScope() { tl_arena = prev; }
+};
+
 template <typename U>
 struct DevBuf {
   U* p = nullptr;
   size_t n = 0;
+  bool pooled = false;
   void alloc(size_t count) {
     free();
     n = count;
-    if (count) HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(U)));
+    if (!count) return;
+    if (tl_arena) { p = static_cast<U*>(tl_arena->take(count * sizeof(U))); pooled = true; }
+    else HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(U)));
   }
-  void free() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+  void free() { if (p && !pooled) (void)hipFree(p); p = nullptr; pooled = false; n = 0; }
   ~DevBuf() { free(); }
   void upload(const std::vector<U>& h, hipStream_t s) {
     if (h.size() != n) alloc(h.size());
@@ -88,6 +119,7 @@ struct DevBuf {
 struct EngineBase {
   virtual ~EngineBase() {}
   std::string err;
+  Arena arena;       // declared in the base: outlives every DevBuf member of the engine
 };
 
 }  // namespace
@@ -1082,6 +1114,7 @@ namespace {
 
 template <typename F>
 int guarded(sba_handle* h, F&& f) {
+  ArenaScope arena_scope(h && h->eng ? &h->eng->arena : nullptr);    // buffers allocated during the call belong to the handle
   try {
     int rc = f();
     if (rc && h) h->err = h->eng ? h->eng->err : h->err;
@@ -1175,8 +1208,8 @@ int sba_create(const sba_problem_desc* desc, sba_handle** out) {
   auto h = std::make_unique<sba_handle>();
   h->dtype = desc->dtype;
   rc = guarded(nullptr, [&] {
-    if (desc->dtype == SBA_F32) { auto e = std::make_unique<Engine<float>>(); e->init(*desc); h->eng = std::move(e); }
-    else { auto e = std::make_unique<Engine<double>>(); e->init(*desc); h->eng = std::move(e); }
+    if (desc->dtype == SBA_F32) { auto e = std::make_unique<Engine<float>>(); ArenaScope sc(&e->arena); e->init(*desc); h->eng = std::move(e); }
+    else { auto e = std::make_unique<Engine<double>>(); ArenaScope sc(&e->arena); e->init(*desc); h->eng = std::move(e); }
     return (int)SBA_OK;
   });
   if (rc) return rc;
