@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sba_lm_kernels.hpp"
@@ -115,6 +116,16 @@ struct DevBuf {
   }
   void zero(hipStream_t s) { if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(U), s)); }
 };
+
+// host-side layout loops over the observation list: a handful of threads once the list is long enough to pay for them
+template <typename F>
+void par_for(int64_t n, F&& f /* (lo, hi, thread) */) {
+  const int nt = n < 200000 ? 1 : 4;
+  if (nt == 1) { f((int64_t)0, n, 0); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back([&f, n, nt, t] { f(n * t / nt, n * (t + 1) / nt, t); });
+  for (auto& x : th) x.join();
+}
 
 struct EngineBase {
   virtual ~EngineBase() {}
@@ -261,16 +272,37 @@ struct Engine : EngineBase {
   int upload(const double* cams_h, const double* pts_h, const double* uv_h, const int64_t* ci_h,
              const int64_t* pi_h, const double* w_h) {
     HIPCHK(hipSetDevice(device));
+    const bool up_dbg = getenv("SBA_UPLOAD_DEBUG") != nullptr;
+    auto up_t0 = std::chrono::steady_clock::now();
+    auto up_lap = [&](const char* what) {
+      if (!up_dbg) return;
+      const auto t = std::chrono::steady_clock::now();
+      fprintf(stderr, "[upload] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - up_t0).count());
+      up_t0 = t;
+    };
     if (C <= 0 || N < 0 || M < 0) { err = "bad problem size"; return SBA_ERR_INVALID; }
     if (C > 128) { err = "more than 128 cameras is not supported yet"; return SBA_ERR_UNSUPPORTED; }
     if (M > (int64_t)0x7fffffff - 1024) { err = "too many observations for int32 device indices"; return SBA_ERR_UNSUPPORTED; }
-    bool sorted = true;
-    for (int64_t i = 0; i < M; ++i) {
-      if (ci_h[i] < 0 || ci_h[i] >= C || pi_h[i] < 0 || pi_h[i] >= N) {
-        err = "camera/point index out of range at observation " + std::to_string(i);
-        return SBA_ERR_INVALID;
+    // one pass: range check, point-major order, and camera order inside a point (strictly increasing cameras inside every
+    // point = no duplicate (point, camera) pair and already canonical: what get_points3d.py:78-86 emits)
+    bool sorted = true, cam_sorted = true;
+    {
+      int64_t bad[4] = {-1, -1, -1, -1};
+      bool uns[4] = {false, false, false, false}, cuns[4] = {false, false, false, false};
+      par_for(M, [&](int64_t lo, int64_t hi, int t) {
+        for (int64_t i = lo; i < hi; ++i) {
+          if (ci_h[i] < 0 || ci_h[i] >= C || pi_h[i] < 0 || pi_h[i] >= N) { if (bad[t] < 0) bad[t] = i; continue; }
+          if (i) {
+            if (pi_h[i] < pi_h[i - 1]) uns[t] = true;
+            else if (pi_h[i] == pi_h[i - 1] && ci_h[i] <= ci_h[i - 1]) cuns[t] = true;
+          }
+        }
+      });
+      for (int t = 0; t < 4; ++t) {
+        if (bad[t] >= 0) { err = "camera/point index out of range at observation " + std::to_string(bad[t]); return SBA_ERR_INVALID; }
+        sorted = sorted && !uns[t];
+        cam_sorted = cam_sorted && !cuns[t];
       }
-      if (i && pi_h[i] < pi_h[i - 1]) sorted = false;
     }
     // point-major order (stable counting sort by point)
     std::vector<int32_t> ptstart(N + 1, 0);
@@ -282,7 +314,7 @@ struct Engine : EngineBase {
     if (maxdeg > PM_BLOCK) { err = "a point has more than 256 observations"; return SBA_ERR_UNSUPPORTED; }
     perm.resize(M);
     identity_perm = sorted;
-    if (sorted) { for (int64_t i = 0; i < M; ++i) perm[i] = i; }
+    if (sorted) par_for(M, [&](int64_t lo, int64_t hi, int) { for (int64_t i = lo; i < hi; ++i) perm[i] = i; });
     else {
       std::vector<int32_t> fill(ptstart.begin(), ptstart.end() - 1);
       for (int64_t i = 0; i < M; ++i) perm[fill[pi_h[i]]++] = i;
@@ -292,7 +324,10 @@ struct Engine : EngineBase {
     // dense = every camera sees every point (observation (p, c) at p*C + c), else through the visibility mask.
     std::vector<uint16_t> vmask;
     bool nodup = (C <= GROUP_CAMS);
-    if (nodup) {
+    if (nodup && sorted && cam_sorted) {           // already canonical: only the visibility masks are needed
+      vmask.assign(N, 0);
+      for (int64_t i = 0; i < M; ++i) vmask[pi_h[i]] |= (uint16_t)(1u << ci_h[i]);
+    } else if (nodup) {
       vmask.assign(N, 0);
       std::vector<int64_t> slot(C);
       for (int p = 0; p < N && nodup; ++p) {
@@ -312,16 +347,20 @@ struct Engine : EngineBase {
     }
     dense = dense && nodup;
     masked_ok = nodup && !dense;
+    up_lap("validate + sort + canonical");
     has_w = (w_h != nullptr);
     std::vector<T2> uvp(M);
     std::vector<T> wp(has_w ? M : 0);
     std::vector<int32_t> cip(M), pip(M);
-    for (int64_t k = 0; k < M; ++k) {
-      const int64_t i = perm[k];
-      uvp[k].x = (T)uv_h[2 * i]; uvp[k].y = (T)uv_h[2 * i + 1];
-      if (has_w) wp[k] = (T)w_h[i];
-      cip[k] = (int32_t)ci_h[i]; pip[k] = (int32_t)pi_h[i];
-    }
+    par_for(M, [&](int64_t lo, int64_t hi, int) {
+      for (int64_t k = lo; k < hi; ++k) {
+        const int64_t i = perm[k];
+        uvp[k].x = (T)uv_h[2 * i]; uvp[k].y = (T)uv_h[2 * i + 1];
+        if (has_w) wp[k] = (T)w_h[i];
+        cip[k] = (int32_t)ci_h[i]; pip[k] = (int32_t)pi_h[i];
+      }
+    });
+    up_lap("permute observations");
     // point-aligned blocks of <= 256 observations
     std::vector<int32_t> blk;
     blk.push_back(0);
@@ -380,6 +419,7 @@ struct Engine : EngineBase {
       ksplit = std::min(ks, maxks);
     }
 
+    up_lap("blocks + camera-major copies");
     uv_pm.upload(uvp, stream); ci_pm.upload(cip, stream); pi_pm.upload(pip, stream);
     if (has_w) { w_pm.upload(wp, stream); w_cm.upload(wc, stream); }
     pt_start.upload(ptstart, stream); blk_pt.upload(blk, stream); blk_desc.upload(bdesc, stream);
@@ -411,7 +451,9 @@ struct Engine : EngineBase {
     if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * GROUP_ROWS);
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1));
     trial_part.alloc((size_t)4 * std::max(nblk, 1));
+    up_lap("allocations + H2D enqueue");
     sync();   // the staging vectors go out of scope now
+    up_lap("H2D completion");
     uploaded = true;
     cur = 0;
     set_params(cams_h, pts_h);
