@@ -17,45 +17,10 @@
 
 #include "sba_lm_kernels.hpp"
 #include "sba_chol_blocked.hpp"
+#include "sba_chol_big.hpp"
 #include "sba_sq_kernels.hpp"
 
 using namespace sba;
-
-#include <dlfcn.h>
-// rocSOLVER / rocBLAS are bound at run time and only when a camera system is too large for the in-LDS Cholesky
-// (more than 16 cameras): the common path never loads them.
-namespace {
-struct RocSolver {
-  using handle_t = void*;
-  int (*create)(handle_t*) = nullptr;
-  int (*destroy)(handle_t) = nullptr;
-  int (*set_stream)(handle_t, hipStream_t) = nullptr;
-  int (*dpotrf)(handle_t, int /*rocblas_fill*/, int, double*, int, int*) = nullptr;
-  int (*dpotrs)(handle_t, int, int, int, double*, int, double*, int) = nullptr;
-  bool ok = false;
-  std::string why;
-  static RocSolver& get() {
-    static RocSolver r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
-    void* blas = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-    if (!blas) blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    void* sol = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-    if (!sol) sol = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!blas || !sol) { r.why = std::string("cannot load rocBLAS/rocSOLVER: ") + (dlerror() ? dlerror() : "?"); return r; }
-    r.create = reinterpret_cast<decltype(r.create)>(dlsym(blas, "rocblas_create_handle"));
-    r.destroy = reinterpret_cast<decltype(r.destroy)>(dlsym(blas, "rocblas_destroy_handle"));
-    r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(blas, "rocblas_set_stream"));
-    r.dpotrf = reinterpret_cast<decltype(r.dpotrf)>(dlsym(sol, "rocsolver_dpotrf"));
-    r.dpotrs = reinterpret_cast<decltype(r.dpotrs)>(dlsym(sol, "rocsolver_dpotrs"));
-    r.ok = r.create && r.destroy && r.set_stream && r.dpotrf && r.dpotrs;
-    if (!r.ok) r.why = "rocBLAS/rocSOLVER symbols missing";
-    return r;
-  }
-};
-constexpr int ROCBLAS_FILL_UPPER = 121;   // rocblas_fill_upper (column-major upper == our row-major lower)
-}  // namespace
 
 namespace {
 
@@ -183,9 +148,8 @@ struct Engine : EngineBase {
   sba_lm_opts opts{};
   bool lm_active = false;
   bool chol_old = false;
-  void* rs_handle = nullptr;
-  int rocsolver_min_n = 512;
-  DevBuf<double> chol_sol, chol_work;
+  int chol_big_min_n = CS_MAX_NB * CB;      // systems larger than this (47+ cameras) take the multi-workgroup factorisation
+  DevBuf<double> chol_sol, chol_work, chol_W, chol_Minv, chol_Ld, chol_yv;
   DevBuf<int> chol_info;
   bool chol_debug = false;
   bool schur_debug = false;
@@ -217,7 +181,6 @@ struct Engine : EngineBase {
 
   ~Engine() override {
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) if (pev[k][j]) (void)hipEventDestroy(pev[k][j]);
-    if (rs_handle) RocSolver::get().destroy(rs_handle);
     if (h_state) (void)hipHostFree(h_state);
 
     if (ev0) (void)hipEventDestroy(ev0);
@@ -255,7 +218,12 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     if (const char* e = getenv("SBA_CHOL")) chol_old = (std::string(e) == "old");
     if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
-    if (const char* e = getenv("SBA_ROCSOLVER_MIN_N")) rocsolver_min_n = atoi(e);
+    if (const char* e = getenv("SBA_CHOL_BIG_MIN_N")) {      // diagnostic: route smaller systems through the big path too
+      char* end = nullptr;
+      const long v = strtol(e, &end, 10);
+      if (end != e && *end == 0 && v >= 0) chol_big_min_n = (int)std::min<long>(v, CS_MAX_NB * CB);
+    }
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
     if (getenv("SBA_SCHUR_DEBUG")) { schur_debug = true; schur_dbg.alloc(64); schur_dbg.zero(stream); }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -863,6 +831,29 @@ struct Engine : EngineBase {
     return SBA_OK;
   }
 
+  // A = S + lam D (n_sys x n_sys, in E) -> chol_sol = A^-1 rhs, chol_info != 0 when A is not positive definite
+  void launch_chol_big(double* Esys, int n_sys) {
+    const int npad = cholbig_npad(n_sys), nbr = npad / BB, nbx = (n_sys + BB - 1) / BB;
+    if (chol_W.n < (size_t)npad * npad) {
+      chol_W.alloc((size_t)npad * npad); chol_Minv.alloc((size_t)nbr * BB * BB); chol_Ld.alloc((size_t)nbr * BB * BB);
+      chol_yv.alloc(npad);
+    }
+    if (chol_sol.n < (size_t)n_sys) { chol_sol.alloc(n_sys); chol_info.alloc(1); }
+    hipLaunchKernelGGL(k_chol_big_prepare, dim3(nbr * (nbr + 1) / 2), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p,
+                       chol_W.p, npad, chol_info.p);
+    const size_t lds = (size_t)48 * CBS * sizeof(double);
+    for (int j = 0; j < nbr; ++j) {
+      const int q = nbr - 1 - j;
+      hipLaunchKernelGGL(k_chol_big_step, dim3(std::max(1, q * (q + 1) / 2)), dim3(CHOLBIG_THREADS), lds, stream, chol_W.p, npad, j,
+                         chol_Minv.p, chol_Ld.p, chol_info.p, d_state.p);
+    }
+    hipLaunchKernelGGL(k_chol_big_back_init, dim3((npad + 255) / 256), dim3(256), 0, stream, chol_W.p, npad, n_sys, chol_Ld.p,
+                       chol_yv.p, d_state.p);
+    for (int b = nbx - 1; b >= 0; --b)
+      hipLaunchKernelGGL(k_chol_big_back, dim3(b + 1), dim3(256), 0, stream, chol_W.p, npad, b, n_sys, chol_Minv.p, chol_yv.p,
+                         chol_sol.p, d_state.p);
+  }
+
   // scal == nullptr: single rank, the partials are folded inside k_decide and no scalar exchange is needed
   int lm_solve_trial(double* E, double* scal) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
@@ -901,18 +892,9 @@ struct Engine : EngineBase {
         const size_t lds = (size_t)n_sys * (n_sys + 1) / 2 * sizeof(double);
         hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
                            ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
-      } else if (n_sys > rocsolver_min_n && RocSolver::get().ok) {
-        // large systems (default: more than 512 unknowns, i.e. 47+ cameras): library potrf/potrs between our prepare /
-        // epilogue kernels.  Below that the single-workgroup global-memory kernel is used: slower per call, but it
-        // spares small jobs the one-off load of the rocBLAS/rocSOLVER code objects (tens of seconds on a cold machine).
-        RocSolver& rs = RocSolver::get();
-        if (!rs_handle) { if (rs.create(&rs_handle) != 0) { err = "rocblas_create_handle failed"; return SBA_ERR_HIP; } rs.set_stream(rs_handle, stream); }
-        if (chol_sol.n < (size_t)n_sys) { chol_sol.alloc(n_sys); chol_info.alloc(1); }
-        hipLaunchKernelGGL(k_chol_prepare, dim3((n_sys + 255) / 256), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p, chol_sol.p);
-        if (rs.dpotrf(rs_handle, ROCBLAS_FILL_UPPER, n_sys, Esys, n_sys, chol_info.p) != 0 ||
-            rs.dpotrs(rs_handle, ROCBLAS_FILL_UPPER, n_sys, 1, Esys, n_sys, chol_sol.p, n_sys) != 0) {
-          err = "rocsolver potrf/potrs failed"; return SBA_ERR_HIP;
-        }
+      } else if (n_sys > chol_big_min_n && !chol_old) {
+        // 47+ cameras: multi-workgroup right-looking factorisation, one launch per 64-wide block column (sba_chol_big.hpp)
+        launch_chol_big(Esys, n_sys);
         hipLaunchKernelGGL(k_chol_epilogue<T>, dim3(1), dim3(1024), 0, stream, Esys, C, n_sys, d_state.p, D2c.p, ps_lm(), delta_c.p,
                            chol_sol.p, chol_info.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       } else if (n_sys <= CS_MAX_NB * CB && !chol_old) {

@@ -1,0 +1,120 @@
+"""GPU parity at BASELINE configs 4/5 camera counts (47 .. 128 cameras: group pairs + the multi-workgroup Cholesky of
+csrc/sba_chol_big.hpp; 11*C > 512 unknowns in the reduced camera system).
+
+Small-N cases are checked against the reference oracle (oracle/sba_oracle.py = scipy least_squares with the reference's
+arguments, pySBA.py:141) and, iteration for iteration, against the numpy model of the device algorithm; the per-GPU shares
+of configs 4 and 5 on 8 GPUs (64 x 25,000 and 128 x 125,000) are covered by size-independent properties.
+
+Tolerances: these rigs have few observations per camera (gauge-free, weakly conditioned), where scipy's TRF step stops on
+ftol = 1e-4 well above the minimum (observed 0.1 - 5 % above the device's).  Parity vs scipy is therefore one-sided, like
+tests/test_gpu_parity.py::test_tight_solve_is_an_optimum_the_reference_accepts: the device cost must not exceed the
+reference's, must stay in the same basin, and scipy restarted FROM the device solution must not lower it by more than that stopping tolerance (ftol = 1e-4 relative).
+Against the numpy model the bound is rounding: cost 1e-8 relative (fp64).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from lasercalib_amd import _native  # noqa: E402
+from lasercalib_amd.synth import make_rig  # noqa: E402
+from oracle import lm_schur_model as model  # noqa: E402
+from oracle import sba_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert _native.device_count() > 0, "no HIP device visible: GPU tests must run on the MI355X box"
+
+
+def _solve(rig, ftol, dtype="f64", **kw):
+    with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], dtype=dtype) as prob:
+        return prob.solve_lm(prob.make_opts(ftol=ftol, **kw))
+
+
+CASES = [(47, 60, 0.3), (64, 80, 0.25), (128, 100, 0.15)]
+
+
+@pytest.mark.parametrize("C,N,vis", CASES)
+def test_large_rigs_follow_the_numpy_model(C, N, vis):
+    """Device trajectory = numpy-model trajectory (same iteration count, same cost to rounding): the reduced system of
+    517 / 704 / 1408 unknowns goes through k_chol_big_prepare / _step / _back."""
+    rig = make_rig(C, N, seed=8, visibility=vis)
+    cams, pts, rep, log = _solve(rig, 1e-6)
+    eng = model.ModelEngine(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    out = model.run_lm_single(eng, ftol=1e-6)
+    assert rep.iterations == out["iterations"] and rep.nfev == out["nfev"] and rep.status == out["status"]
+    assert abs(rep.cost - out["cost"]) <= 1e-8 * out["cost"]
+    assert np.allclose(cams, out["cams"], rtol=1e-4, atol=1e-3) and np.allclose(pts, out["pts"], rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("C,N,vis", CASES)
+def test_large_rigs_vs_reference_oracle(C, N, vis, dtype):
+    rig = make_rig(C, N, seed=8, visibility=vis)
+    args = (rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    ref, _, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], *args, ftol=1e-4)
+    cams, pts, rep, _ = _solve(rig, 1e-4, dtype)
+    assert rep.status in (2, 3, 4)
+    cost64 = 0.5 * np.sum(orc.fun(np.hstack((cams.ravel(), pts.ravel())), C, N, rig["camera_ind"], rig["point_ind"],
+                                  rig["points_2d"], 1.0) ** 2)
+    assert abs(cost64 - rep.cost) <= (1e-9 if dtype == "f64" else 1e-4) * cost64       # reported cost = oracle's cost at x
+    assert cost64 <= ref.cost * (1 + 1e-6) and cost64 >= 0.9 * ref.cost               # never above scipy, same basin
+    again, _, _ = orc.bundle_adjust(cams, pts, *args, ftol=1e-4, max_nfev=10)
+    # scipy cannot lower it by more than the stopping tolerance (fp32: plus the 1e-4 fp32 cost bar of SURVEY 8d, observed 1.2e-4)
+    assert again.cost >= cost64 * (1 - (1e-4 if dtype == "f64" else 3e-4))
+    rms = orc.rms_reprojection(cams, pts, *args)
+    rms_ref = np.sqrt(2 * ref.cost / rig["camera_ind"].size)
+    assert rms <= rms_ref + 1e-6
+
+
+@pytest.mark.parametrize("C,N,vis", [(17, 64, 1.0), (32, 120, 0.5), (46, 90, 0.4)])
+def test_big_cholesky_equals_streamed_cholesky(monkeypatch, C, N, vis):
+    """SBA_CHOL_BIG_MIN_N=0 routes the 176 < n <= 512 systems (which default to the one-workgroup streamed kernel)
+    through the multi-workgroup factorisation as well: same trajectory, same answer (rhs row inside / at the start of
+    a 64-block: n = 187, 352, 506)."""
+    rig = make_rig(C, N, seed=8, visibility=vis)
+    monkeypatch.delenv("SBA_CHOL_BIG_MIN_N", raising=False)
+    c0, p0, r0, _ = _solve(rig, 1e-6)
+    monkeypatch.setenv("SBA_CHOL_BIG_MIN_N", "0")
+    c1, p1, r1, _ = _solve(rig, 1e-6)
+    assert r0.iterations == r1.iterations and r0.status == r1.status
+    assert abs(r0.cost - r1.cost) <= 1e-10 * r0.cost
+    # two summation orders of the same factorisation: the cost agrees to 1e-10, but nothing fixes the 7-DoF similarity gauge
+    # (pySBA.py:138), along which rounding differences drift freely (observed 7e-5 mm on a translation): same bound as
+    # tests/test_gpu_parity.py::test_more_than_16_cameras_uses_camera_groups
+    assert np.allclose(c0, c1, rtol=1e-4, atol=1e-3) and np.allclose(p0, p1, rtol=1e-4, atol=1e-3)
+
+
+def test_indefinite_big_system_is_a_rejected_step_not_a_crash():
+    """A camera no observation constrains (all-zero rows in S) with zero damping: the factorisation must flag it, the LM
+    loop raises the damping and carries on."""
+    rig = make_rig(48, 70, seed=3, visibility=0.3)
+    keep = rig["camera_ind"] != 5
+    with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"][keep], rig["camera_ind"][keep], rig["point_ind"][keep]) as prob:
+        cams, pts, rep, log = prob.solve_lm(prob.make_opts(ftol=1e-6))
+    assert rep.status in (2, 3, 4) and np.all(np.isfinite(cams)) and np.all(np.isfinite(pts))
+    assert np.array_equal(cams[5], rig["cams0"][5])         # zero gradient, unit scale: the camera never moves
+
+
+@pytest.mark.parametrize("C,N", [(64, 25000), (128, 125000)])
+def test_per_gpu_shares_of_configs_4_and_5(C, N):
+    """fp32, full visibility: one GPU's share of BASELINE config 4 (64 x 200k / 8) and config 5 (128 x 1M / 8, radial model)."""
+    rig = make_rig(C, N, seed=0)
+    M = rig["camera_ind"].size
+    with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], dtype="f32") as prob:
+        r0, c0 = prob.residual()
+        cams, pts, rep, log = prob.solve_lm(prob.make_opts(ftol=1e-4))
+        r1, c1 = prob.residual(np.hstack((cams.ravel(), pts.ravel())))
+    idx = np.random.default_rng(0).choice(M, 5000, replace=False)
+    ref = orc.project(rig["pts0"][rig["point_ind"][idx]], rig["cams0"][rig["camera_ind"][idx]]) - rig["points_2d"][idx]
+    assert np.max(np.abs(r0.reshape(-1, 2)[idx] - ref)) <= 5e-3
+    assert rep.status == 2 and rep.cost < 1e-3 * c0
+    costs = [row.cost for row in log if row.accepted]
+    assert all(b <= a for a, b in zip(costs, costs[1:]))
+    assert abs(c1 - rep.cost) <= 1e-4 * c1
+    rms = np.sqrt(np.mean(np.sum(r1.reshape(-1, 2) ** 2, axis=1)))
+    assert 0.38 < rms < 0.45                                  # 0.3 px noise per axis
+    _, ratios = orc.gauge_invariants(cams)
+    _, ratios_t = orc.gauge_invariants(rig["cams_true"])
+    assert np.max(np.abs(ratios - ratios_t)) <= 1e-3
