@@ -332,9 +332,10 @@ class ModelEngine:
         self.optimality = gmax
         self.step_norm = np.sqrt(dx2)
         self.cost_trial = cost_new
-        if gmax < gtol:
+        if gmax < gtol:                 # scipy tests this before taking a step (trf.py:452): the trial does not count
             self.accepted = False
             self.actual = self.rho = 0.0
+            self.nfev -= 1
             return 1
         ok = (not fail) and np.isfinite(cost_new) and pred > 0
         actual = self.cost - cost_new if ok else -1.0

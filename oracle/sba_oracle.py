@@ -93,8 +93,9 @@ def split_params(x, n_cams, n_pts):
 
 # --------------------------------------------------------------------------- solvers
 def bundle_adjust(cams, pts, uv, cam_ind, pt_ind, weights=None, ftol=1e-4, verbose=0,
-                  max_nfev=None):
-    """Full BA exactly as pySBA.py:132-147 drives scipy.  Returns (res, cams_opt, pts_opt)."""
+                  max_nfev=None, **lsq_kw):
+    """Full BA exactly as pySBA.py:132-147 drives scipy.  Returns (res, cams_opt, pts_opt).
+    lsq_kw: extra least_squares keywords the reference leaves at their defaults (xtol, gtol: the LM-control tests set them)."""
     if weights is None:
         weights = default_weights(pt_ind)
     C, N = cams.shape[0], pts.shape[0]
@@ -102,7 +103,7 @@ def bundle_adjust(cams, pts, uv, cam_ind, pt_ind, weights=None, ftol=1e-4, verbo
     A = sparsity(C, N, cam_ind, pt_ind)
     res = least_squares(fun, x0, jac_sparsity=A, verbose=verbose, x_scale="jac", ftol=ftol,
                         method="trf", jac="3-point", max_nfev=max_nfev,
-                        args=(C, N, cam_ind, pt_ind, uv, weights))
+                        args=(C, N, cam_ind, pt_ind, uv, weights), **lsq_kw)
     c_opt, p_opt = split_params(res.x, C, N)
     return res, c_opt, p_opt
 

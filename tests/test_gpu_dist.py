@@ -91,4 +91,4 @@ def test_sharded_gpu_solve_two_ranks_f32_fused_path():
         cams, pts, rep, _ = prob.solve_lm(prob.make_opts(ftol=1e-4))
     assert abs(rep.cost - r0[2]) <= 1e-4 * rep.cost          # fp32: the shards sum in a different order
     ref = float(g[f"{tag}_loose_cost"])
-    assert abs(r0[2] - ref) <= 1e-3 * ref
+    assert abs(r0[2] - ref) <= 1e-4 * ref                     # fp32 bar of SURVEY 8(d)

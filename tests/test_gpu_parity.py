@@ -34,15 +34,28 @@ def _problem(rig, dtype="f64", weights=None, cams=None, pts=None):
 
 
 # ----------------------------------------------------------------------------- F1: rotate / project
-@pytest.mark.parametrize("dtype,tol_rot,tol_uv", [("f64", 1e-9, 1e-7), ("f32", 2e-3, 0.5)])
-def test_project_rotate_golden(golden, dtype, tol_rot, tol_uv):
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_project_rotate_golden(golden, dtype):
     g = golden("f1_project.npz")
     rot = _native.rotate_rows(g["points"], g["cam_rows"][:, :3], dtype=dtype)
     uv = _native.project_rows(g["points"], g["cam_rows"], dtype=dtype)
-    assert np.max(np.abs(rot - g["rotated"])) <= tol_rot
-    # rows 128:160 put points a few cm from the camera (huge pixel values); compare relatively there
-    scale = np.maximum(1.0, np.abs(g["projected"]) / 1e3)
-    assert np.max(np.abs(uv - g["projected"]) / scale) <= tol_uv
+    near = slice(128, 160)       # rows that put points a few cm from the camera: pixel values up to 1e10, compared relatively
+    far = np.r_[0:128, 160:g["points"].shape[0]]
+    if dtype == "f64":
+        assert np.max(np.abs(rot - g["rotated"])) <= 1e-9
+        scale = np.maximum(1.0, np.abs(g["projected"]) / 1e3)
+        assert np.max(np.abs(uv - g["projected"]) / scale) <= 1e-7
+        return
+    # fp32: a-priori rounding bound, 4 eps32 (|uv| + f cond^2) per row with cond = |p| / p_z of the camera-frame point
+    # (observed: at most 1.0 of the un-multiplied bound, 5e-4 px), coordinates up to 1.7e3 mm for the rotation
+    eps = float(np.finfo(np.float32).eps)
+    assert np.max(np.abs(rot - g["rotated"])) <= 4 * eps * 1.7e3
+    pc = g["rotated"] + g["cam_rows"][:, 3:6]
+    cond = np.linalg.norm(pc, axis=1) / np.abs(pc[:, 2])
+    bound = 4 * eps * (np.max(np.abs(g["projected"]), axis=1) + g["cam_rows"][:, 6] * cond * cond)
+    err = np.max(np.abs(uv - g["projected"]), axis=1)
+    assert np.all(err[far] <= bound[far]) and np.max(err[far]) <= 3e-3
+    assert np.max(np.abs(uv[near] - g["projected"][near]) / np.maximum(1.0, np.abs(g["projected"][near]))) <= 0.5
 
 
 def test_project_theta_zero_is_identity():
@@ -275,7 +288,11 @@ def test_config2_scipy_drives_device_residual_and_jacobian():
     # same optimiser, same stopping rule; the Jacobians differ by the FD truncation error only
     assert res.status == ref.status and abs(res.nfev - ref.nfev) <= 1
     assert abs(res.cost - ref.cost) <= 1e-6 * ref.cost
-    assert np.max(np.abs(res.x - ref.x)) <= 5e-2      # px / mm; LSMR amplifies the FD-vs-analytic Jacobian difference along weak directions
+    # parameter bounds of SURVEY 8(d) at ftol = 1e-4, per block (LSMR amplifies the FD-vs-analytic Jacobian difference along
+    # weak directions; observed: rotvec 6e-6, t 1.2e-2 mm, f 9e-3 px, k 4e-6, centre 1.5e-2 px, points 6e-4 mm)
+    dc = np.abs(res.x[:C * 11] - ref.x[:C * 11]).reshape(C, 11).max(axis=0)
+    assert np.all(dc[0:3] <= 5e-5) and np.all(dc[3:6] <= 0.05) and dc[6] <= 0.05 and np.all(dc[7:9] <= 1e-4) and np.all(dc[9:11] <= 0.05)
+    assert np.max(np.abs(res.x[C * 11:] - ref.x[C * 11:])) <= 0.02
 
 
 # ----------------------------------------------------------------------------- class surface end to end
@@ -427,7 +444,7 @@ def test_more_than_16_cameras_f32():
     cams, pts, rep, _ = prob.solve_lm(prob.make_opts(ftol=1e-4))
     prob.close()
     ref, _, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], ftol=1e-4)
-    assert rep.status in (2, 3, 4) and abs(rep.cost - ref.cost) <= 2e-3 * ref.cost
+    assert rep.status in (2, 3, 4) and abs(rep.cost - ref.cost) <= 1e-4 * ref.cost       # fp32 bar of SURVEY 8(d); observed 4e-6
 
 
 # ----------------------------------------------------------------------------- full size (BASELINE config 3) properties
@@ -505,6 +522,12 @@ def test_dense_kernels_match_general_kernels(monkeypatch, dtype, C, N, vis, rtol
         assert np.max(np.abs(Ed[a:b] - Eg[a:b])) <= rtol * max(np.abs(Eg[a:b]).max(), 1.0)
     assert np.allclose(sd[:4], sg[:4], rtol=50 * rtol, atol=1e-6)      # trial cost, predicted reduction, |dx|^2, |x|^2
     assert rd.status == rg_.status or {rd.status, rg_.status} <= {2, 3, 4}
-    # f64 solves stop at ftol=1e-8 and must agree tightly.  f32 ones stop at ftol=1e-4, where the two rounding
-    # histories may end one crawling LM step apart on these small, gauge-free rigs (observed 0.7 %): 2 % bound
-    assert abs(rd.cost - rg_.cost) <= (1e-7 if dtype == "f64" else 2e-2) * rg_.cost
+    # f64 solves stop at ftol=1e-8 and must agree tightly.  f32 ones stop at ftol=1e-4, where the two rounding histories
+    # may end one crawling LM step apart on these small, gauge-free rigs (observed 0.7 % between them), so each fp32 solve is
+    # held to the fp32 bar against the REFERENCE instead: at least as converged as scipy at the same ftol (1e-4 relative)
+    if dtype == "f64":
+        assert abs(rd.cost - rg_.cost) <= 1e-7 * rg_.cost
+    else:
+        ref, _, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], uv, ci, pi, weights=wts.reshape(-1, 1), ftol=1e-4)
+        assert rd.cost <= ref.cost * (1 + 1e-4) and rg_.cost <= ref.cost * (1 + 1e-4)
+        assert min(rd.cost, rg_.cost) >= 0.9 * ref.cost
