@@ -13,7 +13,8 @@
  * whatever dtype the device computes in.
  *
  * Camera row layout (11 doubles): [rotvec(3), t(3), f, k1, k2, cx, cy]      (pySBA.py:31-35)
- * Parameter vector x:  [cams.ravel() (11*C), points.ravel() (3*N)]           (pySBA.py:138)
+ *   (13 doubles with SBA_CAM_RADIAL_TANGENTIAL: [rotvec(3), t(3), f, k1, k2, p1, p2, cx, cy]; P below = 11 or 13)
+ * Parameter vector x:  [cams.ravel() (P*C), points.ravel() (3*N)]            (pySBA.py:138)
  * Residual vector:     interleaved [u0,v0,u1,v1,...] in the caller's observation order (pySBA.py:101)
  */
 #ifndef SBA_HIP_H
@@ -25,8 +26,16 @@
 extern "C" {
 #endif
 
-#define SBA_ABI_VERSION 1
-#define SBA_CAM_PARAMS 11
+#define SBA_ABI_VERSION 2
+#define SBA_CAM_PARAMS 11            /* the reference's camera row (pySBA.py:31-35)                      */
+#define SBA_CAM_PARAMS_TANGENTIAL 13 /* [rvec(3), t(3), f, k1, k2, p1, p2, cx, cy]: extension, see below */
+
+/* Camera model of a handle.  SBA_CAM_RADIAL is the reference's (pySBA.py:76-89: one focal length, two radial terms).
+ * SBA_CAM_RADIAL_TANGENTIAL adds the two tangential (decentering) coefficients p1, p2 in OpenCV's convention
+ *   x' = x d + 2 p1 x y + p2 (r2 + 2 x^2),  y' = y d + p1 (r2 + 2 y^2) + 2 p2 x y,  d = 1 + k1 r2 + k2 r2^2
+ * -- BASELINE.json configs[4]; the reference itself has no tangential term (its exporter writes zeros for p1, p2,
+ * lasercalib/convert_params.py:110), so this model is an extension that cannot be pinned to reference output. */
+typedef enum { SBA_CAM_RADIAL = 0, SBA_CAM_RADIAL_TANGENTIAL = 1 } sba_cam_model;
 
 typedef enum {
   SBA_OK = 0,
@@ -66,7 +75,8 @@ typedef struct {
                             1: run on `stream` exactly as given -- NULL then means the legacy default
                                stream (what torch.cuda.current_stream() is unless the caller changed it),
                                so that the caller's collectives are ordered with the engine's kernels */
-  int32_t reserved[3];
+  int32_t cam_model;     /* sba_cam_model: 0 = 11-parameter rows (the reference), 1 = 13-parameter rows            */
+  int32_t reserved[2];
 } sba_problem_desc;
 
 typedef struct {
@@ -118,6 +128,9 @@ int sba_rotate(int device, int dtype, int64_t n, const double* points /*n*3*/,
                const double* rot_vecs /*n*3*/, double* out /*n*3*/);
 int sba_project(int device, int dtype, int64_t n, const double* points /*n*3*/,
                 const double* cam_rows /*n*11*/, double* uv_out /*n*2*/);
+/* the same for either camera model: cam_rows is n x 11 (SBA_CAM_RADIAL) or n x 13 (SBA_CAM_RADIAL_TANGENTIAL) */
+int sba_project_model(int device, int dtype, int cam_model, int64_t n, const double* points /*n*3*/,
+                      const double* cam_rows /*n*(11|13)*/, double* uv_out /*n*2*/);
 
 /* ---------------------------------------------------------------- problem handle
  * sba_create/sba_upload <-> PySBA.__init__ state (pySBA.py:28-59): observation list + initial x.

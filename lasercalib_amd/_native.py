@@ -15,12 +15,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsba_hip.so")
 
 SBA_F64, SBA_F32 = 0, 1
+CAM_RADIAL, CAM_RADIAL_TANGENTIAL = 0, 1        # sba_cam_model: 11 / 13 parameters per camera
 MODE_FULL, MODE_POINTS_ONLY, MODE_SHARED_INTR, MODE_CAMS_ONLY_SQ, MODE_TRANSFORM_SQ = 0, 1, 2, 3, 4
 NSCALARS = 8
 
 # every symbol include/sba_hip.h declares (tests/test_cabi_symbols.py checks the .so exports all of them)
 EXPORTED_SYMBOLS = (
-    "sba_abi_version", "sba_device_count", "sba_last_error", "sba_rotate", "sba_project",
+    "sba_abi_version", "sba_device_count", "sba_last_error", "sba_rotate", "sba_project", "sba_project_model",
     "sba_create", "sba_upload", "sba_set_params", "sba_get_params", "sba_destroy",
     "sba_get_gradient", "sba_get_transform", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
@@ -35,7 +36,7 @@ class SbaError(RuntimeError):
 class ProblemDesc(C.Structure):
     _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int64),
                 ("dtype", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
-                ("use_stream", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("use_stream", C.c_int32), ("cam_model", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class LmOpts(C.Structure):
@@ -104,6 +105,7 @@ def load():
         "sba_last_error": (C.c_char_p, [H]),
         "sba_rotate": (C.c_int, [C.c_int, C.c_int, C.c_int64, dp, dp, dp]),
         "sba_project": (C.c_int, [C.c_int, C.c_int, C.c_int64, dp, dp, dp]),
+        "sba_project_model": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, dp, dp, dp]),
         "sba_create": (C.c_int, [C.POINTER(ProblemDesc), C.POINTER(H)]),
         "sba_upload": (C.c_int, [H, dp, dp, dp, ip, ip, dp]),
         "sba_set_params": (C.c_int, [H, dp]),
@@ -133,7 +135,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.sba_abi_version() != 1:
+    if lib.sba_abi_version() != 2:
         raise SbaError("libsba_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -174,14 +176,23 @@ def device_count():
     return int(load().sba_device_count())
 
 
+def cam_model_of(n_cam_params):
+    """11 columns = the reference's radial camera row (pySBA.py:31-35), 13 = radial + tangential (p1, p2 before cx, cy)."""
+    if n_cam_params == 11:
+        return CAM_RADIAL
+    if n_cam_params == 13:
+        return CAM_RADIAL_TANGENTIAL
+    raise ValueError("camera rows must have 11 columns (radial model) or 13 (radial + tangential)")
+
+
 def project_rows(points, cam_rows, dtype=SBA_F64, device=0):
     """PySBA.project on gathered rows (pySBA.py:76-89), computed on the GPU."""
     lib = load()
     p, c = _f64(points), _f64(cam_rows)
-    if p.ndim != 2 or p.shape[1] != 3 or c.ndim != 2 or c.shape[1] != 11 or p.shape[0] != c.shape[0]:
-        raise ValueError("project expects (M,3) points and (M,11) camera rows")
+    if p.ndim != 2 or p.shape[1] != 3 or c.ndim != 2 or c.shape[1] not in (11, 13) or p.shape[0] != c.shape[0]:
+        raise ValueError("project expects (M,3) points and (M,11) camera rows ((M,13) with tangential distortion)")
     out = np.empty((p.shape[0], 2))
-    _check(lib.sba_project(device, dtype_code(dtype), p.shape[0], _dptr(p), _dptr(c), _dptr(out)))
+    _check(lib.sba_project_model(device, dtype_code(dtype), cam_model_of(c.shape[1]), p.shape[0], _dptr(p), _dptr(c), _dptr(out)))
     return out
 
 
@@ -207,8 +218,9 @@ class Problem:
         ci = np.ascontiguousarray(cam_idx, dtype=np.int64).reshape(-1)
         pi = np.ascontiguousarray(pt_idx, dtype=np.int64).reshape(-1)
         self.C, self.N, self.M = self.cams0.shape[0], self.pts0.shape[0], ci.shape[0]
-        if self.cams0.ndim != 2 or self.cams0.shape[1] != 11:
-            raise ValueError("cameraArray must have shape (n_cameras, 11)")
+        if self.cams0.ndim != 2 or self.cams0.shape[1] not in (11, 13):
+            raise ValueError("cameraArray must have shape (n_cameras, 11) (or (n_cameras, 13) with tangential distortion)")
+        self.P = self.cams0.shape[1]
         if self.pts0.ndim != 2 or self.pts0.shape[1] != 3:
             raise ValueError("points3D must have shape (n_points, 3)")
         if uv.shape != (self.M, 2) or pi.shape[0] != self.M:
@@ -221,7 +233,8 @@ class Problem:
         self.dtype = dtype_code(dtype)
         # stream=None: private stream.  stream=<int handle>: run on it (0 = the legacy default stream).
         desc = ProblemDesc(self.C, self.N, self.M, self.dtype, device,
-                           C.c_void_p(stream) if stream else None, 0 if stream is None else 1, (C.c_int32 * 3)())
+                           C.c_void_p(stream) if stream else None, 0 if stream is None else 1, cam_model_of(self.P),
+                           (C.c_int32 * 2)())
         h = C.c_void_p()
         _check(lib.sba_create(C.byref(desc), C.byref(h)))
         self._h = h
@@ -251,7 +264,7 @@ class Problem:
 
     @property
     def n_params(self):
-        return 11 * self.C + 3 * self.N
+        return self.P * self.C + 3 * self.N
 
     # -- model evaluation
     def residual(self, x=None, want_r=True):
@@ -263,7 +276,7 @@ class Problem:
 
     def residual_jacobian(self, x=None):
         r = np.empty(2 * self.M)
-        Jc = np.empty((self.M, 2, 11))
+        Jc = np.empty((self.M, 2, self.P))
         Jp = np.empty((self.M, 2, 3))
         xx = None if x is None else _f64(x)
         _check(self._lib.sba_residual_jacobian(self._h, _dptr(xx), _dptr(r), _dptr(Jc), _dptr(Jp)), self._h)
@@ -273,13 +286,13 @@ class Problem:
         _check(self._lib.sba_set_params(self._h, _dptr(_f64(x))), self._h)
 
     def get_params(self):
-        cams = np.empty((self.C, 11))
+        cams = np.empty((self.C, self.P))
         pts = np.empty((self.N, 3))
         _check(self._lib.sba_get_params(self._h, _dptr(cams), _dptr(pts)), self._h)
         return cams, pts
 
     def get_gradient(self):
-        gc = np.empty((self.C, 11))
+        gc = np.empty((self.C, self.P))
         gp = np.empty((self.N, 3))
         _check(self._lib.sba_get_gradient(self._h, _dptr(gc), _dptr(gp)), self._h)
         return gc, gp
@@ -297,7 +310,7 @@ class Problem:
                       1 if always_relinearize else 0, float(lambda0), (C.c_int32 * 4)(1 if profile else 0, 0, 0, 0))
 
     def solve_lm(self, opts, log_capacity=4096):
-        cams = np.empty((self.C, 11))
+        cams = np.empty((self.C, self.P))
         pts = np.empty((self.N, 3))
         rep = LmReport()
         log = (LmIterLog * log_capacity)()
@@ -338,7 +351,7 @@ class Problem:
         return status.value, iters.value
 
     def lm_finish(self):
-        cams = np.empty((self.C, 11))
+        cams = np.empty((self.C, self.P))
         pts = np.empty((self.N, 3))
         rep = LmReport()
         _check(self._lib.sba_lm_finish(self._h, _dptr(cams), _dptr(pts), C.byref(rep)), self._h)

@@ -96,27 +96,35 @@ def write_opencv_yaml(path: str, nodes: Dict[str, object]) -> None:
         f.write("\n".join(lines) + "\n")
 
 
-def initialize_from_checkerboard(filedir: str, nCams: int, cam_names: Sequence[str]) -> np.ndarray:
+def initialize_from_checkerboard(filedir: str, nCams: int, cam_names: Sequence[str], tangential: bool = False) -> np.ndarray:
     """(nCams, 11) initial ``cameraArray`` from per-camera OpenCV YAML files (convert_params.py:66-87).
 
     Row = [rotvec(rc_ext) (3), tc_ext (3), K[0,0], dist[0], dist[1], K[0,2], K[1,2]].
+    tangential=True (extension, the reference drops these two): (nCams, 13) rows that also carry OpenCV's p1, p2 =
+    dist[2], dist[3] before the principal point -- the camera model PySBA switches to for 13-column arrays.
     """
     rows = []
     for name in list(cam_names)[:nCams]:
         node = read_opencv_yaml(os.path.join(filedir, f"{name}.yaml"))
         K, dist = node["camera_matrix"], node["distortion_coefficients"].ravel()
+        tang = [dist[2] if dist.size > 2 else 0.0, dist[3] if dist.size > 3 else 0.0] if tangential else []
         rows.append(np.concatenate([
             R.from_matrix(node["rc_ext"]).as_rotvec(), node["tc_ext"].ravel()[:3],
-            [K[0, 0], dist[0], dist[1], K[0, 2], K[1, 2]],
+            [K[0, 0], dist[0], dist[1]], tang, [K[0, 2], K[1, 2]],
         ]))
-    return np.asarray(rows, dtype=np.float64).reshape(nCams, 11)
+    return np.asarray(rows, dtype=np.float64).reshape(nCams, 13 if tangential else 11)
 
 
 def sba_to_readable_format(camParamVec: np.ndarray) -> Dict[str, np.ndarray]:
-    """One ``cameraArray`` row -> {'K','R','t','d'} (convert_params.py:18-27); ``t`` and ``d`` are views, like upstream."""
-    f, cx, cy = camParamVec[6], camParamVec[9], camParamVec[10]
+    """One ``cameraArray`` row -> {'K','R','t','d'} (convert_params.py:18-27); ``t`` and ``d`` are views, like upstream.
+    A 13-parameter row (tangential model) also yields 'p' = (p1, p2); an 11-parameter row gives exactly upstream's dict."""
+    tang = len(camParamVec) == 13
+    f, cx, cy = camParamVec[6], camParamVec[-2], camParamVec[-1]
     K = np.array([[f, 0.0, 0.0], [0.0, f, 0.0], [cx, cy, 1.0]])          # transposed intrinsic matrix (see module doc)
-    return {"K": K, "R": R.from_rotvec(-camParamVec[:3]).as_matrix(), "t": camParamVec[3:6], "d": camParamVec[7:9]}
+    out = {"K": K, "R": R.from_rotvec(-camParamVec[:3]).as_matrix(), "t": camParamVec[3:6], "d": camParamVec[7:9]}
+    if tang:
+        out["p"] = camParamVec[9:11]
+    return out
 
 
 def camera_array_to_readable(cameraArray: np.ndarray) -> List[Dict[str, np.ndarray]]:
@@ -125,23 +133,26 @@ def camera_array_to_readable(cameraArray: np.ndarray) -> List[Dict[str, np.ndarr
 
 
 def readable_to_red_format(camList: Sequence[Dict[str, np.ndarray]]) -> np.ndarray:
-    """(len(camList), 25) table [K^T (9) | R^T (9) | t (3) | d (2), 0, 0] (convert_params.py:7-16)."""
+    """(len(camList), 25) table [K^T (9) | R^T (9) | t (3) | d (2), 0, 0] (convert_params.py:7-16); the two zeros are
+    the tangential slots and receive p1, p2 when the camera dict has them."""
     out = np.full((len(camList), 25), np.nan)
     for row, p in zip(out, camList):
         row[0:9] = np.asarray(p["K"]).T.ravel()
         row[9:18] = np.asarray(p["R"]).T.ravel()
         row[18:21] = p["t"]
         row[21:23] = p["d"]
-        row[23:25] = 0.0
+        row[23:25] = p.get("p", (0.0, 0.0))
     return out
 
 
 def readable_format_to_aruco_format(save_root: str, nCams: int, camList, cam_names: Sequence[str]) -> None:
-    """Write one OpenCV YAML per camera (convert_params.py:105-113): camera_matrix = K^T, rc_ext = R^T, 5 distortion terms."""
+    """Write one OpenCV YAML per camera (convert_params.py:105-113): camera_matrix = K^T, rc_ext = R^T, 5 distortion terms
+    [k1, k2, p1, p2, k3 = 0] in OpenCV's order; upstream writes zeros for p1, p2 (its model has none, line 110), here they
+    are exported when the camera came from a 13-parameter row."""
     for i in range(nCams):
         write_opencv_yaml(save_root + "{}.yaml".format(cam_names[i]), {
             "camera_matrix": camList[i]["K"].T,
-            "distortion_coefficients": np.asarray([camList[i]["d"][0], camList[i]["d"][1], 0, 0, 0]),
+            "distortion_coefficients": np.asarray([camList[i]["d"][0], camList[i]["d"][1], *camList[i].get("p", (0, 0)), 0]),
             "rc_ext": camList[i]["R"].T,
             "tc_ext": camList[i]["t"],
         })

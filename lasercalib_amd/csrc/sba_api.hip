@@ -1,1131 +1,15 @@
-// sba_api.hip -- C ABI (include/sba_hip.h) over the HIP kernels.  gfx950 only; no CPU fallback:
+// sba_api.hip -- C ABI (include/sba_hip.h) over the per-camera-model engines.  gfx950 only; no CPU fallback:
 // every entry point fails with SBA_ERR_NO_DEVICE / SBA_ERR_HIP when the GPU is not usable.
-#include "../../include/sba_hip.h"
+#include "sba_common.hpp"
 
-#include <hip/hip_runtime.h>
+using namespace sba_host;
 
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "sba_lm_kernels.hpp"
-#include "sba_chol_blocked.hpp"
-#include "sba_chol_big.hpp"
-#include "sba_sq_kernels.hpp"
-
-using namespace sba;
-
-namespace {
-
-thread_local std::string g_last_error;
-
-struct HipError { hipError_t e; const char* what; int line; };
-#define HIPCHK(expr)                                                 \
-  do {                                                               \
-    hipError_t _e = (expr);                                          \
-    if (_e != hipSuccess) throw HipError{_e, #expr, __LINE__};       \
-  } while (0)
-
-// Device memory of one handle comes from a few large slabs (bump allocation, released together when the handle dies):
-// a handle owns ~40 buffers, and at ~80 us per hipMalloc / hipFree they used to cost more wall time than the solve.
-struct Arena {
-  struct Slab { char* base; size_t size, used; };
-  std::vector<Slab> slabs;
-  // slab sizes double from 8 MB to 64 MB: few hipMalloc calls (each large one costs milliseconds on this driver, whatever
-  // its size) without grabbing much more than the handle needs
-  size_t next_size = (size_t)8 << 20;
-  void* take(size_t bytes) {
-    bytes = (bytes + 255) & ~(size_t)255;
-    for (auto& sl : slabs)
-      if (sl.size - sl.used >= bytes) { void* p = sl.base + sl.used; sl.used += bytes; return p; }
-    const size_t sz = std::max(bytes, next_size);
-    void* base = nullptr;
-    HIPCHK(hipMalloc(&base, sz));
-    next_size = std::min(next_size * 2, (size_t)64 << 20);
-    slabs.push_back({static_cast<char*>(base), sz, bytes});
-    return base;
-  }
-  ~Arena() { for (auto& sl : slabs) (void)hipFree(sl.base); }
-};
-thread_local Arena* tl_arena = nullptr;      // set for the duration of a call on a handle (ArenaScope)
-struct ArenaScope {
-  Arena* prev;
-  explicit ArenaScope(Arena* a) : prev(tl_arena) { tl_arena = a; }
-  ~ArenaScope() { tl_arena = prev; }
-};
-
-template <typename U>
-struct DevBuf {
-  U* p = nullptr;
-  size_t n = 0;
-  bool pooled = false;
-  void alloc(size_t count) {
-    free();
-    n = count;
-    if (!count) return;
-    if (tl_arena) { p = static_cast<U*>(tl_arena->take(count * sizeof(U))); pooled = true; }
-    else HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(U)));
-  }
-  void free() { if (p && !pooled) (void)hipFree(p); p = nullptr; pooled = false; n = 0; }
-  ~DevBuf() { free(); }
-  void upload(const std::vector<U>& h, hipStream_t s) {
-    if (h.size() != n) alloc(h.size());
-    if (n) HIPCHK(hipMemcpyAsync(p, h.data(), n * sizeof(U), hipMemcpyHostToDevice, s));
-  }
-  void zero(hipStream_t s) { if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(U), s)); }
-};
-
-// host-side layout loops over the observation list: a handful of threads once the list is long enough to pay for them
-template <typename F>
-void par_for(int64_t n, F&& f /* (lo, hi, thread) */) {
-  const int nt = n < 200000 ? 1 : 4;
-  if (nt == 1) { f((int64_t)0, n, 0); return; }
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t) th.emplace_back([&f, n, nt, t] { f(n * t / nt, n * (t + 1) / nt, t); });
-  for (auto& x : th) x.join();
-}
-
-struct EngineBase {
-  virtual ~EngineBase() {}
-  std::string err;
-  Arena arena;       // declared in the base: outlives every DevBuf member of the engine
-};
-
-}  // namespace
-
-// ============================================================================================== engine
-template <typename T>
-struct Engine : EngineBase {
-  using T2 = typename Vec2<T>::type;
-  int C = 0, N = 0;
-  int64_t M = 0;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  bool uploaded = false;
-  bool has_w = false;
-  bool identity_perm = true;
-  bool dense = false;                // every point is observed by every camera exactly once
-  bool dense_one_group = false;      // dense and <= 16 cameras: lane = (point, camera) kernels apply
-  int nbs_dense = 1;                 // workgroups of k_backsub_dense
-  bool fused_masked = false;         // the fused kernel runs with the visibility mask
-  bool lin_pts_ok = false;           // f64, one group: the point linearisation runs inside k_schur_sym (LIN)
-  bool masked_ok = false;            // one group, no duplicate (point, camera) pairs, not dense: visibility mask available
-  DevBuf<uint16_t> vis_mask;
-  bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
-  DevBuf<double> gdpart;
-  std::vector<int64_t> perm;          // pm position -> caller's observation index
-  int nblk = 0, nchunk = 0, ngroups = 0, npairs = 0, ksplit = 1;
-  int n = 0;                          // 11*C
-
-  // static problem data
-  DevBuf<T2> uv_pm, uv_cm;
-  DevBuf<T> w_pm, w_cm;
-  DevBuf<int32_t> ci_pm, pi_pm, pt_start, blk_pt, pi_cm, chunk_cam, chunk_begin, chunk_end, cam_chunk_start;
-  DevBuf<int32_t> pair_ga, pair_gb;
-  DevBuf<int4> blk_desc;
-  // parameters (double-buffered: cur / trial)
-  DevBuf<double> cams[2], pts[2];
-  DevBuf<T> ptsT[2], campre[2];
-  int cur = 0;
-  // linearization + LM work space
-  DevBuf<double> V, gp, D2p, D2c, U, gc, Upart, bpart, E_own, scal_own, delta_c, cost_part, gmax_part, trial_part;
-  DevBuf<T> slabs, pfac;
-  DevBuf<T2> r_pm;
-  DevBuf<T> Jc_pm, Jp_pm;
-  DevBuf<LMState> d_state;
-  DevBuf<sba_lm_iter_log> d_log;
-  int log_read = 0;
-  int cur_at_begin = 0;
-  LMState* h_state = nullptr;         // pinned
-  sba_lm_opts opts{};
-  bool lm_active = false;
-  bool chol_old = false;
-  int chol_big_min_n = CS_MAX_NB * CB;      // systems larger than this (47+ cameras) take the multi-workgroup factorisation
-  DevBuf<double> chol_sol, chol_work, chol_W, chol_Minv, chol_Ld, chol_yv;
-  DevBuf<int> chol_info;
-  bool chol_debug = false;
-  bool schur_debug = false;
-  DevBuf<long long> schur_dbg;
-  DevBuf<long long> chol_dbg;
-  double initial_cost = 0;
-  std::vector<sba_lm_iter_log> log;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // in-loop kernel timing (opts.reserved[0] != 0): one HIP event pair per kernel class per LM iteration
-  enum { KP_LINP = 0, KP_LINC, KP_SCHUR, KP_REDUCE, KP_CHOL, KP_BACKSUB, KP_N };
-  hipEvent_t pev[KP_N][2] = {};
-  bool pev_used[KP_N] = {};
-  bool prof_on = false;
-  double prof_us[KP_N] = {};
-  long long prof_cnt[KP_N] = {};
-  int pslot = 0;
-  void pslot_advance() {}
-  void prof_begin(int k) { if (prof_on) HIPCHK(hipEventRecord(pev[k][0], stream)); }
-  void prof_end(int k) { if (prof_on) { HIPCHK(hipEventRecord(pev[k][1], stream)); pev_used[k] = true; } }
-  void prof_collect() {   // call after a stream sync
-    if (!prof_on) return;
-    for (int k = 0; k < KP_N; ++k)
-      if (pev_used[k]) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, pev[k][0], pev[k][1]) == hipSuccess) { prof_us[k] += (double)ms * 1e3; prof_cnt[k]++; }
-        pev_used[k] = false;
-      }
-  }
-
-  ~Engine() override {
-    for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) if (pev[k][j]) (void)hipEventDestroy(pev[k][j]);
-    if (h_state) (void)hipHostFree(h_state);
-
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
-  }
-
-  void init(const sba_problem_desc& d) {
-    C = d.n_cams; N = d.n_points; M = d.n_obs; device = d.device; n = C * NCP;
-    HIPCHK(hipSetDevice(device));
-    if (d.use_stream) { stream = reinterpret_cast<hipStream_t>(d.stream); own_stream = false; }
-    else { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(LMState), hipHostMallocDefault));
-    HIPCHK(hipEventCreate(&ev0));
-    HIPCHK(hipEventCreate(&ev1));
-    for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) HIPCHK(hipEventCreate(&pev[k][j]));
-    d_state.alloc(1);
-    // kernels whose dynamic LDS can exceed the 64 KB default
-    // only the Schur flavours this dtype launches are instantiated (f32: producer/consumer + fused; f64: symmetric + PARTIAL)
-    auto big_lds = [&](const void* fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); };
-    if constexpr (SCHUR_SYM<T>) {
-      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, false>)));
-      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, false, false>)));
-      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, true>)));
-      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, false, true>)));
-      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, false, true>)));
-    } else {
-      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, true, false>)));
-      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, false, false>)));
-      HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
-    }
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    if (const char* e = getenv("SBA_CHOL")) chol_old = (std::string(e) == "old");
-    if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
-    if (const char* e = getenv("SBA_CHOL_BIG_MIN_N")) {      // diagnostic: route smaller systems through the big path too
-      char* end = nullptr;
-      const long v = strtol(e, &end, 10);
-      if (end != e && *end == 0 && v >= 0) chol_big_min_n = (int)std::min<long>(v, CS_MAX_NB * CB);
-    }
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
-    if (getenv("SBA_SCHUR_DEBUG")) { schur_debug = true; schur_dbg.alloc(64); schur_dbg.zero(stream); }
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residual<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_linearize<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_linearize<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_trial<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_trial<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-  }
-
-  void sync() { HIPCHK(hipStreamSynchronize(stream)); }
-
-  // ------------------------------------------------------------------ upload + host-side layout
-  int upload(const double* cams_h, const double* pts_h, const double* uv_h, const int64_t* ci_h,
-             const int64_t* pi_h, const double* w_h) {
-    HIPCHK(hipSetDevice(device));
-    const bool up_dbg = getenv("SBA_UPLOAD_DEBUG") != nullptr;
-    auto up_t0 = std::chrono::steady_clock::now();
-    auto up_lap = [&](const char* what) {
-      if (!up_dbg) return;
-      const auto t = std::chrono::steady_clock::now();
-      fprintf(stderr, "[upload] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - up_t0).count());
-      up_t0 = t;
-    };
-    if (C <= 0 || N < 0 || M < 0) { err = "bad problem size"; return SBA_ERR_INVALID; }
-    if (C > 128) { err = "more than 128 cameras is not supported yet"; return SBA_ERR_UNSUPPORTED; }
-    if (M > (int64_t)0x7fffffff - 1024) { err = "too many observations for int32 device indices"; return SBA_ERR_UNSUPPORTED; }
-    // one pass: range check, point-major order, and camera order inside a point (strictly increasing cameras inside every
-    // point = no duplicate (point, camera) pair and already canonical: what get_points3d.py:78-86 emits)
-    bool sorted = true, cam_sorted = true;
-    {
-      int64_t bad[4] = {-1, -1, -1, -1};
-      bool uns[4] = {false, false, false, false}, cuns[4] = {false, false, false, false};
-      par_for(M, [&](int64_t lo, int64_t hi, int t) {
-        for (int64_t i = lo; i < hi; ++i) {
-          if (ci_h[i] < 0 || ci_h[i] >= C || pi_h[i] < 0 || pi_h[i] >= N) { if (bad[t] < 0) bad[t] = i; continue; }
-          if (i) {
-            if (pi_h[i] < pi_h[i - 1]) uns[t] = true;
-            else if (pi_h[i] == pi_h[i - 1] && ci_h[i] <= ci_h[i - 1]) cuns[t] = true;
-          }
-        }
-      });
-      for (int t = 0; t < 4; ++t) {
-        if (bad[t] >= 0) { err = "camera/point index out of range at observation " + std::to_string(bad[t]); return SBA_ERR_INVALID; }
-        sorted = sorted && !uns[t];
-        cam_sorted = cam_sorted && !cuns[t];
-      }
-    }
-    // point-major order (stable counting sort by point)
-    std::vector<int32_t> ptstart(N + 1, 0);
-    for (int64_t i = 0; i < M; ++i) ptstart[pi_h[i] + 1]++;
-    int maxdeg = 0;
-    for (int p = 0; p < N; ++p) { maxdeg = std::max(maxdeg, ptstart[p + 1]); ptstart[p + 1] += ptstart[p]; }
-    dense = (M == (int64_t)N * C);
-    for (int p = 0; p < N && dense; ++p) dense = (ptstart[p + 1] - ptstart[p] == C);
-    if (maxdeg > PM_BLOCK) { err = "a point has more than 256 observations"; return SBA_ERR_UNSUPPORTED; }
-    perm.resize(M);
-    identity_perm = sorted;
-    if (sorted) par_for(M, [&](int64_t lo, int64_t hi, int) { for (int64_t i = lo; i < hi; ++i) perm[i] = i; });
-    else {
-      std::vector<int32_t> fill(ptstart.begin(), ptstart.end() - 1);
-      for (int64_t i = 0; i < M; ++i) perm[fill[pi_h[i]]++] = i;
-    }
-    // One camera group: put the observations of every point in camera order (what get_points3d.py:78-86 emits anyway) and
-    // record which cameras see it.  Without duplicate (point, camera) pairs the lane = (point, camera) kernels apply:
-    // dense = every camera sees every point (observation (p, c) at p*C + c), else through the visibility mask.
-    std::vector<uint16_t> vmask;
-    bool nodup = (C <= GROUP_CAMS);
-    if (nodup && sorted && cam_sorted) {           // already canonical: only the visibility masks are needed
-      vmask.assign(N, 0);
-      for (int64_t i = 0; i < M; ++i) vmask[pi_h[i]] |= (uint16_t)(1u << ci_h[i]);
-    } else if (nodup) {
-      vmask.assign(N, 0);
-      std::vector<int64_t> slot(C);
-      for (int p = 0; p < N && nodup; ++p) {
-        std::fill(slot.begin(), slot.end(), (int64_t)-1);
-        const int a = ptstart[p], b = ptstart[p + 1];
-        for (int k = a; k < b; ++k) {
-          const int64_t i = perm[k];
-          if (slot[ci_h[i]] >= 0) { nodup = false; break; }
-          slot[ci_h[i]] = i;
-          vmask[p] |= (uint16_t)(1u << ci_h[i]);
-        }
-        if (!nodup) break;
-        int k = a;
-        for (int c = 0; c < C; ++c)
-          if (slot[c] >= 0) { if (perm[k] != slot[c]) { perm[k] = slot[c]; identity_perm = false; } ++k; }
-      }
-    }
-    dense = dense && nodup;
-    masked_ok = nodup && !dense;
-    up_lap("validate + sort + canonical");
-    has_w = (w_h != nullptr);
-    std::vector<T2> uvp(M);
-    std::vector<T> wp(has_w ? M : 0);
-    std::vector<int32_t> cip(M), pip(M);
-    par_for(M, [&](int64_t lo, int64_t hi, int) {
-      for (int64_t k = lo; k < hi; ++k) {
-        const int64_t i = perm[k];
-        uvp[k].x = (T)uv_h[2 * i]; uvp[k].y = (T)uv_h[2 * i + 1];
-        if (has_w) wp[k] = (T)w_h[i];
-        cip[k] = (int32_t)ci_h[i]; pip[k] = (int32_t)pi_h[i];
-      }
-    });
-    up_lap("permute observations");
-    // point-aligned blocks of <= 256 observations
-    std::vector<int32_t> blk;
-    blk.push_back(0);
-    {
-      int p = 0;
-      while (p < N) {
-        int q = p; int cnt = 0;
-        while (q < N && cnt + (ptstart[q + 1] - ptstart[q]) <= PM_BLOCK && (q - p) < PM_BLOCK) { cnt += ptstart[q + 1] - ptstart[q]; ++q; }
-        if (q == p) ++q;   // cannot happen (maxdeg <= 256) but never loop forever
-        blk.push_back(q);
-        p = q;
-      }
-    }
-    nblk = (int)blk.size() - 1;
-    std::vector<int4> bdesc(nblk);
-    for (int b = 0; b < nblk; ++b) bdesc[b] = make_int4(blk[b], blk[b + 1], ptstart[blk[b]], ptstart[blk[b + 1]]);
-    // camera-major order of the pm list (stable => points ascending inside a camera)
-    std::vector<int32_t> camcount(C + 1, 0);
-    for (int64_t k = 0; k < M; ++k) camcount[cip[k] + 1]++;
-    for (int c = 0; c < C; ++c) camcount[c + 1] += camcount[c];
-    std::vector<T2> uvc(M);
-    std::vector<T> wc(has_w ? M : 0);
-    std::vector<int32_t> pic(M);
-    {
-      std::vector<int32_t> fill(camcount.begin(), camcount.end() - 1);
-      for (int64_t k = 0; k < M; ++k) {
-        const int32_t d = fill[cip[k]]++;
-        uvc[d] = uvp[k]; pic[d] = pip[k];
-        if (has_w) wc[d] = wp[k];
-      }
-    }
-    std::vector<int32_t> ch_cam, ch_beg, ch_end, cam_ch(C + 1, 0);
-    for (int c = 0; c < C; ++c) {
-      cam_ch[c] = (int32_t)ch_cam.size();
-      for (int32_t b = camcount[c]; b < camcount[c + 1]; b += CM_CHUNK) {
-        ch_cam.push_back(c); ch_beg.push_back(b); ch_end.push_back(std::min(camcount[c + 1], b + CM_CHUNK));
-      }
-    }
-    cam_ch[C] = (int32_t)ch_cam.size();
-    nchunk = (int)ch_cam.size();
-    // camera groups / pairs for the Schur kernel
-    ngroups = (C + GROUP_CAMS - 1) / GROUP_CAMS;
-    std::vector<int32_t> pga, pgb;
-    for (int a = 0; a < ngroups; ++a) { pga.push_back(a); pgb.push_back(a); }   // diagonal pairs first
-    for (int a = 0; a < ngroups; ++a)
-      for (int b = a + 1; b < ngroups; ++b) { pga.push_back(a); pgb.push_back(b); }
-    npairs = (int)pga.size();
-    {
-      int target = 256;
-      if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
-      // workgroups per k-split: every pair is dealt to TS workgroups (tile split, grid.z of k_schur)
-      // the diagonal and the off-diagonal pairs are two launches, one after the other: each must fill the chip
-      const int wg_per_ks = std::max(ngroups * SchurSel<T, true>::TS, (npairs - ngroups) * SchurSel<T, false>::TS);
-      int ks = std::max(1, target / wg_per_ks);
-      const int maxks = std::max(1, (N + SCHUR_PTS - 1) / SCHUR_PTS);
-      ksplit = std::min(ks, maxks);
-    }
-
-    up_lap("blocks + camera-major copies");
-    uv_pm.upload(uvp, stream); ci_pm.upload(cip, stream); pi_pm.upload(pip, stream);
-    if (has_w) { w_pm.upload(wp, stream); w_cm.upload(wc, stream); }
-    pt_start.upload(ptstart, stream); blk_pt.upload(blk, stream); blk_desc.upload(bdesc, stream);
-    uv_cm.upload(uvc, stream); pi_cm.upload(pic, stream);
-    chunk_cam.upload(ch_cam, stream); chunk_begin.upload(ch_beg, stream); chunk_end.upload(ch_end, stream);
-    cam_chunk_start.upload(cam_ch, stream);
-    pair_ga.upload(pga, stream); pair_gb.upload(pgb, stream);
-
-    for (int b = 0; b < 2; ++b) {
-      cams[b].alloc((size_t)C * NCP); pts[b].alloc((size_t)N * 3);
-      ptsT[b].alloc((size_t)N * 3); campre[b].alloc((size_t)C * CAMPRE);
-    }
-    pfac.alloc((size_t)std::max(N, 1) * PF);
-    V.alloc((size_t)N * 6); gp.alloc((size_t)N * 3); D2p.alloc((size_t)N * 3); D2c.alloc(n);
-    U.alloc((size_t)C * 121); gc.alloc(n); Upart.alloc((size_t)std::max(1, nchunk) * 256);
-    bpart.alloc((size_t)ngroups * ksplit * GROUP_ROWS);
-    slabs.alloc((size_t)npairs * ksplit * GROUP_TILES * GROUP_TILES * 256);
-    E_own.alloc((size_t)n * n + 3 * n + 1); scal_own.alloc(NSCAL); delta_c.alloc(n);
-    const int nres_blocks = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
-    dense_one_group = dense && C <= GROUP_CAMS && N > 0 && !getenv("SBA_NO_DENSE");
-    nbs_dense = std::max(1, std::min((N + 15) / 16, getenv("SBA_BS_WGS") ? atoi(getenv("SBA_BS_WGS")) : (sizeof(T) == 4 ? 768 : 512)));
-    // the fused linearise+Schur kernel also serves sparse one-group rigs through the visibility mask; its producer cost
-    // does not shrink with the number of observations, so below ~35 % visibility the three-pass path is used
-    const bool masked_fused = masked_ok && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
-    fused_ok = (dense_one_group || masked_fused) && sizeof(T) == 4 && !getenv("SBA_NO_FUSED");
-    fused_masked = fused_ok && !dense_one_group;
-    lin_pts_ok = (dense_one_group || masked_fused) && SCHUR_SYM<T> && !getenv("SBA_NO_FUSED");
-    if (fused_masked || (lin_pts_ok && !dense_one_group)) vis_mask.upload(vmask, stream);
-    if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * GROUP_ROWS);
-    cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1));
-    trial_part.alloc((size_t)4 * std::max(nblk, 1));
-    up_lap("allocations + H2D enqueue");
-    sync();   // the staging vectors go out of scope now
-    up_lap("H2D completion");
-    uploaded = true;
-    cur = 0;
-    set_params(cams_h, pts_h);
-    return SBA_OK;
-  }
-
-  void set_params(const double* cams_h, const double* pts_h) {
-    HIPCHK(hipMemcpyAsync(cams[cur].p, cams_h, sizeof(double) * C * NCP, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(pts[cur].p, pts_h, sizeof(double) * (size_t)N * 3, hipMemcpyHostToDevice, stream));
-    std::vector<T> pt((size_t)N * 3);
-    for (size_t i = 0; i < pt.size(); ++i) pt[i] = (T)pts_h[i];
-    HIPCHK(hipMemcpyAsync(ptsT[cur].p, pt.data(), sizeof(T) * pt.size(), hipMemcpyHostToDevice, stream));
-    cam_prep(cur);
-    sync();
-  }
-
-  void cam_prep(int b) {
-    hipLaunchKernelGGL(k_cam_prep<T>, dim3((C + 63) / 64), dim3(64), 0, stream, cams[b].p, campre[b].p, C);
-  }
-
-  size_t lds_cams() const { return (size_t)C * CAMPRE * sizeof(T); }
-
-  // ------------------------------------------------------------------ kernel launchers
-  // The LM kernels read the current / trial buffers through a device-resident pointer table that k_decide swaps on
-  // acceptance; the host mirror `cur` is refreshed from LMState::cur whenever the state is read back.
-  ParamSets<T> psets{};              // both buffer sets + the side that was current at lm_begin
-  void push_ptrs() {                 // (re)build the by-value kernel argument for the host's notion of `cur`
-    for (int b = 0; b < 2; ++b) { psets.cams[b] = cams[b].p; psets.pts[b] = pts[b].p; psets.ptsT[b] = ptsT[b].p; psets.campre[b] = campre[b].p; }
-    psets.base = cur;
-  }
-  // argument for launches inside the LM loop (side = base ^ LMState::cur) ...
-  ParamSets<T> ps_lm() const { return psets; }
-  // ... and for launches outside it (st == nullptr): the host's current side
-  ParamSets<T> ps_now() const { ParamSets<T> q = psets; q.base = cur; return q; }
-  void launch_residual(T2* r_out) {
-    const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
-    if (g == 0) return;
-    hipLaunchKernelGGL(k_residual<T>, dim3(g), dim3(PM_BLOCK), lds_cams(), stream, campre[cur].p, C, ptsT[cur].p,
-                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, r_out, cost_part.p);
-  }
-  void launch_resjac(T2* r_out) {
-    const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
-    if (g == 0) return;
-    const size_t lds = (((size_t)C * CAMPRE + 3) & ~(size_t)3) * sizeof(T) + (size_t)PM_BLOCK * 29 * sizeof(T);
-    hipLaunchKernelGGL(k_resjac<T>, dim3(g), dim3(PM_BLOCK), lds, stream, campre[cur].p, C, ptsT[cur].p, uv_pm.p,
-                       has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, r_out, Jc_pm.p, Jp_pm.p);
-  }
-  // st == nullptr: unconditional (used outside the LM loop); otherwise the launch is a no-op once the solve has
-  // terminated or when the last step was rejected and nothing has to be re-linearized
-  void launch_linearize_points(const LMState* st) {
-    if (nblk == 0) return;
-    const size_t lds = (size_t)PM_BLOCK * 9 * sizeof(double) + lds_cams();
-    hipLaunchKernelGGL(k_linearize_points<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, st ? ps_lm() : ps_now(), st, C,
-                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_desc.p, V.p, gp.p, D2p.p,
-                       cost_part.p, gmax_part.p);
-  }
-  void launch_linearize_cams(const LMState* st) {
-    if (nchunk == 0) return;
-    hipLaunchKernelGGL(k_linearize_cams<T>, dim3(nchunk), dim3(256), 0, stream, st ? ps_lm() : ps_now(), st, uv_cm.p,
-                       has_w ? w_cm.p : nullptr, pi_cm.p, chunk_cam.p, chunk_begin.p, chunk_end.p, Upart.p);
-    hipLaunchKernelGGL(k_reduce_cams, dim3(C), dim3(1024), 0, stream, Upart.p, cam_chunk_start.p, U.p, gc.p, st);
-  }
-  // the linearisation is folded into the Schur kernel (k_schur_fused) whenever the cameras are free
-  bool fused() const { return fused_ok && h_state && h_state->free_cams; }
-  bool lin_pts() const { return lin_pts_ok && h_state && h_state->free_cams; }   // f64: points linearised inside k_schur_sym
-  int n_lin_parts() const { return (fused() || lin_pts()) ? ksplit : nblk; }       // entries of cost_part / gmax_part
-  void launch_schur() {
-    if constexpr (sizeof(T) == 4) {
-      if (fused()) {
-        hipLaunchKernelGGL(k_schur_fused, dim3(ksplit), dim3(SCHUR_THREADS), SchurFusedCfg<float>::LDS_BYTES, stream,
-                           ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
-                           N, ksplit, D2p.p, gp.p, pfac.p,
-                           slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p, schur_debug ? schur_dbg.p : nullptr);
-        if (schur_debug) {
-          std::vector<long long> st(64);
-          HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
-          sync();
-          fprintf(stderr, "[schur_fused stamps, cycles since the first producer stamp; per chunk: producer-done consumer-done]\n");
-          for (int i = 0; i < 14; ++i) fprintf(stderr, "  it %2d: P %7lld  C %7lld\n", i, st[2 * i] - st[0], st[2 * i + 1] - st[0]);
-          schur_debug = false;
-        }
-        return;
-      }
-    }
-    if constexpr (SCHUR_SYM<T>) {
-      if (lin_pts()) {
-        using CfgD = SchurSel<T, true>;
-        hipLaunchKernelGGL((k_schur_sym<T, true, false, true>), dim3(ksplit, 1, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
-                           stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
-                           pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, 1, slabs.p, bpart.p, (long long*)nullptr,
-                           dense_one_group ? (const uint16_t*)nullptr : vis_mask.p, D2p.p, gp.p, cost_part.p, gmax_part.p);
-        return;
-      }
-    }
-    if (N > 0)
-      hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
-    // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
-    // a camera count that is not a multiple of 16 leaves the last group's panel mostly empty: the PARTIAL
-    // instantiations skip the MFMAs of empty tiles (kept apart so that the full-group kernels pay nothing for it)
-    // (f64 only: the f32 consumers are paced by their producers and lose more to the per-tile branches than they save)
-    if constexpr (SCHUR_SYM<T>) {
-      if (C % GROUP_CAMS != 0) { launch_schur_kernels<true>(); return; }
-    }
-    launch_schur_kernels<false>();
-  }
-  template <bool PARTIAL> void launch_schur_kernels() {
-    using CfgD = SchurSel<T, true>;
-    using CfgO = SchurSel<T, false>;
-    if constexpr (SCHUR_SYM<T>) {
-      hipLaunchKernelGGL((k_schur_sym<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
-                         stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
-                         pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p, schur_debug ? schur_dbg.p : nullptr);
-      if (schur_debug) {
-        std::vector<long long> st(64);
-        HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
-        sync();
-        fprintf(stderr, "[schur_sym stamps, cycles; per chunk: produce-done after-barrier consume-done]\n");
-        for (int i = 0; i < 8; ++i)
-          fprintf(stderr, "  it %2d: P %7lld  B %7lld  C %7lld\n", i, st[3 * i] - st[0], st[3 * i + 1] - st[0], st[3 * i + 2] - st[0]);
-        schur_debug = false;
-      }
-      if (npairs > ngroups)
-        hipLaunchKernelGGL((k_schur_sym<T, false, PARTIAL>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
-                           CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
-                           has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
-                           pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
-      return;
-    } else {
-    hipLaunchKernelGGL((k_schur<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
-                       stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
-                       pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,
-                       schur_debug ? schur_dbg.p : nullptr);
-    if (schur_debug) {
-      std::vector<long long> st(64);
-      HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
-      sync();
-      fprintf(stderr, "[schur stamps, cycles since first barrier; per chunk: producer-done consumer-done barrier-out]\n");
-      for (int i = 0; i < 14; ++i)
-        fprintf(stderr, "  it %2d: P %7lld  C %7lld  out %7lld\n", i, st[3 * i] - st[2], st[3 * i + 1] - st[2], st[3 * i + 2] - st[2]);
-      schur_debug = false;
-    }
-    if (npairs > ngroups)
-      hipLaunchKernelGGL((k_schur<T, false, PARTIAL>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
-                         CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
-                         has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
-                         pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
-    }
-  }
-  // dense visibility with one camera group: the row-reduction kernel (any dtype); its partial rows are per workgroup
-  bool backsub_dense() const { return dense_one_group; }
-  int n_trial_parts() const { return backsub_dense() ? nbs_dense : nblk; }
-  void launch_backsub_trial() {
-    if (nblk == 0) return;
-    if (backsub_dense()) {
-      hipLaunchKernelGGL(k_backsub_dense<T>, dim3(nbs_dense), dim3(PM_BLOCK), 0, stream, ps_lm(), C, uv_pm.p,
-                         has_w ? w_pm.p : nullptr, N, pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nbs_dense);
-      return;
-    }
-    const size_t lds = (size_t)PM_BLOCK * 6 * sizeof(double) + (2 * (size_t)C * CAMPRE + (size_t)C * NCP) * sizeof(T);
-    hipLaunchKernelGGL(k_backsub_trial<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, ps_lm(), C,
-                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_desc.p,
-                       pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nblk);
-  }
-
-  // ------------------------------------------------------------------ model evaluation entry points
-  int residual(const double* x, double* r_out, double* cost_out) {
-    if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
-    HIPCHK(hipSetDevice(device));
-    if (x) set_params(x, x + (size_t)C * NCP);
-    if (r_out && r_pm.n != (size_t)M) r_pm.alloc(M);
-    launch_residual(r_out ? r_pm.p : nullptr);
-    const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
-    std::vector<double> part(g);
-    if (g) HIPCHK(hipMemcpyAsync(part.data(), cost_part.p, sizeof(double) * g, hipMemcpyDeviceToHost, stream));
-    std::vector<T2> r(r_out ? M : 0);
-    if (r_out && M) HIPCHK(hipMemcpyAsync(r.data(), r_pm.p, sizeof(T2) * M, hipMemcpyDeviceToHost, stream));
-    sync();
-    HIPCHK(hipGetLastError());
-    double c = 0;
-    for (double v : part) c += v;
-    if (cost_out) *cost_out = c;
-    if (r_out)
-      for (int64_t k = 0; k < M; ++k) { const int64_t i = perm[k]; r_out[2 * i] = (double)r[k].x; r_out[2 * i + 1] = (double)r[k].y; }
-    return SBA_OK;
-  }
-
-  int residual_jacobian(const double* x, double* r_out, double* Jc_out, double* Jp_out) {
-    if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
-    HIPCHK(hipSetDevice(device));
-    if (x) set_params(x, x + (size_t)C * NCP);
-    if (r_pm.n != (size_t)M) r_pm.alloc(M);
-    if (Jc_pm.n != (size_t)M * 22) { Jc_pm.alloc((size_t)M * 22); Jp_pm.alloc((size_t)M * 6); }
-    launch_resjac(r_pm.p);
-    std::vector<T2> r(M);
-    std::vector<T> jc((size_t)M * 22), jp((size_t)M * 6);
-    if (M) {
-      HIPCHK(hipMemcpyAsync(r.data(), r_pm.p, sizeof(T2) * M, hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipMemcpyAsync(jc.data(), Jc_pm.p, sizeof(T) * jc.size(), hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipMemcpyAsync(jp.data(), Jp_pm.p, sizeof(T) * jp.size(), hipMemcpyDeviceToHost, stream));
-    }
-    sync();
-    HIPCHK(hipGetLastError());
-    for (int64_t k = 0; k < M; ++k) {
-      const int64_t i = perm[k];
-      if (r_out) { r_out[2 * i] = (double)r[k].x; r_out[2 * i + 1] = (double)r[k].y; }
-      if (Jc_out) for (int e = 0; e < 22; ++e) Jc_out[(size_t)i * 22 + e] = (double)jc[(size_t)k * 22 + e];
-      if (Jp_out) for (int e = 0; e < 6; ++e) Jp_out[(size_t)i * 6 + e] = (double)jp[(size_t)k * 6 + e];
-    }
-    return SBA_OK;
-  }
-
-  // ------------------------------------------------------------------ squared-pixel-error variants (pySBA.py:151-205)
-  bool sq_mode() const { return opts.mode == SBA_MODE_CAMS_ONLY_SQ || opts.mode == SBA_MODE_TRANSFORM_SQ; }
-  int nblk_sq = 0, nchunk_sq = 0;
-  DevBuf<double> sq_part, sq_16, theta[2];
-  DevBuf<int32_t> sq_start;
-  double h_theta[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-  ThetaSets tsets() const { ThetaSets t; t.th[0] = theta[0].p; t.th[1] = theta[1].p; t.base = cur_at_begin; return t; }
-  void sq_setup() {
-    nblk_sq = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
-    std::vector<int32_t> st;
-    if (opts.mode == SBA_MODE_CAMS_ONLY_SQ) {          // one 16x16 per camera, from the camera-major chunks
-      nchunk_sq = nchunk;
-      sq_16.alloc((size_t)C * 256);
-    } else {                                           // one 16x16 for the whole problem
-      nchunk_sq = (int)((M + SQ_CHUNK - 1) / SQ_CHUNK);
-      st = {0, nchunk_sq};
-      sq_start.upload(st, stream);
-      sq_16.alloc(256);
-      for (int b = 0; b < 2; ++b) if (theta[b].n != 12) theta[b].alloc(12);
-    }
-    sq_part.alloc((size_t)std::max(nchunk_sq, 1) * 256);
-    if (trial_part.n < (size_t)4 * std::max(nblk_sq, 1)) trial_part.alloc((size_t)4 * std::max(nblk_sq, 1));
-    if (gmax_part.n < (size_t)std::max(nblk_sq, 1)) gmax_part.alloc(std::max(nblk_sq, 1));
-    gmax_part.zero(stream);
-  }
-  void launch_sq_linearize(const LMState* st) {
-    if (nchunk_sq == 0) return;
-    const ParamSets<T> ps = st ? ps_lm() : ps_now();
-    ThetaSets ts = tsets();
-    if (!st) ts.base = cur;
-    if (opts.mode == SBA_MODE_CAMS_ONLY_SQ) {
-      const size_t lds = ((size_t)4 * 16 * 130 + CAMPRE) * sizeof(T);
-      hipLaunchKernelGGL((k_sq_linearize<T, 1>), dim3(nchunk_sq), dim3(256), lds, stream, ps, ts, st, C, uv_cm.p,
-                         has_w ? w_cm.p : nullptr, (const int32_t*)nullptr, pi_cm.p, chunk_cam.p, chunk_begin.p, chunk_end.p, M, sq_part.p);
-      hipLaunchKernelGGL(k_reduce16, dim3(C), dim3(1024), 0, stream, sq_part.p, cam_chunk_start.p, sq_16.p, st);
-    } else {
-      const size_t lds = ((size_t)4 * 16 * 130 + (size_t)C * CAMPRE) * sizeof(T);
-      hipLaunchKernelGGL((k_sq_linearize<T, 2>), dim3(nchunk_sq), dim3(256), lds, stream, ps, ts, st, C, uv_pm.p,
-                         has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, (const int32_t*)nullptr, (const int32_t*)nullptr,
-                         (const int32_t*)nullptr, M, sq_part.p);
-      hipLaunchKernelGGL(k_reduce16, dim3(1), dim3(1024), 0, stream, sq_part.p, sq_start.p, sq_16.p, st);
-    }
-  }
-  void launch_sq_trial() {
-    if (nblk_sq == 0) return;
-    if (opts.mode == SBA_MODE_CAMS_ONLY_SQ)
-      hipLaunchKernelGGL((k_sq_trial<T, 1>), dim3(nblk_sq), dim3(PM_BLOCK), lds_cams(), stream, ps_lm(), tsets(), d_state.p, C,
-                         uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, trial_part.p, nblk_sq);
-    else
-      hipLaunchKernelGGL((k_sq_trial<T, 2>), dim3(nblk_sq), dim3(PM_BLOCK), lds_cams(), stream, ps_lm(), tsets(), d_state.p, C,
-                         uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, trial_part.p, nblk_sq);
-  }
-  // cost (0.5 sum rho^2) and max |gradient| from the 16x16 sums of the last squared-variant linearization
-  void sq_read(double& cost, double& gmax) {
-    const int ng = (opts.mode == SBA_MODE_CAMS_ONLY_SQ) ? C : 1;
-    const int np = (opts.mode == SBA_MODE_CAMS_ONLY_SQ) ? NCP : 12;
-    std::vector<double> h((size_t)ng * 256);
-    HIPCHK(hipMemcpyAsync(h.data(), sq_16.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
-    sync();
-    cost = 0; gmax = 0;
-    for (int g = 0; g < ng; ++g) {
-      cost += 0.5 * h[(size_t)g * 256 + np * 16 + np];
-      for (int i = 0; i < np; ++i) gmax = std::max(gmax, std::fabs(h[(size_t)g * 256 + i * 16 + np]));
-    }
-  }
-
-  // shared intrinsics (pySBA.py:252-325): unknowns [f,k1,k2 | 6 extrinsics x C | 2 centre x C], pySBA.py:313 order
-  void build_tie_tables() {
-    n_tied = 3 + 8 * C;
-    std::vector<int32_t> tie(n), start(n_tied + 1, 0), idx(n), firstv(n_tied);
-    for (int c = 0; c < C; ++c)
-      for (int e = 0; e < NCP; ++e)
-        tie[c * NCP + e] = e < 6 ? 3 + 6 * c + e : e < 9 ? e - 6 : 3 + 6 * C + 2 * c + (e - 9);
-    for (int i = 0; i < n; ++i) start[tie[i] + 1]++;
-    for (int a = 0; a < n_tied; ++a) start[a + 1] += start[a];
-    std::vector<int32_t> fill(start.begin(), start.end() - 1);
-    for (int i = 0; i < n; ++i) idx[fill[tie[i]]++] = i;
-    for (int a = 0; a < n_tied; ++a) firstv[a] = idx[start[a]];
-    h_tie = tie;
-    tie_map.upload(tie, stream); tie_pre_start.upload(start, stream); tie_pre_idx.upload(idx, stream); tie_first.upload(firstv, stream);
-    E_tied.alloc((size_t)n_tied * n_tied + 3 * (size_t)n_tied + 1);
-    sync();
-  }
-  int n_tied = 0;
-  std::vector<int32_t> h_tie;
-  DevBuf<int32_t> tie_map, tie_pre_start, tie_pre_idx, tie_first;
-  DevBuf<double> E_tied;
-
-  // ------------------------------------------------------------------ LM phases
-  int64_t exchange_size() const { return (int64_t)n * n + 3 * (int64_t)n + 1; }
-  static constexpr int LOG_CAP = 4096;
-  static constexpr int BATCH = 4;      // LM iterations enqueued between two host polls of the state
-
-  int lm_begin(const sba_lm_opts* o) {
-    if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
-    HIPCHK(hipSetDevice(device));
-    opts = *o;
-    prof_on = opts.reserved[0] != 0;
-    for (int k = 0; k < KP_N; ++k) { prof_us[k] = 0; prof_cnt[k] = 0; }
-    pslot = 0;
-    for (auto& u : pev_used) u = false;
-    if (opts.mode < SBA_MODE_FULL || opts.mode > SBA_MODE_TRANSFORM_SQ) { err = "unsupported mode"; return SBA_ERR_UNSUPPORTED; }
-    if (opts.mode == SBA_MODE_SHARED_INTR) build_tie_tables();
-    // initial cost; scipy raises ValueError when it is not finite (least_squares.py:844-845)
-    double c0 = 0;
-    int rc = residual(nullptr, nullptr, &c0);
-    if (rc) return rc;
-    initial_cost = c0;
-    LMState s{};
-    s.lam = opts.lambda0 > 0 ? opts.lambda0 : 1e-4;
-    // x_scale = 1 (unscaled damping): lambda = tau * max diag(J^T J), set on the device.  tau is tiny because the
-    // parameters of these variants differ by orders of magnitude in scale (rotation vs focal length; affine matrix vs
-    // translation column), and only a near Gauss-Newton step moves the weakly scaled ones -- scipy gets the same
-    // effect from its large initial trust radius
-    if (sq_mode()) s.lam = -(opts.lambda0 > 0 ? opts.lambda0 : 1e-9);
-    s.nu = 2.0;
-    s.cost = c0;
-    s.ftol = opts.ftol; s.xtol = opts.xtol; s.gtol = opts.gtol;
-    s.lam_min = 1e-12; s.lam_max = 1e12;
-    s.nfev = 1; s.njev = 1;
-    const long long nparam = opts.mode == SBA_MODE_CAMS_ONLY_SQ ? (long long)n : opts.mode == SBA_MODE_TRANSFORM_SQ ? 12LL :
-        (opts.mode == SBA_MODE_FULL ? (long long)n : opts.mode == SBA_MODE_SHARED_INTR ? (long long)n_tied : 0) + 3LL * N;
-    s.max_nfev = opts.max_nfev > 0 ? opts.max_nfev : 100 * nparam;
-    s.status = -1; s.fresh = 1; s.need_lin = 1;
-    s.always_relin = opts.always_relinearize ? 1 : 0;
-    s.max_iter = opts.max_iter > 0 ? opts.max_iter : 0;
-    s.cur = 0;
-    s.free_cams = (opts.mode == SBA_MODE_POINTS_ONLY) ? 0 : 1;
-    *h_state = s;
-    HIPCHK(hipMemcpyAsync(d_state.p, h_state, sizeof(LMState), hipMemcpyHostToDevice, stream));
-    D2p.zero(stream); D2c.zero(stream); delta_c.zero(stream);
-    // trial buffers start as copies so that points-only mode has valid trial cameras
-    HIPCHK(hipMemcpyAsync(cams[1 - cur].p, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
-    HIPCHK(hipMemcpyAsync(campre[1 - cur].p, campre[cur].p, sizeof(T) * C * CAMPRE, hipMemcpyDeviceToDevice, stream));
-    push_ptrs();
-    cur_at_begin = cur;
-    if (d_log.n == 0) d_log.alloc(LOG_CAP);
-    if (sq_mode()) {
-      // points never move in these variants, but the buffer parity flips with every accepted step: both sides equal
-      HIPCHK(hipMemcpyAsync(pts[1 - cur].p, pts[cur].p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToDevice, stream));
-      HIPCHK(hipMemcpyAsync(ptsT[1 - cur].p, ptsT[cur].p, sizeof(T) * (size_t)N * 3, hipMemcpyDeviceToDevice, stream));
-      sq_setup();
-      if (opts.mode == SBA_MODE_TRANSFORM_SQ) {
-        const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};     // x0 of pySBA.py:193
-        for (int b = 0; b < 2; ++b) HIPCHK(hipMemcpyAsync(theta[b].p, ident, sizeof ident, hipMemcpyHostToDevice, stream));
-      }
-      launch_sq_linearize(nullptr);
-      double g0 = 0;
-      sq_read(c0, g0);
-      initial_cost = c0;
-      h_state->cost = c0;
-      HIPCHK(hipMemcpyAsync(d_state.p, h_state, sizeof(LMState), hipMemcpyHostToDevice, stream));
-    }
-    sync();
-    log.clear();
-    log_read = 0;
-    lm_active = true;
-    if (!std::isfinite(c0)) { err = "Residuals are not finite in the initial point."; return SBA_ERR_NONFINITE; }
-    return SBA_OK;
-  }
-
-  int lm_linearize() {
-    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
-    if (sq_mode()) { launch_sq_linearize(d_state.p); return SBA_OK; }
-    if (fused()) return SBA_OK;          // k_schur_fused linearises
-    if (!lin_pts()) {                    // (f64 one-group rigs: k_schur_sym<LIN> linearises the points)
-      prof_begin(KP_LINP);
-      launch_linearize_points(d_state.p);
-      prof_end(KP_LINP);
-    }
-    if (h_state->free_cams) { prof_begin(KP_LINC); launch_linearize_cams(d_state.p); prof_end(KP_LINC); }
-    return SBA_OK;
-  }
-
-  int lm_form_reduced(double* E) {
-    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
-    if (sq_mode()) {
-      if (opts.mode == SBA_MODE_CAMS_ONLY_SQ)
-        hipLaunchKernelGGL(k_sq_pack_cams, dim3(64), dim3(256), 0, stream, sq_16.p, C, d_state.p, E);
-      return SBA_OK;
-    }
-    if (h_state->free_cams) {
-      prof_begin(KP_SCHUR);
-      launch_schur();
-      prof_end(KP_SCHUR);
-    }
-    prof_begin(KP_REDUCE);
-    {
-      const int fc = (int)h_state->free_cams;
-      const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 15) / 16 : 0) + 1;
-      hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
-                         pair_gb.p, npairs, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? gdpart.p : (const double*)nullptr);
-    }
-    prof_end(KP_REDUCE);
-    return SBA_OK;
-  }
-
-  // A = S + lam D (n_sys x n_sys, in E) -> chol_sol = A^-1 rhs, chol_info != 0 when A is not positive definite
-  void launch_chol_big(double* Esys, int n_sys) {
-    const int npad = cholbig_npad(n_sys), nbr = npad / BB, nbx = (n_sys + BB - 1) / BB;
-    if (chol_W.n < (size_t)npad * npad) {
-      chol_W.alloc((size_t)npad * npad); chol_Minv.alloc((size_t)nbr * BB * BB); chol_Ld.alloc((size_t)nbr * BB * BB);
-      chol_yv.alloc(npad);
-    }
-    if (chol_sol.n < (size_t)n_sys) { chol_sol.alloc(n_sys); chol_info.alloc(1); }
-    hipLaunchKernelGGL(k_chol_big_prepare, dim3(nbr * (nbr + 1) / 2), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p,
-                       chol_W.p, npad, chol_info.p);
-    const size_t lds = (size_t)48 * CBS * sizeof(double);
-    for (int j = 0; j < nbr; ++j) {
-      const int q = nbr - 1 - j;
-      hipLaunchKernelGGL(k_chol_big_step, dim3(std::max(1, q * (q + 1) / 2)), dim3(CHOLBIG_THREADS), lds, stream, chol_W.p, npad, j,
-                         chol_Minv.p, chol_Ld.p, chol_info.p, d_state.p);
-    }
-    hipLaunchKernelGGL(k_chol_big_back_init, dim3((npad + 255) / 256), dim3(256), 0, stream, chol_W.p, npad, n_sys, chol_Ld.p,
-                       chol_yv.p, d_state.p);
-    for (int b = nbx - 1; b >= 0; --b)
-      hipLaunchKernelGGL(k_chol_big_back, dim3(b + 1), dim3(256), 0, stream, chol_W.p, npad, b, n_sys, chol_Minv.p, chol_yv.p,
-                         chol_sol.p, d_state.p);
-  }
-
-  // scal == nullptr: single rank, the partials are folded inside k_decide and no scalar exchange is needed
-  int lm_solve_trial(double* E, double* scal) {
-    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
-    if (opts.mode == SBA_MODE_TRANSFORM_SQ) {
-      hipLaunchKernelGGL(k_sq_solve12, dim3(1), dim3(64), 0, stream, sq_16.p, d_state.p, tsets());
-      launch_sq_trial();
-      return SBA_OK;
-    }
-    if (h_state->free_cams) {
-      prof_begin(KP_CHOL);
-      const bool tied = (opts.mode == SBA_MODE_SHARED_INTR);
-      const int n_sys = tied ? n_tied : n;
-      double* Esys = E;
-      if (tied) {   // collapse the camera system onto the tied unknowns
-        hipLaunchKernelGGL(k_tie_system, dim3(n_tied), dim3(256), 0, stream, E, n, n_tied, tie_pre_start.p, tie_pre_idx.p,
-                           E_tied.p, d_state.p);
-        Esys = E_tied.p;
-      }
-      if (n_sys <= CHOL_LDS_MAX_N && !chol_old) {
-        const int nb = (n_sys + CB - 1) / CB;
-        const size_t lds = ((size_t)(nb * (nb + 1) / 2) * CBS + 2 * (size_t)nb * CB) * sizeof(double);
-        if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }
-        hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
-                           ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr,
-                           chol_debug ? chol_dbg.p : nullptr);
-        if (chol_debug) {
-          std::vector<long long> st(64);
-          HIPCHK(hipMemcpyAsync(st.data(), chol_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
-          sync();
-          fprintf(stderr, "[chol stamps, cycles] load %lld  chol0 %lld |", st[1] - st[0], st[2] - st[1]);
-          for (int j = 0; j < nb; ++j) fprintf(stderr, " B%d %lld C%d %lld |", j, st[3 + 2 * j] - st[2 + 2 * j], j, st[4 + 2 * j] - st[3 + 2 * j]);
-          fprintf(stderr, " backsub %lld  epilogue %lld  total %lld\n", st[3 + 2 * nb] - st[2 + 2 * nb], st[4 + 2 * nb] - st[3 + 2 * nb], st[4 + 2 * nb] - st[0]);
-          chol_debug = false;
-        }
-      } else if (n_sys <= CHOL_LDS_MAX_N) {
-        const size_t lds = (size_t)n_sys * (n_sys + 1) / 2 * sizeof(double);
-        hipLaunchKernelGGL((k_cholesky_solve<true, T>), dim3(1), dim3(CHOL_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
-                           ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
-      } else if (n_sys > chol_big_min_n && !chol_old) {
-        // 47+ cameras: multi-workgroup right-looking factorisation, one launch per 64-wide block column (sba_chol_big.hpp)
-        launch_chol_big(Esys, n_sys);
-        hipLaunchKernelGGL(k_chol_epilogue<T>, dim3(1), dim3(1024), 0, stream, Esys, C, n_sys, d_state.p, D2c.p, ps_lm(), delta_c.p,
-                           chol_sol.p, chol_info.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
-      } else if (n_sys <= CS_MAX_NB * CB && !chol_old) {
-        // 17 .. 46 cameras: one workgroup, left-looking, finished block columns streamed through L2
-        const int nb = (n_sys + CB - 1) / CB;
-        if (chol_sol.n < (size_t)n_sys) { chol_sol.alloc(n_sys); chol_info.alloc(1); }
-        if (chol_work.n < (size_t)nb * (nb + 1) / 2 * CB * CB) chol_work.alloc((size_t)nb * (nb + 1) / 2 * CB * CB);
-        // panel (nb blocks) + rhs + as much staging as the 150 KB budget leaves (fewer, larger streaming rounds)
-        const size_t fixed = ((size_t)nb * CBS + (size_t)nb * CB) * sizeof(double);
-        const int scap = std::min(64, std::max(nb, (int)((150 * 1024 - fixed) / (CBS * sizeof(double)))));
-        const size_t lds = fixed + (size_t)scap * CBS * sizeof(double);
-        hipLaunchKernelGGL(k_chol_prepare, dim3((n_sys + 255) / 256), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p, chol_sol.p);
-        hipLaunchKernelGGL(k_cholesky_stream, dim3(1), dim3(CHOLB_THREADS), lds, stream, Esys, n_sys, chol_work.p, chol_sol.p,
-                           chol_info.p, d_state.p, scap, chol_debug ? (chol_dbg.n ? chol_dbg.p : (chol_dbg.alloc(64), chol_dbg.p)) : nullptr);
-        if (chol_debug) {
-          std::vector<long long> st(8);
-          HIPCHK(hipMemcpyAsync(st.data(), chol_dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost, stream));
-          sync();
-          fprintf(stderr, "[chol_stream cycles] update %lld  factor %lld  solve %lld  write-back %lld  back-substitution %lld\n", st[0], st[1], st[2], st[3], st[4]);
-          chol_debug = false;
-        }
-        hipLaunchKernelGGL(k_chol_epilogue<T>, dim3(1), dim3(1024), 0, stream, Esys, C, n_sys, d_state.p, D2c.p, ps_lm(), delta_c.p,
-                           chol_sol.p, chol_info.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
-      } else {
-        hipLaunchKernelGGL((k_cholesky_solve<false, T>), dim3(1), dim3(CHOL_THREADS), 0, stream, Esys, C, d_state.p, D2c.p,
-                           ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
-      }
-      prof_end(KP_CHOL);
-    } else {
-      hipLaunchKernelGGL(k_nocam_step, dim3(1), dim3(64), 0, stream, d_state.p, E, n);
-      if (N > 0)
-        hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
-    }
-    if (sq_mode()) { launch_sq_trial(); return SBA_OK; }
-    prof_begin(KP_BACKSUB);
-    launch_backsub_trial();
-    prof_end(KP_BACKSUB);
-    if (scal)
-      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, n_trial_parts(), n_lin_parts(), d_state.p, scal);
-    return SBA_OK;
-  }
-
-  // enqueue the accept / reject / terminate kernel; nothing is read back
-  int lm_decide_async(const double* scal_all, int n_ranks) {
-    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
-    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(1024), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
-                       gmax_part.p, sq_mode() ? nblk_sq : n_trial_parts(), sq_mode() ? nblk_sq : n_lin_parts(), reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
-    pslot_advance();
-    return SBA_OK;
-  }
-
-  // read the state back (one sync); returns the scipy status or -1 while the solve is still running
-  int lm_poll(int32_t* status_out, int32_t* iterations_out) {
-    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
-    HIPCHK(hipMemcpyAsync(h_state, d_state.p, sizeof(LMState), hipMemcpyDeviceToHost, stream));
-    sync();
-    HIPCHK(hipGetLastError());
-    prof_collect();
-    const LMState& s = *h_state;
-    cur = cur_at_begin ^ (s.cur & 1);
-    const int have = std::min(s.iter, LOG_CAP);
-    if (have > log_read) {
-      log.resize(have);
-      HIPCHK(hipMemcpy(log.data() + log_read, d_log.p + log_read, sizeof(sba_lm_iter_log) * (have - log_read), hipMemcpyDeviceToHost));
-      log_read = have;
-    }
-    if (status_out) *status_out = s.status;
-    if (iterations_out) *iterations_out = s.iter;
-    return SBA_OK;
-  }
-
-  int lm_decide(const double* scal_all, int n_ranks, int32_t* status_out, int32_t* accepted_out, sba_lm_iter_log* row) {
-    int rc = lm_decide_async(scal_all, n_ranks);
-    if (rc) return rc;
-    int32_t st = -1, it = 0;
-    rc = lm_poll(&st, &it);
-    if (rc) return rc;
-    if (row && !log.empty()) *row = log.back();
-    if (status_out) *status_out = st;
-    if (accepted_out) *accepted_out = h_state->accepted;
-    return SBA_OK;
-  }
-
-  int lm_finish(double* cams_out, double* pts_out, sba_lm_report* rep) {
-    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
-    int32_t st = -1, it = 0;
-    int rc = lm_poll(&st, &it);          // refreshes `cur` and the log
-    if (rc) return rc;
-    push_ptrs();                         // table consistent with `cur` for the unconditional launches below
-    if (sq_mode()) {
-      launch_sq_linearize(nullptr);
-      double cost = 0, gmax = 0;
-      sq_read(cost, gmax);
-      if (opts.mode == SBA_MODE_TRANSFORM_SQ) {
-        HIPCHK(hipMemcpyAsync(h_theta, theta[cur].p, sizeof h_theta, hipMemcpyDeviceToHost, stream));
-        std::vector<double> X((size_t)N * 3);
-        HIPCHK(hipMemcpyAsync(X.data(), pts[cur].p, sizeof(double) * X.size(), hipMemcpyDeviceToHost, stream));
-        sync();
-        if (pts_out)
-          for (int p = 0; p < N; ++p)
-            for (int k = 0; k < 3; ++k)
-              pts_out[3 * (size_t)p + k] = h_theta[4 * k] * X[3 * (size_t)p] + h_theta[4 * k + 1] * X[3 * (size_t)p + 1] +
-                                           h_theta[4 * k + 2] * X[3 * (size_t)p + 2] + h_theta[4 * k + 3];
-      } else if (pts_out) {
-        HIPCHK(hipMemcpyAsync(pts_out, pts[cur].p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost, stream));
-      }
-      if (cams_out) HIPCHK(hipMemcpyAsync(cams_out, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
-      sync();
-      if (rep) {
-        const LMState& s = *h_state;
-        rep->cost = cost; rep->initial_cost = initial_cost; rep->optimality = gmax; rep->step_norm = s.step_norm;
-        rep->lambda = s.lam; rep->nfev = s.nfev; rep->njev = s.njev; rep->iterations = s.iter; rep->accepted = s.n_accepted;
-        rep->status = s.status < 0 ? 0 : s.status;
-      }
-      lm_active = false;
-      return SBA_OK;
-    }
-    // gradient norm at the returned point (scipy reports optimality there, trf.py:546-551)
-    launch_linearize_points(nullptr);
-    double gmax = 0;
-    std::vector<double> gm(nblk), cp(nblk);
-    if (nblk) {
-      HIPCHK(hipMemcpyAsync(gm.data(), gmax_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipMemcpyAsync(cp.data(), cost_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
-    }
-    std::vector<double> gch(n, 0.0);
-    if (h_state->free_cams) {
-      launch_linearize_cams(nullptr);
-      HIPCHK(hipMemcpyAsync(gch.data(), gc.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
-    } else {
-      gc.zero(stream);
-    }
-    if (cams_out) HIPCHK(hipMemcpyAsync(cams_out, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
-    if (pts_out) HIPCHK(hipMemcpyAsync(pts_out, pts[cur].p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost, stream));
-    sync();
-    HIPCHK(hipGetLastError());
-    double cost = 0;
-    for (int i = 0; i < nblk; ++i) { gmax = std::max(gmax, gm[i]); cost += cp[i]; }
-    if (opts.mode == SBA_MODE_SHARED_INTR && (int)h_tie.size() == n) {   // gradient in the tied unknowns
-      std::vector<double> gs(n_tied, 0.0);
-      for (int i = 0; i < n; ++i) gs[h_tie[i]] += gch[i];
-      for (double v : gs) gmax = std::max(gmax, std::fabs(v));
-    } else {
-      for (double v : gch) gmax = std::max(gmax, std::fabs(v));
-    }
-    if (rep) {
-      const LMState& s = *h_state;
-      rep->cost = cost; rep->initial_cost = initial_cost; rep->optimality = gmax; rep->step_norm = s.step_norm;
-      rep->lambda = s.lam; rep->nfev = s.nfev; rep->njev = s.njev; rep->iterations = s.iter; rep->accepted = s.n_accepted;
-      rep->status = s.status < 0 ? 0 : s.status;
-    }
-    lm_active = false;
-    return SBA_OK;
-  }
-
-  int solve(const sba_lm_opts* o, double* cams_out, double* pts_out, sba_lm_report* rep, sba_lm_iter_log* lg, int cap,
-            int32_t* rows) {
-    const auto t0 = std::chrono::steady_clock::now();
-    int rc = lm_begin(o);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(ev0, stream));
-    int32_t status = -1, iters = 0;
-    while (status < 0) {
-      // a batch of iterations is enqueued back to back; the kernels turn into no-ops once the device-side state says the
-      // solve has terminated, and a rejected step skips its re-linearization on the device, not on the host
-      int batch = prof_on ? 1 : BATCH;
-      if (o->max_iter > 0) batch = prof_on ? 1 : std::min(std::max(1, o->max_iter - iters), 64);
-      for (int b = 0; b < batch; ++b) {
-        lm_linearize();
-        lm_form_reduced(E_own.p);
-        lm_solve_trial(E_own.p, nullptr);
-        lm_decide_async(nullptr, 1);
-      }
-      rc = lm_poll(&status, &iters);
-      if (rc) return rc;
-    }
-    HIPCHK(hipEventRecord(ev1, stream));
-    HIPCHK(hipEventSynchronize(ev1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-    rc = lm_finish(cams_out, pts_out, rep);
-    if (rc) return rc;
-    if (rep) {
-      rep->status = status;
-      rep->seconds_device = ms * 1e-3;
-      rep->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    }
-    const int nrow = std::min<int>(cap, (int)log.size());
-    if (lg) for (int i = 0; i < nrow; ++i) lg[i] = log[i];
-    if (rows) *rows = (int32_t)log.size();
-    return SBA_OK;
-  }
-
-  // ------------------------------------------------------------------ measurement hook
-  int time_kernel(const char* name, int reps, double* mean_us) {
-    if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
-    HIPCHK(hipSetDevice(device));
-    const std::string k(name);
-    if (reps < 1) reps = 1;
-    // make sure everything the kernel reads exists
-    if (k == "resjac" && Jc_pm.n != (size_t)M * 22) { r_pm.alloc(M); Jc_pm.alloc((size_t)M * 22); Jp_pm.alloc((size_t)M * 6); }
-    if (k == "schur" || k == "backsub") {
-      sba_lm_opts o{}; o.ftol = o.xtol = o.gtol = 0; o.mode = SBA_MODE_FULL;
-      if (!lm_active) { int rc = lm_begin(&o); if (rc) return rc; }
-      lm_linearize(); lm_form_reduced(E_own.p); lm_solve_trial(E_own.p, scal_own.p);
-    } else {
-      push_ptrs();
-    }
-    auto once = [&]() {
-      if (k == "residual") launch_residual(nullptr);
-      else if (k == "resjac") launch_resjac(r_pm.p);
-      else if (k == "linearize_points") launch_linearize_points(nullptr);
-      else if (k == "linearize_cams") launch_linearize_cams(nullptr);
-      else if (k == "schur") launch_schur();
-      else if (k == "backsub") launch_backsub_trial();
-      else return false;
-      return true;
-    };
-    if (!once()) { err = "unknown kernel name"; return SBA_ERR_INVALID; }
-    sync();
-    HIPCHK(hipEventRecord(ev0, stream));
-    for (int i = 0; i < reps; ++i) once();
-    HIPCHK(hipEventRecord(ev1, stream));
-    HIPCHK(hipEventSynchronize(ev1));
-    HIPCHK(hipGetLastError());
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-    *mean_us = (double)ms * 1e3 / reps;
-    return SBA_OK;
-  }
-};
+// factories of the two engine translation units (sba_engine_ncp11.hip: the reference's 11-parameter radial camera,
+// sba_engine_ncp13.hip: 13 parameters, radial + tangential)
+sba_host::EngineBase* sba_make_engine_ncp11(int dtype);
+sba_host::EngineBase* sba_make_engine_ncp13(int dtype);
+int sba_rows_call_ncp11(int dtype, bool project, int device, int64_t n, const double* pts, const double* other, double* out);
+int sba_rows_call_ncp13(int dtype, bool project, int device, int64_t n, const double* pts, const double* other, double* out);
 
 // ============================================================================================== C ABI
 struct sba_handle {
@@ -1145,7 +29,8 @@ int guarded(sba_handle* h, F&& f) {
     return rc;
   } catch (const HipError& e) {
     char buf[512];
-    snprintf(buf, sizeof buf, "HIP error %d (%s) at sba_api.hip:%d: %s", (int)e.e, hipGetErrorString(e.e), e.line, e.what);
+    const char* base = strrchr(e.file, '/');
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e.e, hipGetErrorString(e.e), base ? base + 1 : e.file, e.line, e.what);
     if (h) h->err = buf; else g_last_error = buf;
     return SBA_ERR_HIP;
   } catch (const std::exception& e) {
@@ -1153,10 +38,6 @@ int guarded(sba_handle* h, F&& f) {
     return SBA_ERR_INVALID;
   }
 }
-
-#define DISPATCH(h, ...)                                                                    \
-  ((h)->dtype == SBA_F32 ? static_cast<Engine<float>*>((h)->eng.get())->__VA_ARGS__         \
-                         : static_cast<Engine<double>*>((h)->eng.get())->__VA_ARGS__)
 
 int check_device(int device) {
   int n = 0;
@@ -1169,23 +50,6 @@ int check_device(int device) {
     g_last_error = std::string("device is ") + p.gcnArchName + ", libsba_hip is built for gfx950 only";
     return SBA_ERR_NO_DEVICE;
   }
-  return SBA_OK;
-}
-
-template <typename T>
-int rows_call(bool project, int device, int64_t nrows, const double* pts, const double* other, double* out) {
-  HIPCHK(hipSetDevice(device));
-  if (nrows == 0) return SBA_OK;
-  const int64_t ow = project ? 11 : 3, rw = project ? 2 : 3;
-  DevBuf<double> d_pts, d_o, d_out;
-  d_pts.alloc(nrows * 3); d_o.alloc(nrows * ow); d_out.alloc(nrows * rw);
-  HIPCHK(hipMemcpy(d_pts.p, pts, sizeof(double) * nrows * 3, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_o.p, other, sizeof(double) * nrows * ow, hipMemcpyHostToDevice));
-  const int g = (int)((nrows + 255) / 256);
-  if (project) hipLaunchKernelGGL(k_project_rows<T>, dim3(g), dim3(256), 0, 0, d_pts.p, d_o.p, d_out.p, nrows);
-  else hipLaunchKernelGGL(k_rotate_rows<T>, dim3(g), dim3(256), 0, 0, d_pts.p, d_o.p, d_out.p, nrows);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(out, d_out.p, sizeof(double) * nrows * rw, hipMemcpyDeviceToHost));
   return SBA_OK;
 }
 
@@ -1203,37 +67,46 @@ int sba_device_count(void) {
 
 const char* sba_last_error(const sba_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 
+static int n_cam_params_of(int model) { return model == SBA_CAM_RADIAL_TANGENTIAL ? 13 : 11; }
+static int rows_dispatch(int ncp, int dtype, bool project, int device, int64_t n, const double* pts, const double* other, double* out) {
+  return ncp == 13 ? sba_rows_call_ncp13(dtype, project, device, n, pts, other, out)
+                   : sba_rows_call_ncp11(dtype, project, device, n, pts, other, out);
+}
+
 int sba_rotate(int device, int dtype, int64_t n, const double* points, const double* rot_vecs, double* out) {
   if (n < 0 || (n > 0 && (!points || !rot_vecs || !out))) { g_last_error = "null argument"; return SBA_ERR_INVALID; }
   int rc = check_device(device);
   if (rc) return rc;
-  return guarded(nullptr, [&] {
-    return dtype == SBA_F32 ? rows_call<float>(false, device, n, points, rot_vecs, out)
-                            : rows_call<double>(false, device, n, points, rot_vecs, out);
-  });
+  return guarded(nullptr, [&] { return rows_dispatch(11, dtype, false, device, n, points, rot_vecs, out); });
 }
 
 int sba_project(int device, int dtype, int64_t n, const double* points, const double* cam_rows, double* uv_out) {
+  return sba_project_model(device, dtype, SBA_CAM_RADIAL, n, points, cam_rows, uv_out);
+}
+
+int sba_project_model(int device, int dtype, int cam_model, int64_t n, const double* points, const double* cam_rows, double* uv_out) {
   if (n < 0 || (n > 0 && (!points || !cam_rows || !uv_out))) { g_last_error = "null argument"; return SBA_ERR_INVALID; }
+  if (cam_model != SBA_CAM_RADIAL && cam_model != SBA_CAM_RADIAL_TANGENTIAL) { g_last_error = "unknown camera model"; return SBA_ERR_INVALID; }
   int rc = check_device(device);
   if (rc) return rc;
-  return guarded(nullptr, [&] {
-    return dtype == SBA_F32 ? rows_call<float>(true, device, n, points, cam_rows, uv_out)
-                            : rows_call<double>(true, device, n, points, cam_rows, uv_out);
-  });
+  return guarded(nullptr, [&] { return rows_dispatch(n_cam_params_of(cam_model), dtype, true, device, n, points, cam_rows, uv_out); });
 }
 
 int sba_create(const sba_problem_desc* desc, sba_handle** out) {
   if (!desc || !out) { g_last_error = "null argument"; return SBA_ERR_INVALID; }
   *out = nullptr;
   if (desc->dtype != SBA_F64 && desc->dtype != SBA_F32) { g_last_error = "dtype must be SBA_F64 or SBA_F32"; return SBA_ERR_INVALID; }
+  if (desc->cam_model != SBA_CAM_RADIAL && desc->cam_model != SBA_CAM_RADIAL_TANGENTIAL) { g_last_error = "unknown camera model"; return SBA_ERR_INVALID; }
   int rc = check_device(desc->device);
   if (rc) return rc;
   auto h = std::make_unique<sba_handle>();
   h->dtype = desc->dtype;
   rc = guarded(nullptr, [&] {
-    if (desc->dtype == SBA_F32) { auto e = std::make_unique<Engine<float>>(); ArenaScope sc(&e->arena); e->init(*desc); h->eng = std::move(e); }
-    else { auto e = std::make_unique<Engine<double>>(); ArenaScope sc(&e->arena); e->init(*desc); h->eng = std::move(e); }
+    std::unique_ptr<EngineBase> e(desc->cam_model == SBA_CAM_RADIAL_TANGENTIAL ? sba_make_engine_ncp13(desc->dtype)
+                                                                                : sba_make_engine_ncp11(desc->dtype));
+    ArenaScope sc(&e->arena);
+    e->init(*desc);
+    h->eng = std::move(e);
     return (int)SBA_OK;
   });
   if (rc) return rc;
@@ -1251,130 +124,93 @@ int sba_upload(sba_handle* h, const double* cams, const double* points, const do
                const int64_t* pt_idx, const double* weights) {
   if (!h) return SBA_ERR_INVALID;
   if (!cams || !points || ((!uv || !cam_idx || !pt_idx))) { h->err = "null argument"; return SBA_ERR_INVALID; }
-  return guarded(h, [&] { return DISPATCH(h, upload(cams, points, uv, cam_idx, pt_idx, weights)); });
+  return guarded(h, [&] { return h->eng->upload(cams, points, uv, cam_idx, pt_idx, weights); });
 }
 
 int sba_set_params(sba_handle* h, const double* x) {
   if (!h || !x) return SBA_ERR_INVALID;
-  return guarded(h, [&] {
-    if (h->dtype == SBA_F32) { auto* e = static_cast<Engine<float>*>(h->eng.get()); if (!e->uploaded) { e->err = "not uploaded"; return (int)SBA_ERR_STATE; } e->set_params(x, x + (size_t)e->C * NCP); }
-    else { auto* e = static_cast<Engine<double>*>(h->eng.get()); if (!e->uploaded) { e->err = "not uploaded"; return (int)SBA_ERR_STATE; } e->set_params(x, x + (size_t)e->C * NCP); }
-    return (int)SBA_OK;
-  });
+  return guarded(h, [&] { return h->eng->set_params_x(x); });
 }
 
 int sba_get_params(sba_handle* h, double* cams_out, double* points_out) {
   if (!h) return SBA_ERR_INVALID;
-  return guarded(h, [&] {
-    auto get = [&](auto* e) {
-      if (!e->uploaded) { e->err = "not uploaded"; return (int)SBA_ERR_STATE; }
-      if (cams_out) HIPCHK(hipMemcpyAsync(cams_out, e->cams[e->cur].p, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
-      if (points_out) HIPCHK(hipMemcpyAsync(points_out, e->pts[e->cur].p, sizeof(double) * (size_t)e->N * 3, hipMemcpyDeviceToHost, e->stream));
-      e->sync();
-      return (int)SBA_OK;
-    };
-    return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
-  });
+  return guarded(h, [&] { return h->eng->get_params(cams_out, points_out); });
 }
 
 int sba_get_transform(sba_handle* h, double* theta12_out) {
   if (!h || !theta12_out) return SBA_ERR_INVALID;
-  auto get = [&](auto* e) { for (int i = 0; i < 12; ++i) theta12_out[i] = e->h_theta[i]; return (int)SBA_OK; };
-  return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
+  return h->eng->get_transform(theta12_out);
 }
 
 int sba_get_gradient(sba_handle* h, double* gc_out, double* gp_out) {
   if (!h) return SBA_ERR_INVALID;
-  return guarded(h, [&] {
-    auto get = [&](auto* e) {
-      if (!e->uploaded) { e->err = "not uploaded"; return (int)SBA_ERR_STATE; }
-      if (gc_out) HIPCHK(hipMemcpyAsync(gc_out, e->gc.p, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
-      if (gp_out) HIPCHK(hipMemcpyAsync(gp_out, e->gp.p, sizeof(double) * (size_t)e->N * 3, hipMemcpyDeviceToHost, e->stream));
-      e->sync();
-      return (int)SBA_OK;
-    };
-    return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
-  });
+  return guarded(h, [&] { return h->eng->get_gradient(gc_out, gp_out); });
 }
 
 int sba_residual(sba_handle* h, const double* x, double* r_out, double* cost_out) {
   if (!h) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, residual(x, r_out, cost_out)); });
+  return guarded(h, [&] { return h->eng->residual(x, r_out, cost_out); });
 }
 
 int sba_residual_jacobian(sba_handle* h, const double* x, double* r_out, double* Jc_out, double* Jp_out) {
   if (!h) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, residual_jacobian(x, r_out, Jc_out, Jp_out)); });
+  return guarded(h, [&] { return h->eng->residual_jacobian(x, r_out, Jc_out, Jp_out); });
 }
 
 int sba_solve_lm(sba_handle* h, const sba_lm_opts* opts, double* cams_out, double* points_out, sba_lm_report* report,
                  sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows) {
   if (!h || !opts) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, solve(opts, cams_out, points_out, report, log, log_capacity, log_rows)); });
+  return guarded(h, [&] { return h->eng->solve(opts, cams_out, points_out, report, log, log_capacity, log_rows); });
 }
 
-int64_t sba_lm_exchange_size(const sba_handle* h) {
-  if (!h) return 0;
-  return h->dtype == SBA_F32 ? static_cast<Engine<float>*>(h->eng.get())->exchange_size()
-                             : static_cast<Engine<double>*>(h->eng.get())->exchange_size();
-}
+int64_t sba_lm_exchange_size(const sba_handle* h) { return h ? h->eng->exchange_size() : 0; }
 
 int sba_lm_begin(sba_handle* h, const sba_lm_opts* opts) {
   if (!h || !opts) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, lm_begin(opts)); });
+  return guarded(h, [&] { return h->eng->lm_begin(opts); });
 }
 int sba_lm_linearize(sba_handle* h) {
   if (!h) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, lm_linearize()); });
+  return guarded(h, [&] { return h->eng->lm_linearize(); });
 }
 int sba_lm_form_reduced(sba_handle* h, double* exchange_dev) {
   if (!h || !exchange_dev) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, lm_form_reduced(exchange_dev)); });
+  return guarded(h, [&] { return h->eng->lm_form_reduced(exchange_dev); });
 }
 int sba_lm_solve_trial(sba_handle* h, const double* exchange_dev, double* scalars_dev) {
   if (!h || !exchange_dev || !scalars_dev) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, lm_solve_trial(const_cast<double*>(exchange_dev), scalars_dev)); });
+  return guarded(h, [&] { return h->eng->lm_solve_trial(const_cast<double*>(exchange_dev), scalars_dev); });
 }
 int sba_lm_decide(sba_handle* h, const double* scalars_all_dev, int32_t n_ranks, int32_t* status_out,
                   int32_t* accepted_out, sba_lm_iter_log* row_out) {
   if (!h || !scalars_all_dev || n_ranks < 1) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, lm_decide(scalars_all_dev, n_ranks, status_out, accepted_out, row_out)); });
+  return guarded(h, [&] { return h->eng->lm_decide(scalars_all_dev, n_ranks, status_out, accepted_out, row_out); });
 }
 int sba_lm_decide_async(sba_handle* h, const double* scalars_all_dev, int32_t n_ranks) {
   if (!h || n_ranks < 1 || (n_ranks > 1 && !scalars_all_dev)) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, lm_decide_async(scalars_all_dev, n_ranks)); });
+  return guarded(h, [&] { return h->eng->lm_decide_async(scalars_all_dev, n_ranks); });
 }
 int sba_lm_poll(sba_handle* h, int32_t* status_out, int32_t* iterations_out) {
   if (!h) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, lm_poll(status_out, iterations_out)); });
+  return guarded(h, [&] { return h->eng->lm_poll(status_out, iterations_out); });
 }
 int sba_lm_get_log(sba_handle* h, sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows) {
   if (!h || !log_rows) return SBA_ERR_INVALID;
-  auto get = [&](auto* e) {
-    const int nrow = std::min<int>(log_capacity, (int)e->log.size());
-    if (log) for (int i = 0; i < nrow; ++i) log[i] = e->log[i];
-    *log_rows = (int32_t)e->log.size();
-    return (int)SBA_OK;
-  };
-  return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
+  return h->eng->get_log(log, log_capacity, log_rows);
 }
 int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report) {
   if (!h) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, lm_finish(cams_out, points_out, report)); });
+  return guarded(h, [&] { return h->eng->lm_finish(cams_out, points_out, report); });
 }
 
 int sba_get_kernel_profile(sba_handle* h, double* total_us_out, int64_t* count_out) {
   if (!h || !total_us_out || !count_out) return SBA_ERR_INVALID;
-  auto get = [&](auto* e) {
-    for (int k = 0; k < SBA_PROFILE_SLOTS; ++k) { total_us_out[k] = e->prof_us[k]; count_out[k] = e->prof_cnt[k]; }
-    return (int)SBA_OK;
-  };
-  return h->dtype == SBA_F32 ? get(static_cast<Engine<float>*>(h->eng.get())) : get(static_cast<Engine<double>*>(h->eng.get()));
+  return h->eng->get_kernel_profile(total_us_out, count_out);
 }
 
 int sba_time_kernel(sba_handle* h, const char* name, int32_t reps, double* mean_us_out) {
   if (!h || !name || !mean_us_out) return SBA_ERR_INVALID;
-  return guarded(h, [&] { return DISPATCH(h, time_kernel(name, reps, mean_us_out)); });
+  return guarded(h, [&] { return h->eng->time_kernel(name, reps, mean_us_out); });
 }
 
 }  // extern "C"

@@ -22,7 +22,7 @@
 #pragma once
 #include "sba_chol_blocked.hpp"
 
-namespace sba {
+namespace SBA_NS {
 
 constexpr int BB = 64;                      // block edge of the big factorisation
 constexpr int BSUB = BB / CB;               // 4 sub-blocks of 16 per edge
@@ -272,4 +272,4 @@ __global__ __launch_bounds__(256) void k_chol_big_back(const double* __restrict_
   if (part == 0) yv[t * BB + i] -= (s_p[0][i] + s_p[1][i]) + (s_p[2][i] + s_p[3][i]);
 }
 
-}  // namespace sba
+}  // namespace SBA_NS

@@ -18,7 +18,7 @@
 #pragma once
 #include "sba_lm_kernels.hpp"
 
-namespace sba {
+namespace SBA_NS {
 
 constexpr int CB = 16;                 // block edge
 constexpr int CLD = 17;                // row stride inside a block (doubles)
@@ -586,4 +586,4 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_stream(
   if (tid == 0) *info = fail ? 1 : 0;
 }
 
-}  // namespace sba
+}  // namespace SBA_NS

@@ -21,16 +21,16 @@
 #include <utility>
 #include "sba_model.hpp"
 
-namespace sba {
+namespace SBA_NS {
 
 constexpr int PM_BLOCK = 256;      // threads (= max observations) of a point-major workgroup
 constexpr int CM_WAVE_OBS = 64;    // observations a wave turns into one 128-row MFMA tile
 constexpr int CM_CHUNK = 1024;     // observations per camera-major workgroup (256 threads x 4)
 constexpr int SCHUR_PTS = 16;      // points per panel chunk  (K = 48 panel rows)
 constexpr int SCHUR_K = 3 * SCHUR_PTS;
-constexpr int GROUP_CAMS = 16;     // cameras per Schur camera group: 16*11 = 176 = 11 MFMA tiles exactly
-constexpr int GROUP_ROWS = GROUP_CAMS * NCP;   // 176
-constexpr int GROUP_TILES = GROUP_ROWS / 16;   // 11
+constexpr int GROUP_CAMS = 16;     // cameras per Schur camera group: 16*11 = 176 = 11 MFMA tiles exactly (16*13 = 208 = 13 tiles)
+constexpr int GROUP_ROWS = GROUP_CAMS * NCP;   // 176 (208)
+constexpr int GROUP_TILES = GROUP_ROWS / 16;   // 11 (13)
 constexpr int NSCAL = 8;
 
 // Current / trial parameter buffers: both sets travel BY VALUE as a kernel argument (no extra dependent load), and
@@ -161,15 +161,21 @@ __global__ void k_project_rows(const double* __restrict__ pts, const double* __r
                                double* __restrict__ uv, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double* c = cam + 11 * i;
+  const double* c = cam + NCP * i;
   T P0, P1, P2;
   rotate_raw<T>((T)c[0], (T)c[1], (T)c[2], (T)pts[3 * i], (T)pts[3 * i + 1], (T)pts[3 * i + 2], P0, P1, P2);
   const T p0 = P0 + (T)c[3], p1 = P1 + (T)c[4], p2 = P2 + (T)c[5];
   const T x = p0 / p2, y = p1 / p2;
   const T nn = x * x + y * y;
   const T r = (T)1 + (T)c[7] * nn + (T)c[8] * nn * nn;
-  uv[2 * i] = x * (r * (T)c[6]) + (T)c[9];
-  uv[2 * i + 1] = y * (r * (T)c[6]) + (T)c[10];
+  if constexpr (TANGENTIAL) {
+    const T tp1 = (T)c[CP_P1], tp2 = (T)c[CP_P2], xy2 = (T)2 * x * y;
+    uv[2 * i] = (x * r + tp1 * xy2 + tp2 * (nn + (T)2 * x * x)) * (T)c[6] + (T)c[CP_CX];
+    uv[2 * i + 1] = (y * r + tp1 * (nn + (T)2 * y * y) + tp2 * xy2) * (T)c[6] + (T)c[CP_CY];
+  } else {
+    uv[2 * i] = x * (r * (T)c[6]) + (T)c[9];
+    uv[2 * i + 1] = y * (r * (T)c[6]) + (T)c[10];
+  }
 }
 
 // ------------------------------------------------------------------ K1: residual (+ cost partial)
@@ -214,7 +220,8 @@ __global__ __launch_bounds__(PM_BLOCK) void k_resjac(
     typename Vec2<T>::type* __restrict__ r_out, T* __restrict__ Jc_out, T* __restrict__ Jp_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* s_cam = reinterpret_cast<T*>(smem);
-  T* s_j = s_cam + ((C * CAMPRE + 3) & ~3);          // [256][29] (odd stride: conflict-free lane writes)
+  constexpr int JW = 2 * NCP + 6, JS = JW + 1;        // 28 (32) Jacobian values per observation, odd LDS stride 29 (33)
+  T* s_j = s_cam + ((C * CAMPRE + 3) & ~3);          // [256][JS] (odd stride: conflict-free lane writes)
   stage_campre(campre, s_cam, C);
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * PM_BLOCK;
@@ -229,20 +236,20 @@ __global__ __launch_bounds__(PM_BLOCK) void k_resjac(
     obs_resjac<T>(s_cam + c * CAMPRE, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2],
                   m.x, m.y, ww, r, Jc, Jp);
     if (r_out) { typename Vec2<T>::type rr; rr.x = r[0]; rr.y = r[1]; r_out[o] = rr; }
-    T* dst = s_j + threadIdx.x * 29;
+    T* dst = s_j + threadIdx.x * JS;
 #pragma unroll
     for (int k = 0; k < NCP; ++k) { dst[k] = Jc[0][k]; dst[NCP + k] = Jc[1][k]; }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { dst[22 + k] = Jp[0][k]; dst[25 + k] = Jp[1][k]; }
+    for (int k = 0; k < 3; ++k) { dst[2 * NCP + k] = Jp[0][k]; dst[2 * NCP + 3 + k] = Jp[1][k]; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nvalid * 22; i += PM_BLOCK) {
-    const int l = i / 22, k = i - l * 22;
-    Jc_out[base * 22 + i] = s_j[l * 29 + k];
+  for (int i = threadIdx.x; i < nvalid * 2 * NCP; i += PM_BLOCK) {
+    const int l = i / (2 * NCP), k = i - l * 2 * NCP;
+    Jc_out[base * 2 * NCP + i] = s_j[l * JS + k];
   }
   for (int i = threadIdx.x; i < nvalid * 6; i += PM_BLOCK) {
     const int l = i / 6, k = i - l * 6;
-    Jp_out[base * 6 + i] = s_j[l * 29 + 22 + k];
+    Jp_out[base * 6 + i] = s_j[l * JS + 2 * NCP + k];
   }
 }
 
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(1024) void k_reduce_cams(const double* __restrict__
   if (g == 0) {
     const double s = (s_p[0][e] + s_p[1][e]) + (s_p[2][e] + s_p[3][e]);
     const int i = e >> 4, j = e & 15;
-    if (i < NCP && j < NCP) U[(size_t)c * 121 + i * NCP + j] = s;
+    if (i < NCP && j < NCP) U[(size_t)c * NCP * NCP + i * NCP + j] = s;
     if (i < NCP && j == NCP) gc[(size_t)c * NCP + i] = s;
   }
 }
@@ -530,10 +537,10 @@ template <typename T, bool DIAG> struct SchurCfg {
   static constexpr int NTILE = DIAG ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : GROUP_TILES * GROUP_TILES;
   // tile split: the pair's tiles are dealt to TS workgroups (grid.z) so that a consumer wave never holds more than
   // ~17 f32 / ~9 f64 accumulator tiles (<= 72 VGPRs); every workgroup of a split still builds the whole panel
-  static constexpr int TS = DIAG ? (sizeof(T) == 8 ? 2 : 1) : (sizeof(T) == 8 ? 4 : 2);
+  static constexpr int TS = DIAG ? (sizeof(T) == 8 ? 2 : 1) : (sizeof(T) == 8 ? 4 : (NCP > 11 ? 3 : 2));
   static constexpr int NV = NCW * TS;                        // "virtual" consumer waves of a pair
   static constexpr int TPW = (NTILE + NV - 1) / NV;          // tiles per consumer wave: 17 / 9 / 16 / 8
-  static constexpr int PTS = (!DIAG && sizeof(T) == 8) ? 8 : 16;   // points per chunk (LDS budget: 2 buffers x panels)
+  static constexpr int PTS = (!DIAG && (sizeof(T) == 8 || NCP > 11)) ? 8 : 16;   // points per chunk (LDS budget: 2 buffers x panels)
   static constexpr int K = 3 * PTS;
   static constexpr int NPANEL = DIAG ? 1 : 2;
   static constexpr int BUF = NPANEL * K * GROUP_ROWS + K;    // one buffer: panel(s) + z   (in T)
@@ -576,10 +583,10 @@ template <typename T, bool DIAG> struct SchurSymCfg {
   static constexpr int THREADS = SCHUR_THREADS;
   static constexpr int NCW = THREADS / 64;                   // every wave consumes
   static constexpr int NTILE = DIAG ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : GROUP_TILES * GROUP_TILES;
-  static constexpr int TS = DIAG ? 1 : 2;
+  static constexpr int TS = (DIAG ? 1 : 2) * (NCP > 11 ? 2 : 1);
   static constexpr int NV = NCW * TS;
-  static constexpr int TPW = (NTILE + NV - 1) / NV;          // 9 / 8 tiles per wave
-  static constexpr int PTS = DIAG ? 32 : 16;                 // one single-buffered chunk: 96 (48+48) panel rows
+  static constexpr int TPW = (NTILE + NV - 1) / NV;          // 9 / 8 tiles per wave (13-parameter model: 6 / 6)
+  static constexpr int PTS = (DIAG ? 32 : 16) / (NCP > 11 ? 2 : 1);   // one single-buffered chunk: 96 (48+48) panel rows; 208-column panels: half
   static constexpr int K = 3 * PTS;
   static constexpr int NPANEL = DIAG ? 1 : 2;
   static constexpr int BUF = NPANEL * K * GROUP_ROWS + K;
@@ -588,6 +595,8 @@ template <typename T, bool DIAG> struct SchurSymCfg {
 
 // which flavour runs: f64 -> symmetric, f32 -> producer/consumer specialised
 template <typename T> constexpr bool SCHUR_SYM = sizeof(T) == 8;
+// the point linearisation rides in k_schur_sym (LIN) only when a chunk has one lane per (point, camera): 32 points x 16 cameras
+template <typename T> constexpr bool SCHUR_LIN_OK = SCHUR_SYM<T> && SchurSymCfg<T, true>::PTS == 32;
 template <typename T, bool DIAG> using SchurSel = std::conditional_t<SCHUR_SYM<T>, SchurSymCfg<T, DIAG>, SchurCfg<T, DIAG>>;
 
 // Consumer wave V of a pair owns the contiguous tile range [V*TPW, V*TPW+TPW): consecutive tiles share their row, so
@@ -952,7 +961,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
   // in k_schur_fused -- the point blocks V_p, g_p are DPP row sums, and scaling, damped factor and z follow in
   // registers, so k_linearize_points and k_point_factor are not launched (f64 keeps k_linearize_cams: 77 f64
   // accumulators per lane do not fit beside the MFMA tiles).
-  static_assert(!LIN || DIAG, "the fused point linearisation needs the one-group diagonal pair");
+  static_assert(!LIN || (DIAG && PTS == 32), "the fused point linearisation needs the one-group diagonal pair and 32-point chunks");
   const int lq = threadIdx.x >> 4, lc = threadIdx.x & 15;
   const bool cam_ok = lc < C;
   const double lam = st->lam;
@@ -1114,6 +1123,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
   }
 }
 
+#if SBA_NCP == 11
 // ------------------------------------------------------------------ K3+K4 fused (dense visibility, <= 16 cameras, f32)
 // When every point is seen by every camera and there is one camera group, the producer lane (q, c) = (point of the
 // chunk, camera) meets the same camera in every chunk, and the 16 lanes of a DPP row hold all observations of one
@@ -1362,4 +1372,6 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
   }
 }
 
-}  // namespace sba
+#endif  // SBA_NCP == 11 (fused linearise + Schur kernel)
+
+}  // namespace SBA_NS

@@ -7,7 +7,7 @@
 #include <cstddef>
 #include "sba_kernels.hpp"
 
-namespace sba {
+namespace SBA_NS {
 
 constexpr int CHOL_THREADS = 1024;
 constexpr int CHOL_LDS_MAX_N = 176;    // packed lower triangle of 176x176 doubles = 124.6 KB of the 160 KB LDS
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
 #pragma unroll
       for (int q = 0; q < NG; ++q) s += s_p[q][l16];
       double v = -s;                 // fused linearisation: the slabs already hold (Schur partials - U)
-      if (!gdpart && ci_ == cj_) v += U[(size_t)ci_ * 121 + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
+      if (!gdpart && ci_ == cj_) v += U[(size_t)ci_ * NCP * NCP + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
       E[(size_t)i * n + j] = v;
       if (!(diag && R == Tc)) E[(size_t)j * n + i] = v;
     }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
       } else {
         const int c = i / NCP, e = i - c * NCP;
         rhs[i] = -gc[i] + bs;
-        dU[i] = U[(size_t)c * 121 + e * NCP + e];
+        dU[i] = U[(size_t)c * NCP * NCP + e * NCP + e];
         gv[i] = gc[i];
       }
     }
@@ -698,4 +698,4 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* st,
   gst->status = status;
 }
 
-}  // namespace sba
+}  // namespace SBA_NS

@@ -12,19 +12,34 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-namespace sba {
+// Camera model selection: the whole device code base is compiled once per model into its own namespace.
+#ifndef SBA_NCP
+#define SBA_NCP 11
+#endif
+#if SBA_NCP == 11
+#define SBA_NS sba11
+#elif SBA_NCP == 13
+#define SBA_NS sba13
+#else
+#error "SBA_NCP must be 11 (radial) or 13 (radial + tangential)"
+#endif
 
-constexpr int NCP = 11;          // camera parameters per camera (pySBA.py:31-35)
-constexpr int CAMPRE = 25;       // CamPre row length (odd stride => LDS reads of different cameras spread over banks)
+namespace SBA_NS {
+
+constexpr int NCP = SBA_NCP;     // camera parameters per camera: 11 (pySBA.py:31-35) or 13 (+ tangential p1, p2 before cx, cy)
+constexpr bool TANGENTIAL = (NCP == 13);
+constexpr int CAMPRE = NCP + 14; // CamPre row length (odd stride => LDS reads of different cameras spread over banks)
 // CamPre row layout
 constexpr int CP_RHO = 0;        // rho[3]
 constexpr int CP_T = 3;          // t[3]
-constexpr int CP_F = 6, CP_K1 = 7, CP_K2 = 8, CP_CX = 9, CP_CY = 10;
-constexpr int CP_R = 11;         // R[9] row-major
-constexpr int CP_A = 20, CP_B = 21, CP_A2 = 22, CP_B2 = 23;   // sin t/t, (1-cos t)/t^2, (cos t - a)/t^2, (a-2b)/t^2
-constexpr int CP_PAD = 24;
+constexpr int CP_F = 6, CP_K1 = 7, CP_K2 = 8;
+constexpr int CP_P1 = 9, CP_P2 = 10;               // tangential model only
+constexpr int CP_CX = NCP - 2, CP_CY = NCP - 1;
+constexpr int CP_R = NCP;        // R[9] row-major
+constexpr int CP_A = NCP + 9, CP_B = NCP + 10, CP_A2 = NCP + 11, CP_B2 = NCP + 12;   // sin t/t, (1-cos t)/t^2, (cos t - a)/t^2, (a-2b)/t^2
+constexpr int CP_PAD = NCP + 13;
 
-// Build one CamPre row from the 11 raw parameters (always evaluated in double, then narrowed).
+// Build one CamPre row from the NCP raw parameters (always evaluated in double, then narrowed).
 template <typename T>
 __device__ inline void campre_build(const double* __restrict__ cam, T* __restrict__ out) {
   const double r0 = cam[0], r1 = cam[1], r2 = cam[2];
@@ -74,14 +89,22 @@ __device__ inline void obs_project(const T* __restrict__ cp, T X0, T X1, T X2, T
   const T x = p0 * iz, y = p1 * iz;
   const T n = x * x + y * y;
   const T d = (T)1 + n * (cp[CP_K1] + cp[CP_K2] * n);
-  const T fd = cp[CP_F] * d;
-  u = fd * x + cp[CP_CX];
-  v = fd * y + cp[CP_CY];
+  if constexpr (TANGENTIAL) {      // OpenCV convention: x' = x d + 2 p1 x y + p2 (n + 2 x^2), y' = y d + p1 (n + 2 y^2) + 2 p2 x y
+    const T tp1 = cp[CP_P1], tp2 = cp[CP_P2], xy2 = (T)2 * x * y;
+    const T xd = d * x + tp1 * xy2 + tp2 * (n + (T)2 * x * x);
+    const T yd = d * y + tp1 * (n + (T)2 * y * y) + tp2 * xy2;
+    u = cp[CP_F] * xd + cp[CP_CX];
+    v = cp[CP_F] * yd + cp[CP_CY];
+  } else {
+    const T fd = cp[CP_F] * d;
+    u = fd * x + cp[CP_CX];
+    v = fd * y + cp[CP_CY];
+  }
 }
 
 // Residual + Jacobian blocks of one observation.
 //   r[2]      = w * (project - uv)
-//   Jc[2][11] = d r / d(cam params),  Jp[2][3] = d r / d X
+//   Jc[2][NCP] = d r / d(cam params),  Jp[2][3] = d r / d X
 template <typename T>
 __device__ inline void obs_resjac(const T* __restrict__ cp, T X0, T X1, T X2, T uo, T vo, T w,
                                   T r[2], T Jc[2][NCP], T Jp[2][3]) {
@@ -97,14 +120,26 @@ __device__ inline void obs_resjac(const T* __restrict__ cp, T X0, T X1, T X2, T 
   const T k1 = cp[CP_K1], k2 = cp[CP_K2], f = cp[CP_F];
   const T d = (T)1 + n * (k1 + k2 * n);
   const T dn = k1 + (T)2 * k2 * n;
-  r[0] = w * (f * d * x + cp[CP_CX] - uo);
-  r[1] = w * (f * d * y + cp[CP_CY] - vo);
-
   // A = w * d(u,v)/dp
   const T wf = w * f;
-  const T ux = wf * (d + (T)2 * x * x * dn);
-  const T uy = wf * ((T)2 * x * y * dn);
-  const T vy = wf * (d + (T)2 * y * y * dn);
+  T gxx = d + (T)2 * x * x * dn, gxy = (T)2 * x * y * dn, gyy = d + (T)2 * y * y * dn;     // d(xd,yd)/d(x,y), symmetric
+  T xd = x, yd = y;                         // tangential model: the distorted normalised coordinates
+  if constexpr (TANGENTIAL) {
+    const T tp1 = cp[CP_P1], tp2 = cp[CP_P2], xy2 = (T)2 * x * y;
+    xd = d * x + tp1 * xy2 + tp2 * (n + (T)2 * x * x);
+    yd = d * y + tp1 * (n + (T)2 * y * y) + tp2 * xy2;
+    gxx += (T)2 * tp1 * y + (T)6 * tp2 * x;
+    gxy += (T)2 * (tp1 * x + tp2 * y);
+    gyy += (T)6 * tp1 * y + (T)2 * tp2 * x;
+    r[0] = w * (f * xd + cp[CP_CX] - uo);
+    r[1] = w * (f * yd + cp[CP_CY] - vo);
+  } else {                                  // the reference's model, operation order unchanged since round 1
+    r[0] = w * (f * d * x + cp[CP_CX] - uo);
+    r[1] = w * (f * d * y + cp[CP_CY] - vo);
+  }
+  const T ux = wf * gxx;
+  const T uy = wf * gxy;
+  const T vy = wf * gyy;
   const T A00 = ux * iz, A01 = uy * iz, A02 = -(ux * x + uy * y) * iz;
   const T A10 = uy * iz, A11 = vy * iz, A12 = -(uy * x + vy * y) * iz;
 
@@ -140,12 +175,18 @@ __device__ inline void obs_resjac(const T* __restrict__ cp, T X0, T X1, T X2, T 
     Jc[rr][4] = a1;
     Jc[rr][5] = a2r;
   }
-  const T wd = w * d, wfn = wf * n;
-  Jc[0][6] = wd * x;        Jc[1][6] = wd * y;
+  const T wfn = wf * n;
+  if constexpr (TANGENTIAL) { Jc[0][6] = w * xd; Jc[1][6] = w * yd; }
+  else { const T wd = w * d; Jc[0][6] = wd * x; Jc[1][6] = wd * y; }
   Jc[0][7] = wfn * x;       Jc[1][7] = wfn * y;
   Jc[0][8] = wfn * n * x;   Jc[1][8] = wfn * n * y;
-  Jc[0][9] = w;             Jc[1][9] = (T)0;
-  Jc[0][10] = (T)0;         Jc[1][10] = w;
+  if constexpr (TANGENTIAL) {
+    const T xy2 = (T)2 * x * y;
+    Jc[0][CP_P1] = wf * xy2;                     Jc[1][CP_P1] = wf * (n + (T)2 * y * y);
+    Jc[0][CP_P2] = wf * (n + (T)2 * x * x);      Jc[1][CP_P2] = wf * xy2;
+  }
+  Jc[0][CP_CX] = w;         Jc[1][CP_CX] = (T)0;
+  Jc[0][CP_CY] = (T)0;      Jc[1][CP_CY] = w;
 }
 
 __device__ inline void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
@@ -174,4 +215,4 @@ __device__ inline void rotate_raw(T h0, T h1, T h2, T X0, T X1, T X2, T& P0, T& 
   P2 = c * X2 + a * (h0 * X1 - h1 * X0) + hd * h2;
 }
 
-}  // namespace sba
+}  // namespace SBA_NS

@@ -8,7 +8,7 @@
 #pragma once
 #include "sba_lm_kernels.hpp"
 
-namespace sba {
+namespace SBA_NS {
 
 constexpr int SQ_CHUNK = 1024;     // observations per workgroup of the transform-variant linearize
 
@@ -234,4 +234,4 @@ __global__ __launch_bounds__(PM_BLOCK) void k_sq_trial(
   }
 }
 
-}  // namespace sba
+}  // namespace SBA_NS

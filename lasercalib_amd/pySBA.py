@@ -8,6 +8,10 @@ projection, analytic Jacobian blocks and the whole Levenberg-Marquardt / Schur-c
 loop execute in libsba_hip.so on the GPU (see include/sba_hip.h).  There is no CPU path in
 this module: without the shared library or without a gfx950 device the methods raise.
 
+Extension beyond the reference: a cameraArray with 13 columns, [rvec(3), t(3), f, k1, k2, p1, p2, cx, cy], selects the
+radial + tangential camera model (BASELINE config 5; the reference's model is radial only, pySBA.py:82-88).  Every method
+below then works on 13-parameter rows; with the reference's 11 columns nothing changes.
+
 Environment knobs (the script itself stays unchanged):
   LASERCALIB_SBA_DTYPE   f64 (default) | f32   arithmetic type of the per-observation math
   LASERCALIB_SBA_DEVICE  HIP device ordinal (default: LOCAL_RANK or 0)
@@ -111,6 +115,11 @@ class PySBA:
         self.pointWeights = pointWeights.reshape((-1, 1))
         self.points3Dfixed_labeled = None
 
+    @property
+    def _P(self):
+        """Camera parameters per camera: 11 (the reference's row, pySBA.py:31-35) or 13 (with tangential p1, p2)."""
+        return int(np.shape(self.cameraArray)[1]) if np.ndim(self.cameraArray) == 2 else N_CAM_PARAMS
+
     # ------------------------------------------------------------------ model (GPU kernels, numpy in/out)
     def rotate(self, points, rot_vecs):
         """Rodrigues rotation of (M,3) points by (M,3) rotation vectors (pySBA.py:61-73)."""
@@ -122,7 +131,7 @@ class PySBA:
 
     def fun(self, params, n_cameras, n_points, camera_indices, point_indices, points_2d, pointWeights):
         """Weighted residual vector, interleaved (u,v) per observation (pySBA.py:92-101)."""
-        nCamParams = N_CAM_PARAMS
+        nCamParams = self._P
         camera_params = params[:n_cameras * nCamParams].reshape((n_cameras, nCamParams))
         points_3d = params[n_cameras * nCamParams:].reshape((n_points, 3))
         points_proj = self.project(points_3d[point_indices], camera_params[camera_indices])
@@ -130,11 +139,12 @@ class PySBA:
 
     def bundle_adjustment_sparsity(self, numCameras, numPoints, cameraIndices, pointIndices):
         """Jacobian pattern of `fun`: 28 ones per observation (pySBA.py:103-118), as a lil_matrix of int."""
+        P = self._P
         m = cameraIndices.size * 2
-        n = numCameras * N_CAM_PARAMS + numPoints * 3
+        n = numCameras * P + numPoints * 3
         obs = np.arange(cameraIndices.size)
-        cols = np.concatenate([cameraIndices[:, None] * N_CAM_PARAMS + np.arange(N_CAM_PARAMS)[None, :],
-                               numCameras * N_CAM_PARAMS + pointIndices[:, None] * 3 + np.arange(3)[None, :]], axis=1)
+        cols = np.concatenate([cameraIndices[:, None] * P + np.arange(P)[None, :],
+                               numCameras * P + pointIndices[:, None] * 3 + np.arange(3)[None, :]], axis=1)
         rows = np.repeat(2 * obs, cols.shape[1])
         cols = cols.ravel()
         rows = np.concatenate([rows, rows + 1])
@@ -146,8 +156,9 @@ class PySBA:
 
     def optimizedParams(self, params, n_cameras, n_points):
         """Split x into (n_cameras,11) and (n_points,3) views (pySBA.py:121-129)."""
-        camera_params = params[:n_cameras * N_CAM_PARAMS].reshape((n_cameras, N_CAM_PARAMS))
-        points_3d = params[n_cameras * N_CAM_PARAMS:].reshape((n_points, 3))
+        P = self._P
+        camera_params = params[:n_cameras * P].reshape((n_cameras, P))
+        points_3d = params[n_cameras * P:].reshape((n_points, 3))
         return camera_params, points_3d
 
     # ------------------------------------------------------------------ solvers
@@ -175,7 +186,7 @@ class PySBA:
         if mode == _native.MODE_POINTS_ONLY:
             x = pts_opt.ravel().copy()
         elif mode == _native.MODE_SHARED_INTR:      # parameter order of pySBA.py:313
-            x = np.hstack((cams_opt[0, 6:9], cams_opt[:, :6].ravel(), cams_opt[:, 9:].ravel(), pts_opt.ravel()))
+            x = np.hstack((cams_opt[0, 6:9], cams_opt[:, :6].ravel(), cams_opt[:, 9:].ravel(), pts_opt.ravel()))   # 13-parameter rows: the tail is [p1, p2, cx, cy]
         else:
             x = np.hstack((cams_opt.ravel(), pts_opt.ravel()))
         message = TERMINATION_MESSAGES[rep.status]
@@ -246,7 +257,7 @@ class PySBA:
     # -- variants whose residual is defined on other parameterisations --------------------------
     def fun_camonly(self, params, n_cameras, n_points, camera_indices, point_indices, points_2d, pointWeights, points_3d):
         """Cameras-only residual; squares the pixel error like the reference (pySBA.py:151-156)."""
-        camera_params = params.reshape(n_cameras, N_CAM_PARAMS)
+        camera_params = params.reshape(n_cameras, self._P)
         points_proj = self.project(points_3d[point_indices], camera_params[camera_indices])
         return (pointWeights * (points_proj - points_2d) ** 2).ravel()
 
@@ -261,7 +272,7 @@ class PySBA:
 
     def fun_sharedcam(self, params, n_cameras, n_points, camera_indices, point_indices, points_2d, pointWeights):
         """Shared (f,k1,k2) parameterisation (pySBA.py:277-295)."""
-        nI, nE, nC = 3, 6, 2
+        nI, nE, nC = 3, 6, self._P - 9
         nCamParams = n_cameras * (nE + nC) + nI
         shared = params[:nI]
         extr = params[nI:nI + n_cameras * nE].reshape((n_cameras, nE))
@@ -273,7 +284,7 @@ class PySBA:
 
     def bundle_adjustment_sparsity_sharedcam(self, numCameras, numPoints, cameraIndices, pointIndices):
         """pySBA.py:252-275."""
-        nI, nE, nC = 3, 6, 2
+        nI, nE, nC = 3, 6, self._P - 9
         nCamParams = numCameras * (nE + nC) + nI
         obs = np.arange(cameraIndices.size)
         cols = np.concatenate([
@@ -356,23 +367,24 @@ def assemble_jacobian(Jc, Jp, cam_idx, pt_idx, n_cams, n_pts, points_only=False,
     """Blocks (M,2,11)/(M,2,3) -> the CSR matrix scipy would return as ``res.jac`` (pySBA.py:110-116 layout;
     pySBA.py:252-275 column layout for the shared-intrinsics variant)."""
     M = cam_idx.shape[0]
+    P = Jc.shape[2]                      # 11, or 13 with tangential distortion
     if shared_intrinsics:
-        ncp = 3 + 8 * n_cams
-        e = np.arange(N_CAM_PARAMS)
+        ncp = 3 + (P - 3) * n_cams
+        e = np.arange(P)
         ccol = np.where(e[None, :] < 6, 3 + 6 * cam_idx[:, None] + e[None, :],
-                        np.where(e[None, :] < 9, e[None, :] - 6, 3 + 6 * n_cams + 2 * cam_idx[:, None] + (e[None, :] - 9)))
+                        np.where(e[None, :] < 9, e[None, :] - 6, 3 + 6 * n_cams + (P - 9) * cam_idx[:, None] + (e[None, :] - 9)))
         cols = np.concatenate([ccol, ncp + pt_idx[:, None] * 3 + np.arange(3)[None, :]], axis=1)
-        data = np.concatenate([Jc, Jp], axis=2).reshape(2 * M, 14)
-        width, ncol = 14, ncp + n_pts * 3
+        data = np.concatenate([Jc, Jp], axis=2).reshape(2 * M, P + 3)
+        width, ncol = P + 3, ncp + n_pts * 3
     elif points_only:
         cols = (pt_idx[:, None] * 3 + np.arange(3)[None, :])
         data = Jp.reshape(2 * M, 3)
         width, ncol = 3, n_pts * 3
     else:
-        cols = np.concatenate([cam_idx[:, None] * N_CAM_PARAMS + np.arange(N_CAM_PARAMS)[None, :],
-                               n_cams * N_CAM_PARAMS + pt_idx[:, None] * 3 + np.arange(3)[None, :]], axis=1)
-        data = np.concatenate([Jc, Jp], axis=2).reshape(2 * M, 14)
-        width, ncol = 14, n_cams * N_CAM_PARAMS + n_pts * 3
+        cols = np.concatenate([cam_idx[:, None] * P + np.arange(P)[None, :],
+                               n_cams * P + pt_idx[:, None] * 3 + np.arange(3)[None, :]], axis=1)
+        data = np.concatenate([Jc, Jp], axis=2).reshape(2 * M, P + 3)
+        width, ncol = P + 3, n_cams * P + n_pts * 3
     cols = np.repeat(cols[:, None, :], 2, axis=1).reshape(2 * M, width)
     indptr = np.arange(0, 2 * M * width + 1, width)
     return csr_matrix((data.ravel(), cols.ravel(), indptr), shape=(2 * M, ncol))

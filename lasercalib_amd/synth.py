@@ -53,12 +53,20 @@ def _project_np(points, cams):
     xy = p[:, :2] / p[:, 2:3]
     n = np.sum(xy * xy, axis=1)
     r = 1 + cams[:, 7] * n + cams[:, 8] * n * n
+    if cams.shape[1] == 13:      # radial + tangential rows [.., k1, k2, p1, p2, cx, cy] (OpenCV convention)
+        p1, p2, x, y = cams[:, 9], cams[:, 10], xy[:, 0], xy[:, 1]
+        xd = x * r + 2 * p1 * x * y + p2 * (n + 2 * x * x)
+        yd = y * r + p1 * (n + 2 * y * y) + 2 * p2 * x * y
+        return np.stack([xd, yd], axis=1) * cams[:, 6][:, None] + cams[:, 11:13]
     return xy * (r * cams[:, 6])[:, None] + cams[:, 9:11]
 
 
 def make_rig(n_cams, n_points, seed=0, visibility=1.0, noise_px=0.3,
-             min_cams_per_point=2, perturb=True):
+             min_cams_per_point=2, perturb=True, tangential=False):
     """Return a dict with truth, initial guess and the observation list.
+
+    tangential=True: 13-parameter camera rows [rvec, t, f, k1, k2, p1, p2, cx, cy] with p1, p2 ~ N(0, 1e-3)
+    (BASELINE config 5 / SURVEY 8d; the initial guess starts them at zero, as a calibration without that term would).
 
     keys: cams_true, pts_true, cams0, pts0 (float64), points_2d (M,2) float64,
           camera_ind (M,) int64, point_ind (M,) int64 (non-decreasing).
@@ -77,6 +85,9 @@ def make_rig(n_cams, n_points, seed=0, visibility=1.0, noise_px=0.3,
     cams[:, 8] = rng.normal(0.0, 1e-2, C)
     cams[:, 9] = rng.normal(1604.0, 10.0, C)
     cams[:, 10] = rng.normal(1100.0, 10.0, C)
+    if tangential:               # drawn after everything the 11-parameter recipe draws at this point: same rig otherwise
+        tp = np.random.default_rng(seed + 7919).normal(0.0, 1e-3, (C, 2))
+        cams = np.hstack([cams[:, :9], tp, cams[:, 9:11]])
 
     pts = np.empty((N, 3))
     pts[:, 0:2] = rng.uniform(-700.0, 700.0, (N, 2))
@@ -100,6 +111,8 @@ def make_rig(n_cams, n_points, seed=0, visibility=1.0, noise_px=0.3,
 
     cams0 = cams.copy()
     pts0 = pts.copy()
+    if tangential:
+        cams0[:, 9:11] = 0.0
     if perturb:
         cams0[:, 0:3] += rng.normal(0.0, 5e-3, (C, 3))
         cams0[:, 3:6] += rng.normal(0.0, 5.0, (C, 3))

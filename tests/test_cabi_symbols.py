@@ -33,7 +33,7 @@ def test_header_symbols_all_exported(lib):
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/sba_hip.h but not exported by libsba_hip.so"
     assert set(names) == set(_native.EXPORTED_SYMBOLS)
-    assert lib.sba_abi_version() == 1
+    assert lib.sba_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

@@ -162,3 +162,23 @@ def test_report_helpers_cpu():
     np.testing.assert_allclose(ex[0, :3, :3], r_f)
     np.testing.assert_allclose(ex[0, :3, 3], -r_f @ Stub.cameraArray[0, 3:6])
     assert "cx" in report.camera_table(Stub()).splitlines()[0]
+
+
+def test_tangential_rows_export_p1_p2(tmp_path):
+    """13-parameter rows (extension): p1, p2 travel through the readable dict, the 25-column table and the YAML, in OpenCV's
+    [k1, k2, p1, p2, k3] order; upstream writes zeros there (convert_params.py:110) and 11-parameter rows still do."""
+    from lasercalib_amd import convert_params as cp
+    row11 = np.array([0.1, -0.2, 0.3, 10.0, 20.0, 1500.0, 2400.0, 1e-3, -2e-2, 1604.0, 1100.0])
+    row13 = np.concatenate([row11[:9], [4e-4, -7e-4], row11[9:]])
+    a, b = cp.sba_to_readable_format(row11), cp.sba_to_readable_format(row13)
+    assert "p" not in a and np.array_equal(b["p"], [4e-4, -7e-4])
+    assert np.array_equal(a["K"], b["K"]) and np.array_equal(a["R"], b["R"]) and np.array_equal(a["d"], b["d"])
+    red = cp.readable_to_red_format([a, b])
+    assert np.array_equal(red[0, 21:25], [1e-3, -2e-2, 0, 0]) and np.array_equal(red[1, 21:25], [1e-3, -2e-2, 4e-4, -7e-4])
+    cp.readable_format_to_aruco_format(str(tmp_path) + "/", 2, [a, b], ["A", "B"])
+    da = cp.read_opencv_yaml(str(tmp_path / "A.yaml"))["distortion_coefficients"].ravel()
+    db = cp.read_opencv_yaml(str(tmp_path / "B.yaml"))["distortion_coefficients"].ravel()
+    assert np.allclose(da, [1e-3, -2e-2, 0, 0, 0]) and np.allclose(db, [1e-3, -2e-2, 4e-4, -7e-4, 0])
+    back = cp.initialize_from_checkerboard(str(tmp_path), 1, ["B"], tangential=True)
+    assert back.shape == (1, 13) and np.allclose(back[0, 6:], row13[6:], rtol=1e-12) and np.allclose(back[0, 3:6], row13[3:6])
+    assert cp.initialize_from_checkerboard(str(tmp_path), 1, ["B"]).shape == (1, 11)

@@ -97,17 +97,19 @@ def test_indefinite_big_system_is_a_rejected_step_not_a_crash():
     assert np.array_equal(cams[5], rig["cams0"][5])         # zero gradient, unit scale: the camera never moves
 
 
-@pytest.mark.parametrize("C,N", [(64, 25000), (128, 125000)])
-def test_per_gpu_shares_of_configs_4_and_5(C, N):
-    """fp32, full visibility: one GPU's share of BASELINE config 4 (64 x 200k / 8) and config 5 (128 x 1M / 8, radial model)."""
-    rig = make_rig(C, N, seed=0)
+@pytest.mark.parametrize("C,N,tangential", [(64, 25000, False), (128, 125000, False), (128, 125000, True)])
+def test_per_gpu_shares_of_configs_4_and_5(C, N, tangential):
+    """fp32, full visibility: one GPU's share of BASELINE config 4 (64 x 200k / 8) and of config 5 (128 x 1M / 8) with the
+    reference's radial model and with the radial + tangential model config 5 names (13 parameters: 1664 camera unknowns)."""
+    from oracle import sba_oracle_tangential as orc13
+    rig = make_rig(C, N, seed=0, tangential=tangential)
     M = rig["camera_ind"].size
     with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], dtype="f32") as prob:
         r0, c0 = prob.residual()
         cams, pts, rep, log = prob.solve_lm(prob.make_opts(ftol=1e-4))
         r1, c1 = prob.residual(np.hstack((cams.ravel(), pts.ravel())))
     idx = np.random.default_rng(0).choice(M, 5000, replace=False)
-    ref = orc.project(rig["pts0"][rig["point_ind"][idx]], rig["cams0"][rig["camera_ind"][idx]]) - rig["points_2d"][idx]
+    ref = (orc13 if tangential else orc).project(rig["pts0"][rig["point_ind"][idx]], rig["cams0"][rig["camera_ind"][idx]]) - rig["points_2d"][idx]
     assert np.max(np.abs(r0.reshape(-1, 2)[idx] - ref)) <= 5e-3
     assert rep.status == 2 and rep.cost < 1e-3 * c0
     costs = [row.cost for row in log if row.accepted]
@@ -115,6 +117,8 @@ def test_per_gpu_shares_of_configs_4_and_5(C, N):
     assert abs(c1 - rep.cost) <= 1e-4 * c1
     rms = np.sqrt(np.mean(np.sum(r1.reshape(-1, 2) ** 2, axis=1)))
     assert 0.38 < rms < 0.45                                  # 0.3 px noise per axis
-    _, ratios = orc.gauge_invariants(cams)
-    _, ratios_t = orc.gauge_invariants(rig["cams_true"])
+    _, ratios = orc.gauge_invariants(cams[:, :11])         # camera centres only: columns 0..5
+    _, ratios_t = orc.gauge_invariants(rig["cams_true"][:, :11])
     assert np.max(np.abs(ratios - ratios_t)) <= 1e-3
+    if tangential:
+        assert np.max(np.abs(cams[:, 9:11] - rig["cams_true"][:, 9:11])) <= 1e-4     # 125k points per camera pin p1, p2

@@ -1,0 +1,107 @@
+"""GPU parity of the 13-parameter camera model (radial + tangential distortion, BASELINE config 5).
+
+The reference has no tangential term (pySBA.py:82-88), so this extension is NOT pinnable to reference output; the oracle is
+oracle/sba_oracle_tangential.py = the reference's model (bit-identical for p1 = p2 = 0, tests/test_oracle_golden.py) plus
+OpenCV's tangential term, driven by the reference's least_squares call.  Bars: fp64 residual / projection <= 1e-9 px;
+analytic 2x13 / 2x3 blocks vs the oracle's scipy 3-point finite differences <= 1e-6 relative to max|J|; converged cost
+one-sided vs scipy at the same ftol (as tests/test_gpu_parity.py), fp32 cost within 1e-4 of it.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from lasercalib_amd import _native  # noqa: E402
+from lasercalib_amd.pySBA import PySBA, assemble_jacobian  # noqa: E402
+from lasercalib_amd.synth import make_rig  # noqa: E402
+from oracle import sba_oracle as orc11  # noqa: E402
+from oracle import sba_oracle_tangential as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert _native.device_count() > 0, "no HIP device visible: GPU tests must run on the MI355X box"
+
+
+def _x(rig, key="cams0"):
+    return np.hstack((rig[key].ravel(), rig["pts0" if key == "cams0" else "pts_true"].ravel()))
+
+
+def test_project13_matches_oracle_and_reduces_to_the_reference_model():
+    rig = make_rig(5, 400, seed=4, visibility=0.8, tangential=True)
+    ci, pi = rig["camera_ind"], rig["point_ind"]
+    P, rows = rig["pts_true"][pi], rig["cams_true"][ci]
+    uv = _native.project_rows(P, rows)
+    assert np.max(np.abs(uv - orc.project(P, rows))) <= 1e-9
+    z = rows.copy()
+    z[:, 9:11] = 0.0
+    rows11 = np.hstack([z[:, :9], z[:, 11:13]])
+    assert np.max(np.abs(_native.project_rows(P, z) - _native.project_rows(P, rows11))) <= 1e-9
+    assert np.max(np.abs(_native.project_rows(P, z) - orc11.project(P, rows11))) <= 1e-9
+    assert np.max(np.abs(uv - _native.project_rows(P, z))) > 0.05      # the tangential term is really there (p ~ 1e-3)
+    uv32 = _native.project_rows(P, rows, dtype="f32")
+    assert np.max(np.abs(uv32 - uv)) <= 3e-3
+
+
+@pytest.mark.parametrize("C,N,vis", [(3, 60, 0.8), (16, 40, 1.0), (20, 50, 0.6)])
+def test_residual_and_jacobian_13_vs_oracle_fd(C, N, vis):
+    rig = make_rig(C, N, seed=21, visibility=vis, tangential=True)
+    rig["cams0"][:, 9:11] = rig["cams_true"][:, 9:11] * 0.7         # linearise where p1, p2 are not zero
+    ci, pi, uv = rig["camera_ind"], rig["point_ind"], rig["points_2d"]
+    x0 = _x(rig)
+    w = np.random.default_rng(1).uniform(0.5, 2.0, ci.size)
+    with _native.Problem(rig["cams0"], rig["pts0"], uv, ci, pi, weights=w) as prob:
+        r, Jc, Jp = prob.residual_jacobian()
+        r2, cost = prob.residual(x0)
+    assert Jc.shape == (ci.size, 2, 13)
+    r_ref = orc.fun(x0, C, N, ci, pi, uv, w.reshape(-1, 1))
+    assert np.max(np.abs(r - r_ref)) <= 1e-9 and np.max(np.abs(r2 - r_ref)) <= 1e-9
+    assert abs(cost - 0.5 * r_ref @ r_ref) <= 1e-10 * cost
+    J = assemble_jacobian(Jc, Jp, ci, pi, C, N)
+    Jfd = orc.fd_jacobian(x0, C, N, ci, pi, uv, w.reshape(-1, 1)).tocsr()
+    assert J.shape == Jfd.shape == (2 * ci.size, 13 * C + 3 * N)
+    d = (J - Jfd).tocoo()
+    assert np.max(np.abs(d.data)) <= 1e-6 * np.max(np.abs(Jfd.data))
+    # the tangential columns specifically (they are small: compare them on their own scale)
+    cols = np.concatenate([13 * np.arange(C) + 9, 13 * np.arange(C) + 10])
+    dt, ft = (J - Jfd).tocsc()[:, cols], Jfd.tocsc()[:, cols]
+    assert np.max(np.abs(dt.data)) <= 1e-6 * np.max(np.abs(ft.data))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("C,N,vis", [(4, 300, 0.9), (16, 200, 1.0), (20, 150, 0.7)])
+def test_converged_solve_13_vs_oracle(C, N, vis, dtype):
+    """4 cameras: general kernels; 16 dense: 208 = 13 tiles of 16 rows exactly, dense back substitution; 20: camera groups."""
+    rig = make_rig(C, N, seed=5, visibility=vis, tangential=True)
+    args = (rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    ref, cams_ref, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], *args, ftol=1e-4)
+    with _native.Problem(rig["cams0"], rig["pts0"], *args, dtype=dtype) as prob:
+        cams, pts, rep, log = prob.solve_lm(prob.make_opts(ftol=1e-4))
+    assert cams.shape == (C, 13) and rep.status in (2, 3, 4)
+    cost64 = 0.5 * np.sum(orc.fun(np.hstack((cams.ravel(), pts.ravel())), C, N, args[1], args[2], args[0], 1.0) ** 2)
+    assert abs(cost64 - rep.cost) <= (1e-9 if dtype == "f64" else 1e-4) * cost64
+    assert cost64 <= ref.cost * (1 + (1e-9 if dtype == "f64" else 1e-4)) and cost64 >= 0.9 * ref.cost
+    assert orc.rms_reprojection(cams, pts, *args) <= np.sqrt(2 * ref.cost / args[1].size) + (1e-6 if dtype == "f64" else 1e-3)
+    # the tangential coefficients (truth ~1e-3, start 0) are recovered as well as the noise allows, i.e. as well as scipy does
+    # (p1, p2 trade off against the principal point; observed errors 1e-4 .. 7e-4 for both solvers at 200 points per camera)
+    err = np.max(np.abs(cams[:, 9:11] - rig["cams_true"][:, 9:11]))
+    err_ref = np.max(np.abs(cams_ref[:, 9:11] - rig["cams_true"][:, 9:11]))
+    assert err <= max(1.5 * err_ref, 3e-4)
+
+
+def test_pysba_surface_with_13_column_camera_array(capsys):
+    rig = make_rig(4, 200, seed=6, visibility=0.9, tangential=True)
+    sba = PySBA(rig["cams0"].copy(), rig["pts0"].copy(), rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    x0 = _x(rig)
+    r = sba.fun(x0, 4, 200, sba.cameraIndices, sba.point2DIndices, sba.points2D, sba.pointWeights)
+    assert np.max(np.abs(r - orc.fun(x0, 4, 200, rig["camera_ind"], rig["point_ind"], rig["points_2d"], 1.0))) <= 1e-9
+    A = sba.bundle_adjustment_sparsity(4, 200, sba.cameraIndices, sba.point2DIndices)
+    assert (A != orc.sparsity(4, 200, rig["camera_ind"], rig["point_ind"])).nnz == 0
+    res = sba.bundleAdjust(1e-4)
+    capsys.readouterr()
+    assert sba.cameraArray.shape == (4, 13) and res.x.shape == (4 * 13 + 200 * 3,) and res.status == 2
+    assert res.jac.shape == (2 * rig["camera_ind"].size, 4 * 13 + 600)
+    assert abs(np.max(np.abs(res.grad)) - res.optimality) <= 1e-6 * max(1.0, res.optimality)
+    res2 = sba.bundleAdjust_nocam(1e-7)
+    capsys.readouterr()
+    assert res2.status in (2, 3, 4) and res2.cost <= res.cost * (1 + 1e-9)

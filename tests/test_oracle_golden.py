@@ -120,3 +120,22 @@ def test_device_algorithm_model_converges_to_reference(golden, tag):
     assert np.allclose(S, S_ref, rtol=1e-8, atol=1e-5 * abs(S_ref).max())
     rhs_ref = -(g_full[:11 * C] - E_ @ np.linalg.solve(Cb, g_full[11 * C:]))
     assert np.allclose(rhs, rhs_ref, rtol=1e-8, atol=1e-8 * abs(rhs_ref).max())
+
+
+def test_tangential_oracle_is_the_reference_model_plus_one_term(golden):
+    """oracle/sba_oracle_tangential.py (13-parameter rows, NOT pinnable to the reference for p != 0): with p1 = p2 = 0 it
+    must reproduce the reference-generated F1 projections bit for bit, and the extra term is OpenCV's."""
+    from oracle import sba_oracle_tangential as t13
+    g = golden("f1_project.npz")
+    rows = g["cam_rows"]
+    rows13 = np.hstack([rows[:, :9], np.zeros((rows.shape[0], 2)), rows[:, 9:11]])
+    assert np.array_equal(t13.project(g["points"], rows13), g["projected"])
+    rows13[:, 9], rows13[:, 10] = 1e-3, -2e-3
+    far = np.r_[0:128, 160:rows.shape[0]]
+    q = orc.rotate(g["points"], rows[:, :3]) + rows[:, 3:6]
+    x, y = q[:, 0] / q[:, 2], q[:, 1] / q[:, 2]
+    r2 = x * x + y * y
+    dx = 2 * 1e-3 * x * y - 2e-3 * (r2 + 2 * x * x)
+    dy = 1e-3 * (r2 + 2 * y * y) - 2 * 2e-3 * x * y
+    extra = np.stack([dx, dy], axis=1) * rows[:, 6:7]
+    assert np.max(np.abs(t13.project(g["points"], rows13)[far] - (g["projected"] + extra)[far])) <= 1e-9
