@@ -2,7 +2,10 @@
 """bench.py -- LM-iteration throughput of the MI355X bundle-adjustment engine.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N = 1:  one process, one GPU.   N > 1: launched by torchrun, one rank per GPU, RCCL over xGMI.
+  N = 1:  one process, one GPU.   N > 1: launched by torchrun, one rank per GPU, RCCL over xGMI: the library owns the
+          collectives (sba_comm_init + sba_solve_lm: one ncclAllReduce of the packed reduced camera system and one
+          ncclAllGather of 8 scalars per LM trial, on the engine's stream); torch.distributed only carries the
+          ncclUniqueId, the barriers around the timed region and the max-over-ranks of the elapsed time.
 One "step" = one full Levenberg-Marquardt iteration of the hot path on synthetic data already resident
 in HBM: linearize (analytic residual + Jacobian blocks -> normal-equation blocks), Schur complement,
 reduced camera solve, back-substitution, trial residual, accept/reject.  Nothing is skipped: steps
@@ -139,7 +142,15 @@ def main():
     prob = _native.Problem(rig["cams0"], shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], dtype=a.dtype,
                            device=local, stream=stream)
     x0 = np.hstack((rig["cams0"].ravel(), shard["pts"].ravel()))
-    comm = sdist.TorchComm() if world > 1 else sdist.SoloComm()
+    rehearsal = world > 1 and os.environ.get("SBA_BENCH_BACKEND", "nccl") != "nccl"     # gloo on one card: phase API + torch collectives
+    phase_api = rehearsal or bool(os.environ.get("SBA_BENCH_PHASE_API"))
+    if world > 1 and not rehearsal:
+        ids = [_native.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        prob.comm_init(ids[0], rank, world)
+    elif os.environ.get("SBA_BENCH_RCCL_1"):          # one GPU through the same RCCL code path (a 1-rank communicator)
+        prob.comm_init(_native.comm_unique_id(), 0, 1)
+    comm = sdist.TorchComm() if rehearsal else sdist.SoloComm()
     E = torch.empty(prob.exchange_size(), dtype=torch.float64, device="cuda")
     sc = torch.empty(sdist.NSCALARS, dtype=torch.float64, device="cuda")
 
@@ -149,8 +160,8 @@ def main():
         opts = prob.make_opts(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=iters, always_relinearize=True, profile=profile)
         barrier()
         t0 = time.perf_counter()
-        if world == 1 and not os.environ.get("SBA_BENCH_PHASE_API"):
-            cams, pts, rep, log = prob.solve_lm(opts)
+        if not phase_api:
+            cams, pts, rep, log = prob.solve_lm(opts)          # N > 1: the library runs the sharded loop and its collectives
             costs = [r.cost for r in log]
         else:
             prob.lm_begin(opts)
@@ -227,7 +238,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{C} cams x {Np} points per GPU, full visibility ({M_local} obs per GPU, {M_total} total), "
                                    "full on-device Schur-complement LM iteration", "cams": C, "points_per_gpu": Np,
-                       "observations_total": int(M_total), "parallelism": f"points sharded x{world}, cameras replicated"},
+                       "observations_total": int(M_total), "parallelism": f"points sharded x{world}, cameras replicated",
+                       "collectives": ("none" if world == 1 else "torch.distributed (rehearsal)" if phase_api else
+                                       "RCCL inside libsba_hip.so: per step 1 all-reduce of n(n+1)/2+3n+1 doubles + 1 all-gather of 8 doubles per rank"),
+                       "exchange_doubles_per_step": (0 if world == 1 else n * (n + 1) // 2 + 3 * n + 1)},
             "lm_iters_per_s": a.steps / dt,
             "resjac_mobs_per_s": M_local / kt["resjac"],
             "fused_linearize_mobs_per_s": M_local / (kt["schur"] if fused else (kt["linearize_points"] + kt["linearize_cams"])),

@@ -195,6 +195,23 @@ int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_re
 /* Rows of the per-iteration log collected so far (filled in by sba_lm_poll / sba_lm_finish). */
 int sba_lm_get_log(sba_handle* h, sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows);
 
+/* ---------------------------------------------------------------- multi-GPU inside the library (RCCL over xGMI)
+ * One process per GPU, one handle per process holding a contiguous slice of the points and all their observations
+ * (cameras replicated).  After sba_comm_init the handle's sba_solve_lm runs the sharded loop itself: per LM trial ONE
+ * ncclAllReduce of the reduced camera system, upper triangle only -- n(n+1)/2 + 3n + 1 doubles, n = P*C -- and ONE
+ * ncclAllGather of 8 scalars per rank, both enqueued on the handle's stream between its kernels; every rank solves the
+ * same camera system and takes the same accept / reject / terminate decision.  No Python, no torch.distributed in a step.
+ * librccl.so is bound with dlopen on first use (single-GPU callers never load it).
+ *   sba_comm_get_unique_id: rank 0 creates the 128-byte ncclUniqueId; the caller carries it to the other ranks
+ *                           (any out-of-band channel: a file, MPI, torch.distributed.broadcast_object_list ...).
+ *   sba_comm_init:          collective over all ranks (ncclCommInitRank on the handle's device).  n_ranks == 1 is allowed
+ *                           and exercises the same code path on one GPU.
+ * The report of a multi-rank sba_solve_lm holds whole-job cost / optimality / nfev; cams_out is identical on every rank,
+ * points_out and sba_residual are the rank's own slice.  The squared-error variants (modes 3, 4) are single-GPU. */
+#define SBA_COMM_ID_BYTES 128
+int sba_comm_get_unique_id(uint8_t* id_out /*SBA_COMM_ID_BYTES*/);
+int sba_comm_init(sba_handle* h, const uint8_t* id /*SBA_COMM_ID_BYTES*/, int32_t rank, int32_t n_ranks);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * Runs `reps` launches of one named kernel on the current parameters and returns the mean launch
  * duration in microseconds measured with HIP events on the handle's stream.

@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "sba_get_gradient", "sba_get_transform", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
     "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_finish", "sba_lm_get_log", "sba_time_kernel", "sba_get_kernel_profile",
+    "sba_comm_get_unique_id", "sba_comm_init",
 )
 
 
@@ -130,6 +131,8 @@ def load():
         "sba_lm_get_log": (C.c_int, [H, C.POINTER(LmIterLog), C.c_int32, C.POINTER(C.c_int32)]),
         "sba_time_kernel": (C.c_int, [H, C.c_char_p, C.c_int32, dp]),
         "sba_get_kernel_profile": (C.c_int, [H, dp, ip]),
+        "sba_comm_get_unique_id": (C.c_int, [C.c_char_p]),
+        "sba_comm_init": (C.c_int, [H, C.c_char_p, C.c_int32, C.c_int32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -174,6 +177,16 @@ def dtype_code(dtype):
 
 def device_count():
     return int(load().sba_device_count())
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """Rank 0: a fresh 128-byte ncclUniqueId (bytes) to hand to every rank's Problem.comm_init."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load().sba_comm_get_unique_id(buf))
+    return buf.raw
 
 
 def cam_model_of(n_cam_params):
@@ -243,6 +256,13 @@ class Problem:
         except Exception:
             self.close()
             raise
+
+    # -- multi-GPU inside the library (RCCL): after this, solve_lm runs the sharded loop on all ranks together
+    def comm_init(self, unique_id, rank, n_ranks):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes comm_unique_id() returned on rank 0")
+        _check(self._lib.sba_comm_init(self._h, bytes(unique_id), int(rank), int(n_ranks)), self._h)
+        self.comm_rank, self.comm_n = int(rank), int(n_ranks)
 
     # -- lifetime
     def close(self):

@@ -33,6 +33,12 @@ int guarded(sba_handle* h, F&& f) {
     snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e.e, hipGetErrorString(e.e), base ? base + 1 : e.file, e.line, e.what);
     if (h) h->err = buf; else g_last_error = buf;
     return SBA_ERR_HIP;
+  } catch (const RcclError& e) {
+    char buf[512];
+    Rccl& r = Rccl::get();
+    snprintf(buf, sizeof buf, "RCCL error %d (%s) at sba_engine.hpp:%d: %s", e.code, r.error_string ? r.error_string(e.code) : "?", e.line, e.what);
+    if (h) h->err = buf; else g_last_error = buf;
+    return SBA_ERR_HIP;
   } catch (const std::exception& e) {
     if (h) h->err = e.what(); else g_last_error = e.what();
     return SBA_ERR_INVALID;
@@ -206,6 +212,22 @@ int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_re
 int sba_get_kernel_profile(sba_handle* h, double* total_us_out, int64_t* count_out) {
   if (!h || !total_us_out || !count_out) return SBA_ERR_INVALID;
   return h->eng->get_kernel_profile(total_us_out, count_out);
+}
+
+int sba_comm_get_unique_id(uint8_t* id_out) {
+  if (!id_out) { g_last_error = "null argument"; return SBA_ERR_INVALID; }
+  Rccl& r = Rccl::get();
+  if (!r.ok) { g_last_error = r.why; return SBA_ERR_UNSUPPORTED; }
+  Rccl::UniqueId uid;
+  const int rc = r.get_unique_id(&uid);
+  if (rc != 0) { g_last_error = std::string("ncclGetUniqueId failed: ") + r.error_string(rc); return SBA_ERR_HIP; }
+  memcpy(id_out, uid.internal, Rccl::ID_BYTES);
+  return SBA_OK;
+}
+
+int sba_comm_init(sba_handle* h, const uint8_t* id, int32_t rank, int32_t n_ranks) {
+  if (!h || !id) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return h->eng->comm_init(id, rank, n_ranks); });
 }
 
 int sba_time_kernel(sba_handle* h, const char* name, int32_t reps, double* mean_us_out) {

@@ -17,6 +17,8 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+
 namespace sba_host {
 
 inline thread_local std::string g_last_error;
@@ -87,6 +89,55 @@ void par_for(int64_t n, F&& f /* (lo, hi, thread) */) {
   for (auto& x : th) x.join();
 }
 
+// RCCL, bound at run time (dlopen) so that single-GPU users never load the 0.5 GB library.  The multi-rank LM loop calls
+// these on the engine's own stream: one ncclAllReduce (reduced camera system, upper triangle) and one ncclAllGather
+// (8 scalars per rank) per LM trial -- SURVEY 8(e); torch.distributed is not involved in a step.
+struct Rccl {
+  static constexpr int ID_BYTES = 128;             // NCCL_UNIQUE_ID_BYTES
+  struct UniqueId { char internal[ID_BYTES]; };
+  using comm_t = void*;
+  enum { kFloat64 = 8 };                           // ncclDataType_t: ncclFloat64
+  enum { kSum = 0, kMax = 2 };                     // ncclRedOp_t
+  int (*get_unique_id)(UniqueId*) = nullptr;
+  int (*comm_init_rank)(comm_t*, int, UniqueId, int) = nullptr;
+  int (*comm_destroy)(comm_t) = nullptr;
+  int (*all_reduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  int (*all_gather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
+  const char* (*error_string)(int) = nullptr;
+  bool ok = false;
+  std::string why;
+  static Rccl& get() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    // a copy the process already holds (PyTorch-ROCm bundles its own librccl.so) is reused; otherwise the system library
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so", "librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }
+    if (!lib) for (const char* name : {"librccl.so.1", "librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+    if (!lib) {
+      const char* e = dlerror();                   // one call: dlerror() clears the message it returns
+      r.why = std::string("cannot load librccl.so: ") + (e ? e : "unknown error");
+      return r;
+    }
+    r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(lib, "ncclGetUniqueId"));
+    r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(lib, "ncclCommInitRank"));
+    r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+    r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(lib, "ncclAllReduce"));
+    r.all_gather = reinterpret_cast<decltype(r.all_gather)>(dlsym(lib, "ncclAllGather"));
+    r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(lib, "ncclGetErrorString"));
+    r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_reduce && r.all_gather && r.error_string;
+    if (!r.ok) r.why = "librccl.so lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclAllGather";
+    return r;
+  }
+};
+struct RcclError { int code; const char* what; int line; };
+#define RCCLCHK(expr)                                                          \
+  do {                                                                         \
+    int _r = (expr);                                                           \
+    if (_r != 0) throw sba_host::RcclError{_r, #expr, __LINE__};               \
+  } while (0)
+
 // One problem handle = one engine.  The concrete class is Engine<T> of the camera model's namespace (sba_engine.hpp);
 // the C ABI only sees this interface.
 struct EngineBase {
@@ -114,6 +165,7 @@ struct EngineBase {
   virtual int get_log(sba_lm_iter_log* log, int32_t cap, int32_t* rows) = 0;
   virtual int get_kernel_profile(double* total_us, int64_t* count) = 0;
   virtual int time_kernel(const char* name, int reps, double* mean_us) = 0;
+  virtual int comm_init(const uint8_t* id, int rank, int n_ranks) = 0;
 };
 
 }  // namespace sba_host

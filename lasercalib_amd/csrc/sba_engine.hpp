@@ -64,6 +64,12 @@ struct Engine : EngineBase {
   DevBuf<int> chol_info;
   bool chol_debug = false;
   bool schur_debug = false;
+  // multi-rank (one handle per GPU, points sharded, cameras replicated): RCCL communicator + exchange buffers
+  Rccl::comm_t comm = nullptr;
+  int comm_rank = 0, comm_n = 1;
+  DevBuf<double> xpack, sc_loc, sc_all, comm_tmp;
+  double* h_comm = nullptr;             // pinned staging of the few scalars all-reduced at begin / finish
+  long long N_global = 0;
   DevBuf<long long> schur_dbg;
   DevBuf<long long> chol_dbg;
   double initial_cost = 0;
@@ -93,6 +99,8 @@ struct Engine : EngineBase {
   ~Engine() override {
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) if (pev[k][j]) (void)hipEventDestroy(pev[k][j]);
     if (h_state) (void)hipHostFree(h_state);
+    if (h_comm) (void)hipHostFree(h_comm);
+    if (comm) (void)Rccl::get().comm_destroy(comm);
 
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -644,6 +652,33 @@ struct Engine : EngineBase {
   static constexpr int LOG_CAP = 4096;
   static constexpr int BATCH = 4;      // LM iterations enqueued between two host polls of the state
 
+  // ------------------------------------------------------------------ multi-rank plumbing (RCCL on the engine's stream)
+  int comm_init(const uint8_t* id, int rank, int n_ranks) override {
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || !id) { err = "bad communicator arguments"; return SBA_ERR_INVALID; }
+    Rccl& r = Rccl::get();
+    if (!r.ok) { err = r.why; return SBA_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(device));
+    if (comm) { (void)r.comm_destroy(comm); comm = nullptr; }
+    Rccl::UniqueId uid;
+    memcpy(uid.internal, id, Rccl::ID_BYTES);
+    RCCLCHK(r.comm_init_rank(&comm, n_ranks, uid, rank));
+    comm_rank = rank; comm_n = n_ranks;
+    sc_loc.alloc(NSCAL); sc_all.alloc((size_t)NSCAL * n_ranks); comm_tmp.alloc(std::max(n, 1) + 8);
+    if (!h_comm) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_comm), sizeof(double) * (std::max(n, 1) + 8), hipHostMallocDefault));
+    return SBA_OK;
+  }
+  // in-place all-reduce of a few host doubles (begin / finish only: the LM loop itself never leaves the device)
+  void comm_reduce(double* v, int count, int op) {
+    for (int i = 0; i < count; ++i) h_comm[i] = v[i];
+    HIPCHK(hipMemcpyAsync(comm_tmp.p, h_comm, sizeof(double) * count, hipMemcpyHostToDevice, stream));
+    RCCLCHK(Rccl::get().all_reduce(comm_tmp.p, comm_tmp.p, count, Rccl::kFloat64, op, comm, stream));
+    HIPCHK(hipMemcpyAsync(h_comm, comm_tmp.p, sizeof(double) * count, hipMemcpyDeviceToHost, stream));
+    sync();
+    for (int i = 0; i < count; ++i) v[i] = h_comm[i];
+  }
+  void comm_sum(double* v, int count) { comm_reduce(v, count, Rccl::kSum); }
+  void comm_max(double* v, int count) { comm_reduce(v, count, Rccl::kMax); }
+
   int lm_begin(const sba_lm_opts* o) override {
     if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
     HIPCHK(hipSetDevice(device));
@@ -658,6 +693,16 @@ struct Engine : EngineBase {
     double c0 = 0;
     int rc = residual(nullptr, nullptr, &c0);
     if (rc) return rc;
+    N_global = N;
+    if (comm) {
+      if (sq_mode() && comm_n > 1) { err = "the squared-error variants (camonly, transform_points_3d) run on one GPU only"; return SBA_ERR_UNSUPPORTED; }
+      // every rank must see the same initial cost (a non-finite one on ANY rank fails the solve on ALL of them, before the
+      // first collective of the loop) and the same default evaluation budget, 100 x the GLOBAL number of parameters
+      double v[2] = {c0, (double)N};
+      comm_sum(v, 2);
+      c0 = v[0];
+      N_global = (long long)(v[1] + 0.5);
+    }
     initial_cost = c0;
     LMState s{};
     s.lam = opts.lambda0 > 0 ? opts.lambda0 : 1e-4;
@@ -672,7 +717,7 @@ struct Engine : EngineBase {
     s.lam_min = 1e-12; s.lam_max = 1e12;
     s.nfev = 1; s.njev = 1;
     const long long nparam = opts.mode == SBA_MODE_CAMS_ONLY_SQ ? (long long)n : opts.mode == SBA_MODE_TRANSFORM_SQ ? 12LL :
-        (opts.mode == SBA_MODE_FULL ? (long long)n : opts.mode == SBA_MODE_SHARED_INTR ? (long long)n_tied : 0) + 3LL * N;
+        (opts.mode == SBA_MODE_FULL ? (long long)n : opts.mode == SBA_MODE_SHARED_INTR ? (long long)n_tied : 0) + 3LL * N_global;
     s.max_nfev = opts.max_nfev > 0 ? opts.max_nfev : 100 * nparam;
     s.status = -1; s.fresh = 1; s.need_lin = 1;
     s.always_relin = opts.always_relinearize ? 1 : 0;
@@ -725,7 +770,8 @@ struct Engine : EngineBase {
     return SBA_OK;
   }
 
-  int lm_form_reduced(double* E) override {
+  int lm_form_reduced(double* E) override { return form_reduced(E, nullptr); }
+  int form_reduced(double* E, double* Pk) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     if (sq_mode()) {
       if (opts.mode == SBA_MODE_CAMS_ONLY_SQ)
@@ -743,7 +789,7 @@ struct Engine : EngineBase {
       const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 15) / 16 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, npairs, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? gdpart.p : (const double*)nullptr);
+                         fused() ? gdpart.p : (const double*)nullptr, Pk);
     }
     prof_end(KP_REDUCE);
     return SBA_OK;
@@ -951,6 +997,15 @@ struct Engine : EngineBase {
     HIPCHK(hipGetLastError());
     double cost = 0;
     for (int i = 0; i < nblk; ++i) { gmax = std::max(gmax, gm[i]); cost += cp[i]; }
+    if (comm) {       // whole-job figures: cost and camera gradient are sums over the ranks, the point-gradient maximum a max
+      std::vector<double> v(n + 1);
+      for (int i = 0; i < n; ++i) v[i] = gch[i];
+      v[n] = cost;
+      comm_sum(v.data(), n + 1);
+      for (int i = 0; i < n; ++i) gch[i] = v[i];
+      cost = v[n];
+      comm_max(&gmax, 1);
+    }
     if (opts.mode == SBA_MODE_SHARED_INTR && (int)h_tie.size() == n) {   // gradient in the tied unknowns
       std::vector<double> gs(n_tied, 0.0);
       for (int i = 0; i < n; ++i) gs[h_tie[i]] += gch[i];
@@ -982,9 +1037,25 @@ struct Engine : EngineBase {
       if (o->max_iter > 0) batch = prof_on ? 1 : std::min(std::max(1, o->max_iter - iters), 64);
       for (int b = 0; b < batch; ++b) {
         lm_linearize();
-        lm_form_reduced(E_own.p);
-        lm_solve_trial(E_own.p, nullptr);
-        lm_decide_async(nullptr, 1);
+        if (!comm) {
+          lm_form_reduced(E_own.p);
+          lm_solve_trial(E_own.p, nullptr);
+          lm_decide_async(nullptr, 1);
+        } else {
+          // one all-reduce of the packed reduced camera system, one all-gather of 8 scalars per rank; every rank then solves
+          // the same system and takes the same decision.  A finished solve turns the kernels into no-ops on the device; the
+          // collectives of such a tail still match because every rank enqueues the same number of them.
+          if (xpack.n < exch_packed_size(n)) xpack.alloc(exch_packed_size(n));
+          form_reduced(E_own.p, xpack.p);
+          const bool fc = h_state->free_cams != 0;
+          double* xb = fc ? xpack.p : xpack.p + exch_packed_size(n) - 1;       // points-only mode: the cost is all there is
+          RCCLCHK(Rccl::get().all_reduce(xb, xb, fc ? exch_packed_size(n) : 1, Rccl::kFloat64, Rccl::kSum, comm, stream));
+          hipLaunchKernelGGL(k_unpack_exchange, dim3(fc ? std::min(1024, (n * n + 255) / 256) : 1), dim3(256), 0, stream, xpack.p, n,
+                             (int)fc, E_own.p, d_state.p);
+          lm_solve_trial(E_own.p, sc_loc.p);
+          RCCLCHK(Rccl::get().all_gather(sc_loc.p, sc_all.p, NSCAL, Rccl::kFloat64, comm, stream));
+          lm_decide_async(sc_all.p, comm_n);
+        }
       }
       rc = lm_poll(&status, &iters);
       if (rc) return rc;

@@ -12,6 +12,10 @@ namespace SBA_NS {
 constexpr int CHOL_THREADS = 1024;
 constexpr int CHOL_LDS_MAX_N = 176;    // packed lower triangle of 176x176 doubles = 124.6 KB of the 160 KB LDS
 
+// packed exchange layout (multi-rank): row i of the upper triangle starts at i*n - i(i-1)/2
+__host__ __device__ inline size_t exch_packed_index(int n, int i, int j) { return (size_t)i * n - (size_t)i * (i - 1) / 2 + (size_t)(j - i); }
+__host__ __device__ inline size_t exch_packed_size(int n) { return (size_t)n * (n + 1) / 2 + 3 * (size_t)n + 1; }
+
 // ------------------------------------------------------------------ reduced system assembly
 // One launch builds the whole exchange buffer E = [S | rhs | diagU | gc | cost]:
 //   blocks [0, 4*NT*npairs):   S(i,j) = [same camera] U(i,j) - sum_ks slab      (NT = 121 tile slots per pair)
@@ -26,7 +30,9 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     const double* __restrict__ cost_part, int n_cost_part, int C, int free_cams, double* __restrict__ E,
     const LMState* __restrict__ st,
     const double* __restrict__ gdpart /* fused linearisation: per-workgroup g_c / diag U partials [ksplit][2][176] (then the
-                                          slabs hold Schur partials - U and bpart holds b - g_c); NULL = classic U / gc */) {
+                                          slabs hold Schur partials - U and bpart holds b - g_c); NULL = classic U / gc */,
+    double* __restrict__ Pk = nullptr /* multi-rank: the same system once more, upper triangle packed row by row
+                                         [S n(n+1)/2 | rhs | diagU | gc | cost] -- what travels through the all-reduce */) {
   using M_ = Mfma<T>;
   // tiles: 64 entries x 16 k-split groups per block (256-byte segments per group load; 16 entries x 64 groups was
   // measured slower: 64-byte segments, four times the blocks).  Rows: 16 rows x 64 groups, see below.
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
       if (!gdpart && ci_ == cj_) v += U[(size_t)ci_ * NCP * NCP + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
       E[(size_t)i * n + j] = v;
       if (!(diag && R == Tc)) E[(size_t)j * n + i] = v;
+      if (Pk && i <= j) Pk[exch_packed_index(n, i, j)] = v;
     }
     return;
   }
@@ -111,23 +118,47 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
       double bs = 0, gs = 0, dsv = 0;
 #pragma unroll 8
       for (int q = 0; q < RG; ++q) { bs += s_r[0][q][lr]; gs += s_r[1][q][lr]; dsv += s_r[2][q][lr]; }
+      double v_r, v_d, v_g;
       if (gdpart) {
-        rhs[i] = bs;                   // k_schur_fused stored b - g_c
-        dU[i] = dsv;
-        gv[i] = gs;
+        v_r = bs;                      // k_schur_fused stored b - g_c
+        v_d = dsv;
+        v_g = gs;
       } else {
         const int c = i / NCP, e = i - c * NCP;
-        rhs[i] = -gc[i] + bs;
-        dU[i] = U[(size_t)c * NCP * NCP + e * NCP + e];
-        gv[i] = gc[i];
+        v_r = -gc[i] + bs;
+        v_d = U[(size_t)c * NCP * NCP + e * NCP + e];
+        v_g = gc[i];
       }
+      rhs[i] = v_r; dU[i] = v_d; gv[i] = v_g;
+      if (Pk) { double* pr = Pk + exch_packed_index(n, n - 1, n - 1) + 1; pr[i] = v_r; pr[n + i] = v_d; pr[2 * n + i] = v_g; }
     }
     return;
   }
   double s = 0;
   for (int i = threadIdx.x; i < n_cost_part; i += blockDim.x) s += cost_part[i];
   s = block_sum(s, scr);
-  if (threadIdx.x == 0) E[(size_t)n * n + 3 * n] = s;
+  if (threadIdx.x == 0) {
+    E[(size_t)n * n + 3 * n] = s;
+    if (Pk) Pk[exch_packed_size(n) - 1] = s;
+  }
+}
+
+// all-reduced packed system -> the full symmetric layout the factorisation kernels read
+__global__ void k_unpack_exchange(const double* __restrict__ Pk, int n, int free_cams, double* __restrict__ E,
+                                  const LMState* __restrict__ st) {
+  if (st->status >= 0) return;
+  const size_t nn = (size_t)n * n;
+  const size_t tail = exch_packed_index(n, n - 1, n - 1) + 1;
+  const size_t total = free_cams ? nn + 3 * (size_t)n : 0;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    if (idx < nn) {
+      const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
+      E[idx] = Pk[exch_packed_index(n, i < j ? i : j, i < j ? j : i)];
+    } else {
+      E[idx] = Pk[tail + (idx - nn)];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) E[nn + 3 * (size_t)n] = Pk[exch_packed_size(n) - 1];
 }
 
 // ------------------------------------------------------------------ shared camera parameters (PySBA.bundleAdjust_sharedcam)

@@ -8,9 +8,17 @@ The only data-path exchange per LM trial is an all-reduce (sum) of the reduced c
 per rank; every rank then solves the same camera system redundantly, so no broadcast is needed
 and all ranks take bit-identical accept/reject decisions.
 
-The driver below is engine-agnostic: the product engine is :class:`HipEngine` (libsba_hip.so
-phase calls + RCCL through ``torch.distributed``); the CPU tests drive the same loop with a
-numpy model over gloo.
+Product path (one GPU per rank): ``solve_sharded`` hands libsba_hip.so an RCCL communicator (``Problem.comm_init``)
+and calls ``sba_solve_lm`` once -- the library runs the whole sharded loop itself, with its two collectives per trial
+(``ncclAllReduce`` of the packed upper triangle, ``ncclAllGather`` of the scalars) enqueued on its own stream.
+torch.distributed only carries the 128-byte ncclUniqueId before and the result shards after the solve.
+
+``run_lm`` below is the same loop written against an abstract engine + communicator: the CPU tests drive it with a numpy
+model over gloo (the logic check of the N > 1 path), and ``LASERCALIB_SBA_COMM=torch`` drives the HIP phase API with it
+(what the one-card rehearsal in tests/test_gpu_dist.py uses, because RCCL refuses two ranks on one device).
+
+Sharding is opt-in: ``PySBA`` methods shard only when ``LASERCALIB_SBA_SHARD=1`` is set AND a process group is up; every
+rank must then call them with the same full problem (checked with a hash of the index arrays).
 """
 from __future__ import annotations
 
@@ -37,6 +45,12 @@ def _td():
 def world_size():
     d = _td()
     return d.get_world_size() if d else 1
+
+
+def sharding_requested():
+    """PySBA shards a solve only on explicit request: a script that merely runs under torchrun, or calls the solver on one
+    rank only, must not fall into collectives by accident."""
+    return os.environ.get("LASERCALIB_SBA_SHARD", "0") not in ("", "0") and world_size() > 1
 
 
 def rank():
@@ -172,7 +186,11 @@ class HipEngine:
         self.E = torch.empty(self.prob.exchange_size(), dtype=torch.float64, device=dev)
         self.sc = torch.empty(NSCALARS, dtype=torch.float64, device=dev)
         self.batch = 1 if opts_kwargs.get("profile") else 4
-        self.prob.lm_begin(self.opts)
+        self.begin_error = None
+        try:
+            self.prob.lm_begin(self.opts)
+        except ValueError as e:          # "Residuals are not finite in the initial point." on THIS shard
+            self.begin_error = str(e)
 
     def linearize(self):
         self.prob.lm_linearize()
@@ -199,41 +217,104 @@ class HipEngine:
         self.prob.close()
 
 
+def raise_everywhere(comm, local_error):
+    """A failure on ANY rank (e.g. a non-finite initial cost in one shard) becomes the same ValueError on ALL ranks, so
+    nobody walks into a collective its peers will never join.  local_error: message or None."""
+    flags = comm.all_gather_var(local_error)
+    bad = [(r, f) for r, f in enumerate(flags) if f is not None]
+    if bad:
+        raise ValueError(f"{bad[0][1]} (rank {bad[0][0]})")
+
+
+def _n_params(mode, P, C, N_total):
+    """Number of free parameters of the whole job (scipy's default max_nfev is 100 x this, trf.py:437-438)."""
+    from . import _native
+    if mode == _native.MODE_POINTS_ONLY:
+        return 3 * N_total
+    if mode == _native.MODE_SHARED_INTR:
+        return 3 + (P - 3) * C + 3 * N_total
+    return P * C + 3 * N_total
+
+
+def _same_problem_everywhere(comm, sba, cams, pts):
+    """Cheap guard against per-rank data: every rank must hold the same full problem."""
+    import hashlib
+    h = hashlib.sha1()
+    for a in (np.asarray(sba.cameraIndices), np.asarray(sba.point2DIndices)):
+        h.update(np.ascontiguousarray(a, dtype=np.int64).tobytes())
+    h.update(np.asarray([cams.shape[0], cams.shape[1], pts.shape[0]], dtype=np.int64).tobytes())
+    digests = comm.all_gather_var(h.hexdigest())
+    if len(set(digests)) != 1:
+        raise ValueError("sharded solve: the ranks do not hold the same problem (index arrays / sizes differ); "
+                         "every rank must call the solver with the full observation list")
+
+
 def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device, max_iter=0,
                   always_relinearize=False):
     """PySBA._solve for world_size > 1.  Every rank calls this with the same full problem and gets
     the same full result back."""
+    from . import _native
     comm = TorchComm()
     cams = np.ascontiguousarray(sba.cameraArray, dtype=np.float64)
     pts = np.ascontiguousarray(sba.points3D, dtype=np.float64)
+    _same_problem_everywhere(comm, sba, cams, pts)
     w = sba._weights_or_none()
     shard = make_shard(pts, sba.points2D, sba.cameraIndices, sba.point2DIndices, w, comm.n, comm.r)
-    eng = HipEngine(cams, shard, dtype, device, dict(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev or 0,
-                                                      mode=mode, verbose=0, max_iter=max_iter,
-                                                      always_relinearize=always_relinearize))
-    try:
-        status, _ = run_lm(eng, comm, max_iter=max_iter)
-        cams_opt, pts_loc, rep = eng.finish()
-        gc_loc, gp_loc = eng.prob.get_gradient()
-        fvec_loc, cost_loc = eng.prob.residual()
-        log = eng.prob.iteration_log()
-    finally:
-        eng.close()
-    gp_max = float(np.max(np.abs(gp_loc))) if gp_loc.size else 0.0
-    parts = comm.all_gather_var((shard["p0"], pts_loc, shard["obs_index"], fvec_loc, cost_loc, gc_loc, gp_max,
-                                 rep.initial_cost))
+    # the evaluation budget is a property of the whole job, not of a shard: ranks own different numbers of points
+    max_nfev = int(max_nfev) if max_nfev else 100 * _n_params(mode, cams.shape[1], cams.shape[0], pts.shape[0])
+    kw = dict(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, mode=mode, verbose=0, max_iter=max_iter,
+              always_relinearize=always_relinearize)
+    use_rccl = os.environ.get("LASERCALIB_SBA_COMM", "rccl" if comm.d.get_backend() == "nccl" else "torch") == "rccl"
+    if use_rccl:
+        # the library owns the collectives: hand it a communicator and make ONE call
+        ids = [_native.comm_unique_id() if comm.r == 0 else None]
+        comm.d.broadcast_object_list(ids, src=0)
+        prob = _native.Problem(cams, shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], weights=shard["w"],
+                               dtype=dtype, device=device)
+        try:
+            prob.comm_init(ids[0], comm.r, comm.n)
+            bad = None
+            try:
+                cams_opt, pts_loc, rep, log = prob.solve_lm(prob.make_opts(**kw))
+            except ValueError as e:       # non-finite start: the library all-reduces the initial cost, so every rank lands here
+                bad = e
+            if bad is not None:
+                raise bad
+            fvec_loc, _ = prob.residual()
+        finally:
+            prob.close()
+        status, cost, opt, cost0 = rep.status, rep.cost, rep.optimality, rep.initial_cost     # whole-job figures already
+        parts = comm.all_gather_var((shard["p0"], pts_loc, shard["obs_index"], fvec_loc))
+    else:
+        eng = HipEngine(cams, shard, dtype, device, kw)
+        try:
+            # a non-finite initial cost on ANY rank must fail the solve on ALL ranks before the first collective of the loop
+            raise_everywhere(comm, eng.begin_error)
+            status, _ = run_lm(eng, comm, max_iter=max_iter)
+            cams_opt, pts_loc, rep = eng.finish()
+            gc_loc, gp_loc = eng.prob.get_gradient()
+            fvec_loc, cost_loc = eng.prob.residual()
+            log = eng.prob.iteration_log()
+        finally:
+            eng.close()
+        gp_max = float(np.max(np.abs(gp_loc))) if gp_loc.size else 0.0
+        extra = comm.all_gather_var((cost_loc, gc_loc, gp_max, rep.initial_cost))
+        cost = sum(e[0] for e in extra)
+        cost0 = sum(e[3] for e in extra)
+        gc = sum(e[1] for e in extra)
+        if mode == _native.MODE_SHARED_INTR:      # gradient in the tied unknowns, like the single-rank report (f, k1, k2 summed)
+            gc_t = np.concatenate([gc[:, 6:9].sum(axis=0), gc[:, :6].ravel(), gc[:, 9:].ravel()])
+        elif mode == _native.MODE_POINTS_ONLY:
+            gc_t = np.zeros(1)
+        else:
+            gc_t = gc.ravel()
+        opt = max(max(e[2] for e in extra), float(np.max(np.abs(gc_t))))
+        parts = comm.all_gather_var((shard["p0"], pts_loc, shard["obs_index"], fvec_loc))
     pts_opt = np.empty_like(pts)
     fvec = np.empty(2 * np.asarray(sba.point2DIndices).size)
-    cost, opt, cost0 = 0.0, 0.0, 0.0
-    gc = np.zeros_like(gc_loc)
-    for p0, pl, oi, fv, cl, gcl, gpm, c0 in parts:
+    for p0, pl, oi, fv in parts:
         pts_opt[p0:p0 + pl.shape[0]] = pl
         fvec.reshape(-1, 2)[oi] = fv.reshape(-1, 2)
-        cost += cl
-        cost0 += c0
-        gc += gcl
-        opt = max(opt, gpm)
-    opt = max(opt, float(np.max(np.abs(gc))))
     rep.cost, rep.optimality, rep.status, rep.initial_cost = cost, opt, status, cost0
     res, c, p = sba._package(mode, cams_opt, pts_opt, rep, log, fvec, verbose if comm.r == 0 else 0)
     return res, c, p

@@ -15,6 +15,10 @@ below then works on 13-parameter rows; with the reference's 11 columns nothing c
 Environment knobs (the script itself stays unchanged):
   LASERCALIB_SBA_DTYPE   f64 (default) | f32   arithmetic type of the per-observation math
   LASERCALIB_SBA_DEVICE  HIP device ordinal (default: LOCAL_RANK or 0)
+  LASERCALIB_SBA_SHARD   1: with a torch.distributed process group up, bundleAdjust / _nocam / _sharedcam shard the points
+                         over the ranks (every rank calls with the same full problem).  Default 0: never implicit.
+                         The squared-error variants (bundle_adjustment_camonly, bundleAdjust_transform_points_3d) always
+                         run on one GPU per process.
 """
 from __future__ import annotations
 
@@ -172,7 +176,7 @@ class PySBA:
         cams = np.ascontiguousarray(self.cameraArray, dtype=np.float64)
         pts = np.ascontiguousarray(self.points3D, dtype=np.float64)
         from . import dist
-        if dist.world_size() > 1:
+        if dist.sharding_requested():
             return dist.solve_sharded(self, mode, ftol, xtol, gtol, max_nfev, verbose, _env_dtype(), _env_device())
         with _native.Problem(cams, pts, self.points2D, self.cameraIndices, self.point2DIndices,
                              weights=self._weights_or_none(), dtype=_env_dtype(), device=_env_device()) as prob:

@@ -68,3 +68,54 @@ def test_two_rank_sharded_lm_matches_single_rank_and_reference(tag):
     assert np.max(np.abs(out["cams"] - cams0)) <= 1e-6 and np.max(np.abs(out["pts"] - pts0)) <= 1e-6
     ref = float(g[f"{tag}_loose_cost"])
     assert cost0 <= ref * (1 + 1e-9) and ref - cost0 <= 1e-5 * ref
+
+
+# ----------------------------------------------------------------------------- termination must be rank-invariant
+def _worker_budget(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lasercalib_amd import dist as sdist
+        from lasercalib_amd.synth import make_rig
+        from oracle import lm_schur_model as model
+        # sparse visibility: shards balanced by observation count own DIFFERENT numbers of points
+        rig = make_rig(5, 90, seed=3, visibility=0.45)
+        sh = sdist.make_shard(rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], None, world, rank)
+        n_global = sdist._n_params(0, 11, 5, 90)
+        eng = model.ModelEngine(rig["cams0"], sh["pts"], sh["uv"], sh["ci"], sh["pi_local"])
+        eng.begin(ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=4)          # explicit, job-wide budget
+        comm = sdist.TorchComm()
+        status, iters = sdist.run_lm(eng, comm)
+        # the "one rank fails, everybody raises" helper
+        try:
+            sdist.raise_everywhere(comm, "Residuals are not finite in the initial point." if rank == 1 else None)
+            raised = None
+        except ValueError as e:
+            raised = str(e)
+        q.put((rank, status, iters, eng.nfev, sh["pts"].shape[0], n_global, raised, sdist.sharding_requested()))
+    except BaseException as e:
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_budget_and_failures_are_job_wide_not_per_shard():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_worker_budget, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    assert all(len(r) > 2 for r in results), results
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = results
+    assert r0[4] != r1[4]                                  # unequal shards ...
+    assert r0[1] == r1[1] == 0 and r0[2] == r1[2] and r0[3] == r1[3] == 4     # ... same status 0 at the same evaluation count
+    assert r0[5] == r1[5] == 11 * 5 + 3 * 90               # default budget basis: parameters of the whole job
+    assert r0[6] == r1[6] and "not finite" in r0[6] and "rank 1" in r0[6]      # both ranks raise the same error
+    assert r0[7] is False and r1[7] is False               # a live process group alone never turns on sharding

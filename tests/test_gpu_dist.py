@@ -15,7 +15,7 @@ def _worker(rank, world, port, tag, q, dtype="f64"):
     sys.path.insert(0, ROOT)
     os.environ["LASERCALIB_SBA_DTYPE"] = dtype
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", LASERCALIB_SBA_DEVICE="0")
+                      LOCAL_RANK="0", LASERCALIB_SBA_DEVICE="0", LASERCALIB_SBA_SHARD="1", LASERCALIB_SBA_COMM="torch")
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)

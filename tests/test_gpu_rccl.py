@@ -1,0 +1,63 @@
+"""GPU: the library-owned multi-rank loop (sba_comm_init + sba_solve_lm, RCCL bound with dlopen) on a ONE-rank communicator.
+
+RCCL refuses two ranks on one device and the GPU box has one card, so N > 1 cannot run here; what a 1-rank communicator
+does exercise is everything but the wire: loading librccl.so, ncclGetUniqueId / ncclCommInitRank, the packed upper-triangle
+exchange buffer written by k_build_exchange, ncclAllReduce and ncclAllGather enqueued on the solve stream between the
+kernels, k_unpack_exchange, the scalar path of k_decide (n_ranks rows), and the job-wide reductions at begin / finish.
+The N = 2 logic runs on CPU over gloo (tests/test_dist_gloo.py) and on this card over gloo (tests/test_gpu_dist.py).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from lasercalib_amd import _native  # noqa: E402
+from lasercalib_amd.synth import make_rig  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert _native.device_count() > 0, "no HIP device visible: GPU tests must run on the MI355X box"
+
+
+def _pair(rig, dtype, mode=_native.MODE_FULL, ftol=1e-6):
+    out = []
+    for with_comm in (False, True):
+        with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], dtype=dtype) as prob:
+            if with_comm:
+                uid = _native.comm_unique_id()
+                assert len(uid) == 128
+                prob.comm_init(uid, 0, 1)
+            out.append(prob.solve_lm(prob.make_opts(ftol=ftol, mode=mode)))
+    return out
+
+
+@pytest.mark.parametrize("dtype,C,N,vis", [("f64", 4, 300, 0.8), ("f32", 16, 400, 1.0), ("f64", 20, 120, 0.6), ("f32", 48, 60, 0.3)])
+def test_rccl_loop_equals_plain_loop(dtype, C, N, vis):
+    """Same kernels, same arithmetic, the exchange detoured through pack -> all-reduce -> unpack: identical trajectories."""
+    rig = make_rig(C, N, seed=13, visibility=vis)
+    (c0, p0, r0, l0), (c1, p1, r1, l1) = _pair(rig, dtype)
+    assert r0.status == r1.status and r0.iterations == r1.iterations and r0.nfev == r1.nfev
+    assert [row.accepted for row in l0] == [row.accepted for row in l1]
+    assert abs(r0.cost - r1.cost) <= 1e-12 * r0.cost and abs(r0.optimality - r1.optimality) <= 1e-9 * max(1.0, r0.optimality)
+    assert np.array_equal(c0, c1) and np.array_equal(p0, p1)
+
+
+def test_rccl_loop_variants_and_errors():
+    rig = make_rig(4, 200, seed=2, visibility=0.9)
+    for mode in (_native.MODE_POINTS_ONLY, _native.MODE_SHARED_INTR):
+        (c0, p0, r0, _), (c1, p1, r1, _) = _pair(rig, "f64", mode=mode)
+        assert r0.status == r1.status and r0.nfev == r1.nfev and abs(r0.cost - r1.cost) <= 1e-12 * r0.cost
+        assert np.array_equal(c0, c1) and np.array_equal(p0, p1)
+    # non-finite start: the all-reduced initial cost fails the solve the same way
+    bad = rig["pts0"].copy()
+    bad[7, 0] = np.nan
+    with _native.Problem(rig["cams0"], bad, rig["points_2d"], rig["camera_ind"], rig["point_ind"]) as prob:
+        prob.comm_init(_native.comm_unique_id(), 0, 1)
+        with pytest.raises(ValueError, match="not finite"):
+            prob.solve_lm(prob.make_opts(ftol=1e-6))
+    with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"]) as prob:
+        with pytest.raises(ValueError):
+            prob.comm_init(b"short", 0, 1)
+        with pytest.raises(_native.SbaError):
+            prob.comm_init(_native.comm_unique_id(), 3, 2)
