@@ -424,6 +424,8 @@ struct Engine : EngineBase {
           sync();
           fprintf(stderr, "[schur_fused stamps, cycles since the first producer stamp; per chunk: producer-done consumer-done]\n");
           for (int i = 0; i < 14; ++i) fprintf(stderr, "  it %2d: P %7lld  C %7lld\n", i, st[2 * i] - st[0], st[2 * i + 1] - st[0]);
+          fprintf(stderr, "  phases (cycles): prologue %lld | main loop %lld | fold U %lld | slab stores %lld | tail %lld | whole kernel %lld\n",
+                  st[49] - st[48], st[50] - st[49], st[51] - st[50], st[52] - st[51], st[53] - st[52], st[53] - st[48]);
           schur_debug = false;
         }
         return;

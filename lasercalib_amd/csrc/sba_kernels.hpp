@@ -492,23 +492,25 @@ __device__ __forceinline__ double row16_sum(double v) {
 }
 // L^-1 of the 3x3 SPD matrix (v00,v01,v02,v11,v12,v22) with hardware rsq (1 ulp): no sqrt / divide sequences
 __device__ __forceinline__ bool chol3_inv_fast(const float v[6], float li[6]) {
-  if (!(v[0] > 0.f)) return false;
-  const float i00 = __builtin_amdgcn_rsqf(v[0]);
+  // straight-line: a failing pivot is replaced by 1 so that everything stays finite, and the verdict is one flag at the
+  // end (the caller discards li then) -- three nested early returns cost three exec-mask round trips per point
+  const bool ok0 = v[0] > 0.f;
+  const float i00 = __builtin_amdgcn_rsqf(ok0 ? v[0] : 1.f);
   const float l10 = v[1] * i00, l20 = v[2] * i00;
   const float d11 = v[3] - l10 * l10;
-  if (!(d11 > 0.f)) return false;
-  const float i11 = __builtin_amdgcn_rsqf(d11);
+  const bool ok1 = d11 > 0.f;
+  const float i11 = __builtin_amdgcn_rsqf(ok1 ? d11 : 1.f);
   const float l21 = (v[4] - l20 * l10) * i11;
   const float d22 = v[5] - l20 * l20 - l21 * l21;
-  if (!(d22 > 0.f)) return false;
-  const float i22 = __builtin_amdgcn_rsqf(d22);
+  const bool ok2 = d22 > 0.f;
+  const float i22 = __builtin_amdgcn_rsqf(ok2 ? d22 : 1.f);
   li[0] = i00;
   li[1] = -l10 * i00 * i11;
   li[2] = i11;
   li[3] = (-l20 * i00 - l21 * li[1]) * i22;
   li[4] = -l21 * i11 * i22;
   li[5] = i22;
-  return isfinite(i22) && isfinite(i11) && isfinite(i00);
+  return ok0 && ok1 && ok2 && isfinite(i22) && isfinite(i11) && isfinite(i00);
 }
 
 // ------------------------------------------------------------------ K4: Schur complement partials (MFMA)
@@ -523,7 +525,7 @@ __device__ __forceinline__ bool chol3_inv_fast(const float v[6], float li[6]) {
 //   !DIAG (ga <  gb): two panels, 121 tiles                  (grid = (ksplit, npairs - ngroups, TS))
 //   The tiles of a pair are dealt to TS workgroups (grid.z) so that a consumer wave never holds more than ~72 accumulator
 //   VGPRs; every workgroup of a split still builds the whole panel.
-//   slab layout: [pair][ks][tile (121 slots)][reg 4][lane 64]   (acc type T)
+//   slab layout: [pair][ks][tile (121 slots)][lane 64][reg 4]   (acc type T; a lane's 4 registers are one 16-byte store)
 //   bpart layout: [ga][ks][176] doubles (only diagonal pairs contribute)
 // Flavours: k_schur (f32: 4 producer + 4 consumer waves), k_schur_sym (f64: all 8 waves produce, then all 8 consume),
 // k_schur_fused (f32, dense visibility, one group: the linearisation rides in the producers) -- see DESIGN.md 4.
@@ -650,7 +652,7 @@ __device__ inline void schur_store(typename Cfg::elem* __restrict__ slab, int la
 #pragma unroll
   for (int t = LO; t < HI; ++t) {
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) slab[(size_t)t * 256 + rg * 64 + lane] = acc[t - LO][rg];
+    for (int rg = 0; rg < 4; ++rg) slab[(size_t)t * 256 + lane * 4 + rg] = acc[t - LO][rg];      // one dwordx4 store per tile (f32)
   }
 }
 
@@ -1156,6 +1158,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF;
   static_assert(PTS == 16 && NPROD == 256, "lane = (point of the chunk, camera) needs 16 x 16 producer lanes");
   if (st->status >= 0) return;
+  const bool stamp_wg = dbg && blockIdx.x == 0;
+  if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();         // kernel entry
   const int cur_ = ps_cur(ps, st);
   const T* __restrict__ campre = ps.campre[cur_];
   const T* __restrict__ ptsT = ps.ptsT[cur_];
@@ -1188,7 +1192,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
   if (producer) {
     const int q = threadIdx.x >> 4, c = threadIdx.x & 15;
     const bool cam_ok = c < C;
-    const T* cp = s_cam + c * CAMPRE;
+    const T* cp_safe = s_cam + (cam_ok ? c : 0) * CAMPRE;          // lanes beyond the last camera read camera 0's row (weight 0)
     T Uacc[UPK];
     static_for<0, UPK>([&](auto kc) { Uacc[decltype(kc)::value] = (T)0; });
     T sq = 0, gmx = 0;
@@ -1222,6 +1226,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
     };
     request_index(0);
     request(0);
+    if (stamp_wg && threadIdx.x == 0) dbg[49] = clock64();       // prologue done
     for (int it = 0; it <= nchunk; ++it) {
       if (it < nchunk) {
         T* panel = s_buf + (it & 1) * BUF;
@@ -1232,12 +1237,10 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
         const double D0 = n_D[0], D1 = n_D[1], D2 = n_D[2];
         const int p = pbeg + it * PTS + q;
         request(it + 1);
-        T r[2] = {0, 0}, Jc[2][NCP], Jp[2][3];
-#pragma unroll
-        for (int e = 0; e < NCP; ++e) { Jc[0][e] = 0; Jc[1][e] = 0; }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { Jp[0][d] = 0; Jp[1][d] = 0; }
-        if (valid) obs_resjac<T>(cp, X0, X1, X2, m.x, m.y, ww, r, Jc, Jp);
+        // a lane without an observation runs the same code with weight 0 (every output carries the weight as a factor) and a
+        // harmless depth: no branch, no zero-initialised outputs
+        T r[2], Jc[2][NCP], Jp[2][3];
+        obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
         sq += r[0] * r[0] + r[1] * r[1];
         // per-point blocks: V (6) and g_p (3), summed over the 16 cameras of the DPP row
         T v6[6], g3[3];
@@ -1293,6 +1296,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
       if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && it < 20) dbg[2 * it] = clock64();
       __syncthreads();
     }
+    if (stamp_wg && threadIdx.x == 0) dbg[50] = clock64();       // main loop done (producer side)
     // hand the accumulators over
     static_for<0, UPK>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * UPK + k] = Uacc[k]; });
     const double cs = wave_sum((double)sq), gm = wave_max((double)gmx);
@@ -1353,8 +1357,10 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
       }
     });
     (void)LO;
+    if (stamp_wg && threadIdx.x == NPROD) dbg[51] = clock64();   // U folded and taken out of the tiles
     T* slab = slabs + (size_t)blockIdx.x * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
     schur_store_v<Cfg>(cw, slab, lane, acc);
+    if (stamp_wg && threadIdx.x == NPROD) dbg[52] = clock64();   // slab stores issued
     if (ct < GROUP_ROWS) {
       const int c = ct / NCP, e = ct - c * NCP;
       const double gpart = (c < C) ? (double)s_Ured[c * UPK + NCP * (NCP + 1) / 2 + e] : 0.0;
@@ -1369,6 +1375,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
     for (int wv = 0; wv < NPROD / 64; ++wv) { cs += s_scr[0][wv]; gm = fmax(gm, s_scr[1][wv]); }
     cost_part[blockIdx.x] = 0.5 * cs;
     gmax_part[blockIdx.x] = gm;
+    if (stamp_wg) dbg[53] = clock64();                           // kernel exit (thread 0)
   }
 }
 

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     if (t >= ntile) return;
     int R, Tc;
     schur_tile_rc(diag, t, R, Tc);
-    const int e = part * EPB + l16;                   // entry of the tile's register dump: reg = e>>6, lane = e&63
-    const int rg = e >> 6, lane = e & 63;
+    const int e = part * EPB + l16;                   // entry of the tile's register dump: lane = e>>2, reg = e&3
+    const int rg = e & 3, lane = e >> 2;            // slab layout [tile][lane][reg]
     const int i = ga * GROUP_ROWS + 16 * R + M_::row_of(lane, rg);
     const int j = gb * GROUP_ROWS + 16 * Tc + (lane & 15);
     const size_t stride = (size_t)NT * 256;

@@ -107,14 +107,15 @@ __device__ inline void obs_project(const T* __restrict__ cp, T X0, T X1, T X2, T
 //   Jc[2][NCP] = d r / d(cam params),  Jp[2][3] = d r / d X
 template <typename T>
 __device__ inline void obs_resjac(const T* __restrict__ cp, T X0, T X1, T X2, T uo, T vo, T w,
-                                  T r[2], T Jc[2][NCP], T Jp[2][3]) {
+                                  T r[2], T Jc[2][NCP], T Jp[2][3], bool valid = true /* false: the caller passes w = 0 and only
+                                  needs finite outputs, so the depth is replaced by 1 (no 1/0 -> inf * 0 = NaN) */) {
   const T R0 = cp[CP_R + 0], R1 = cp[CP_R + 1], R2 = cp[CP_R + 2];
   const T R3 = cp[CP_R + 3], R4 = cp[CP_R + 4], R5 = cp[CP_R + 5];
   const T R6 = cp[CP_R + 6], R7 = cp[CP_R + 7], R8 = cp[CP_R + 8];
   const T p0 = R0 * X0 + R1 * X1 + R2 * X2 + cp[CP_T + 0];
   const T p1 = R3 * X0 + R4 * X1 + R5 * X2 + cp[CP_T + 1];
   const T p2 = R6 * X0 + R7 * X1 + R8 * X2 + cp[CP_T + 2];
-  const T iz = (T)1 / p2;
+  const T iz = (T)1 / (valid ? p2 : (T)1);
   const T x = p0 * iz, y = p1 * iz;
   const T n = x * x + y * y;
   const T k1 = cp[CP_K1], k2 = cp[CP_K2], f = cp[CP_F];

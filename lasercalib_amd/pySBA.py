@@ -322,9 +322,33 @@ class PySBA:
         x = cams_opt.ravel().copy() if mode == _native.MODE_CAMS_ONLY_SQ else theta
         message = TERMINATION_MESSAGES[rep.status]
         _print_table(log, rep.initial_cost, rep, message, verbose)
+        ci, pi = np.asarray(self.cameraIndices), np.asarray(self.point2DIndices)
+        uv, dt, dev = self.points2D, _env_dtype(), _env_device()
+
+        def make_jac():
+            """Jacobian of the reference's squared residual rho = w * Delta^2 at the solution (scipy returns it dense for
+            these variants, least_squares.py:950-961):  d rho = 2 (r / w) * (w dDelta/dtheta), with r and the blocks
+            w dDelta/d(cam), w dDelta/dX from the device Jacobian kernel."""
+            with _native.Problem(cams_opt, pts_opt, uv, ci, pi, weights=w, dtype=dt, device=dev) as prob:
+                rr, Jc, Jp = prob.residual_jacobian()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                two_delta = np.where(np.repeat(wv, 2) != 0, 2.0 * rr / np.repeat(wv, 2), 0.0).reshape(-1, 2)
+            M_, P_ = ci.size, cams_opt.shape[1]
+            if mode == _native.MODE_CAMS_ONLY_SQ:
+                J = np.zeros((2 * M_, P_ * cams_opt.shape[0]))
+                rows = np.arange(M_)
+                for comp in range(2):
+                    blk = two_delta[:, comp, None] * Jc[:, comp, :]
+                    J[(2 * rows + comp)[:, None], ci[:, None] * P_ + np.arange(P_)[None, :]] = blk
+                return J
+            Xh = np.hstack((pts[pi], np.ones((M_, 1))))                       # d(A X + b)/d theta[k, :] = [X, 1]
+            J = np.einsum("mc,mck,mj->mckj", two_delta, Jp, Xh).reshape(2 * M_, 12)
+            return J
+
         res = SBAResult(x=x, cost=rep.cost, fun=fvec, optimality=rep.optimality, active_mask=np.zeros_like(x),
                         nfev=int(rep.nfev), njev=int(rep.njev), status=int(rep.status), message=message,
                         success=rep.status > 0)
+        dict.__setitem__(res, "_jac_maker", make_jac)
         return res, cams_opt, pts_opt
 
     def bundle_adjustment_camonly(self, ftol=1e-4):

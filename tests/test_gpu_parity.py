@@ -372,6 +372,14 @@ def test_camonly_squared_error_variant(golden):
     assert np.max(np.abs(f - res.fun)) <= 1e-6 and abs(0.5 * f @ f - res.cost) <= 1e-9 * res.cost
     again, _ = orc.bundle_adjust_camonly(sba.cameraArray, g["pts0"], g["uv"], g["ci"], g["pi"], ftol=1e-4)
     assert again.cost >= res.cost * (1 - 1e-4)
+    # res.jac / res.grad exist like on scipy's OptimizeResult: dense Jacobian of the squared residual, checked against
+    # scipy's own finite differences of the reference function at the solution
+    from scipy.optimize._numdiff import approx_derivative
+    Jfd = approx_derivative(orc.fun_camonly, res.x, method="3-point", args=(C, N, g["ci"], g["pi"], g["uv"], 1.0, g["pts0"]))
+    assert res.jac.shape == Jfd.shape == (2 * g["ci"].size, 11 * C)
+    assert np.max(np.abs(res.jac - Jfd)) <= 1e-6 * np.max(np.abs(Jfd))
+    assert np.max(np.abs(res.grad - res.jac.T @ res.fun)) <= 1e-12 * np.max(np.abs(res.grad))
+    assert np.max(np.abs(res.grad - Jfd.T @ f)) <= 1e-4 * np.max(np.abs(Jfd.T @ f))      # the FD entries carry ~1e-6 each
 
 
 def test_transform_points_3d_squared_error_variant(golden):
@@ -391,6 +399,11 @@ def test_transform_points_3d_squared_error_variant(golden):
     assert np.max(np.abs(moved - sba.points3D)) <= 1e-9       # points3D replaced by the transformed points (pySBA.py:197-204)
     assert np.max(np.abs(sba.points3D - g["transform_pts"])) <= 0.5      # mm, against the reference's result
     assert np.max(np.abs(res.x - g["transform_x"])[[0, 1, 2, 4, 5, 6, 8, 9, 10]]) <= 2e-3
+    from scipy.optimize._numdiff import approx_derivative
+    Jfd = approx_derivative(orc.fun_transform_points_3d, res.x, method="3-point",
+                            args=(C, N, g["cams0"], g["ci"], g["pi"], g["uv"], 1.0, g["pts0"]))
+    assert res.jac.shape == Jfd.shape == (2 * g["ci"].size, 12)
+    assert np.max(np.abs(res.jac - Jfd)) <= 1e-6 * np.max(np.abs(Jfd))
 
 
 def test_nonfinite_start_raises_value_error():
