@@ -31,6 +31,7 @@ struct Engine : EngineBase {
   bool masked_ok = false;            // one group, no duplicate (point, camera) pairs, not dense: visibility mask available
   DevBuf<uint16_t> vis_mask;
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
+  bool fused_bf3 = true;             // ... with the Schur products on the bf16 matrix pipe (k_schur_fused_bf3)
   DevBuf<double> gdpart;
   std::vector<int64_t> perm;          // pm position -> caller's observation index
   int nblk = 0, nchunk = 0, ngroups = 0, npairs = 0, ksplit = 1;
@@ -131,6 +132,9 @@ struct Engine : EngineBase {
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, false, false>)));
 #if SBA_NCP == 11
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
+      // SBA_FUSED_MFMA=f32 keeps the f32-input MFMA kernel (A/B measurements, equivalence test); default: bf16 x 3 split
+      if (const char* e = getenv("SBA_FUSED_MFMA")) fused_bf3 = (std::string(e) != "f32");
 #endif
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -414,10 +418,16 @@ struct Engine : EngineBase {
 #if SBA_NCP == 11
     if constexpr (sizeof(T) == 4) {
       if (fused()) {
-        hipLaunchKernelGGL(k_schur_fused, dim3(ksplit), dim3(SCHUR_THREADS), SchurFusedCfg<float>::LDS_BYTES, stream,
-                           ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
-                           N, ksplit, D2p.p, gp.p, pfac.p,
-                           slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p, schur_debug ? schur_dbg.p : nullptr);
+        if (fused_bf3)
+          hipLaunchKernelGGL(k_schur_fused_bf3, dim3(ksplit), dim3(SCHUR_THREADS), SchurBf3Cfg::LDS_BYTES, stream,
+                             ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
+                             N, ksplit, D2p.p, gp.p, pfac.p,
+                             slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p, schur_debug ? schur_dbg.p : nullptr);
+        else
+          hipLaunchKernelGGL(k_schur_fused, dim3(ksplit), dim3(SCHUR_THREADS), SchurFusedCfg<float>::LDS_BYTES, stream,
+                             ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
+                             N, ksplit, D2p.p, gp.p, pfac.p,
+                             slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p, schur_debug ? schur_dbg.p : nullptr);
         if (schur_debug) {
           std::vector<long long> st(64);
           HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));

@@ -1379,6 +1379,321 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
   }
 }
 
+
+// ------------------------------------------------------------------ K3+K4 fused, Schur products on the bf16 matrix pipe
+// Same kernel structure and the same producer mathematics as k_schur_fused; what changes is how panel^T panel is formed.
+// On gfx950 the f32-input MFMA runs on the SIMD's f32 FMA lanes (tools/micro/mix_waves.hip: a VALU-only wave beside a
+// saturating f32-MFMA wave makes no progress at all), so the 6.3k MFMA cycles of a 16-point chunk and the ~5k cycles of
+// producer arithmetic simply add up.  The bf16 MFMA is a separate pipe.  Each f32 panel value y is therefore split EXACTLY
+// into three bf16 pieces by truncation, y = h + m + l (8 + 8 + 8 mantissa bits; h = top half of y's bit pattern,
+// m = top half of (y - h), l = (y - h) - m), and a product of two panel values is accumulated in f32 as the six partial
+// products of combined order <= 2,
+//     y y' ~= h h' + h m' + m h' + h l' + l h' + m m'        (dropped: m l', l m', l l' <= 2^-24 |y y'|),
+// each of them exact in f32 (8 x 8 bits).  Error per product <= 3 * 2^-24 relative, the order of the f32 MFMA's own
+// rounding -- this is f32 arithmetic carried by six 16x16x32 bf16 MFMAs (16 cycles each, K = 32 = 8 points x (3 + 1 pad))
+// instead of eight 16x16x4 f32 MFMAs (32 cycles each): 2.7x fewer matrix cycles, and they overlap with the producers.
+//   LDS: three bf16 planes [176 rows][72] per buffer (k = 4 q + d inside a 16-point chunk, d = 3 is a zero pad; 72 = 64 + 8
+//   keeps the 16-byte fragment reads of 16 consecutive rows on distinct banks), double-buffered: 2 x 76,032 B.
+//   The right-hand side b = panel^T z moves into the producers (11 more register accumulators per lane), so the
+//   consumers touch nothing but bf16 fragments.
+struct SchurBf3Cfg {
+  using elem = float;
+  static constexpr bool diag = true;
+  static constexpr int THREADS = SCHUR_THREADS, NPROD = 256, NCW = 4, TS = 1, NV = 4;
+  static constexpr int NTILE = (GROUP_TILES * (GROUP_TILES + 1)) / 2;
+  static constexpr int TPW = (NTILE + NV - 1) / NV;
+  static constexpr int PTS = 16, KQ = 4, K = PTS * KQ;            // 64 panel columns per chunk = 2 MFMA k-steps of 32
+  static constexpr int KP = K + 8;                                 // row stride in bf16 elements (144 B)
+  static constexpr int PLANE = GROUP_ROWS * KP;                    // bf16 elements per plane
+  static constexpr int BUF_BYTES = 3 * PLANE * 2;                  // h, m, l
+  static constexpr int UPKB = UPK + NCP;                           // per-lane accumulators handed over at the end: U (66) + g (11) + b (11)
+  static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES + (size_t)GROUP_CAMS * CAMPRE * sizeof(float);
+  static_assert(2 * (size_t)BUF_BYTES >= (size_t)(NPROD + GROUP_CAMS) * UPKB * sizeof(float), "the accumulator hand-over reuses the panel buffers");
+};
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
+    const ParamSets<float> ps, const LMState* __restrict__ st, int C,
+    const float2* __restrict__ uv, const float* __restrict__ w, const int32_t* __restrict__ pt_start,
+    const uint16_t* __restrict__ vis, int N, int ksplit, double* __restrict__ D2p, double* __restrict__ gp,
+    float* __restrict__ pf, float* __restrict__ slabs, double* __restrict__ bpart, double* __restrict__ gdpart,
+    double* __restrict__ cost_part, double* __restrict__ gmax_part, long long* __restrict__ dbg) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using T = float;
+  using Cfg = SchurBf3Cfg;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, KP = Cfg::KP, UPKB = Cfg::UPKB;
+  if (st->status >= 0) return;
+  const bool stamp_wg = dbg && blockIdx.x == 0;
+  if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ campre = ps.campre[cur_];
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  T* s_cam = reinterpret_cast<T*>(smem + 2 * Cfg::BUF_BYTES);            // [16][CAMPRE]
+  T* s_U = reinterpret_cast<T*>(smem);                                   // [256][UPKB] once the panels are done with
+  T* s_Ured = s_U + NPROD * UPKB;                                        // [C][UPKB]
+  __shared__ double s_scr[2][NPROD / 64];
+  {   // zero both buffers once: the pad column (d = 3) of every point is never written again
+    uint4* z4 = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < 2 * Cfg::BUF_BYTES / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
+  }
+  for (int i = threadIdx.x; i < C * CAMPRE; i += THREADS) s_cam[i] = campre[i];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool producer = threadIdx.x < NPROD;
+  int per = (N + ksplit - 1) / ksplit;
+  per = ((per + PTS - 1) / PTS) * PTS;
+  const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
+  const int nchunk = (pend - pbeg + PTS - 1) / PTS;
+  const T lam = (T)st->lam;
+  auto fold_u = [&]() {
+    for (int o = threadIdx.x; o < C * UPKB; o += THREADS) {
+      const int c = o / UPKB, k = o - c * UPKB;
+      T sum = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += s_U[(q * 16 + c) * UPKB + k];
+      s_Ured[o] = sum;
+    }
+  };
+  __syncthreads();
+
+  if (producer) {
+    const int q = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const bool cam_ok = c < C;
+    const T* cp_safe = s_cam + (cam_ok ? c : 0) * CAMPRE;
+    T Uacc[UPKB];
+    static_for<0, UPKB>([&](auto kc) { Uacc[decltype(kc)::value] = (T)0; });
+    T sq = 0, gmx = 0;
+    float2 n_uv = make_float2(0.f, 0.f);
+    T n_w = 1, n_X[3] = {0, 0, 0};
+    double n_D[3] = {0, 0, 0};
+    bool n_valid = false, n_pt = false;
+    unsigned i_mask = 0; int i_start = 0; bool i_pt = false;
+    auto request_index = [&](int chunk) {
+      const int p = pbeg + chunk * PTS + q;
+      i_pt = chunk < nchunk && p < pend;
+      i_mask = 0xffffu; i_start = 0;
+      if (i_pt && vis) { i_mask = vis[p]; i_start = pt_start[p]; }
+    };
+    auto request = [&](int chunk) {
+      const int p = pbeg + chunk * PTS + q;
+      n_pt = i_pt;
+      n_valid = i_pt && cam_ok && ((i_mask >> c) & 1u);
+      if (n_pt) {
+        n_X[0] = ptsT[3 * (size_t)p]; n_X[1] = ptsT[3 * (size_t)p + 1]; n_X[2] = ptsT[3 * (size_t)p + 2];
+        n_D[0] = D2p[3 * (size_t)p]; n_D[1] = D2p[3 * (size_t)p + 1]; n_D[2] = D2p[3 * (size_t)p + 2];
+      }
+      if (n_valid) {
+        const size_t o = vis ? (size_t)i_start + __builtin_popcount(i_mask & ((1u << c) - 1u)) : (size_t)p * C + c;
+        n_uv = uv[o];
+        n_w = w ? w[o] : (T)1;
+      }
+      request_index(chunk + 1);
+    };
+    request_index(0);
+    request(0);
+    if (stamp_wg && threadIdx.x == 0) dbg[49] = clock64();
+    // byte offset of this lane's 8-byte slot inside a plane row block: rows c*11 + e, columns 4q .. 4q+3
+    const int lane_slot = (c * NCP) * KP * 2 + q * 8;
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it < nchunk) {
+        unsigned char* pbuf = smem + (it & 1) * Cfg::BUF_BYTES;
+        const bool valid = n_valid, have_pt = n_pt;
+        const float2 m = n_uv;
+        const T ww = n_w, X0 = n_X[0], X1 = n_X[1], X2 = n_X[2];
+        const double D0 = n_D[0], D1 = n_D[1], D2 = n_D[2];
+        const int p = pbeg + it * PTS + q;
+        request(it + 1);
+        T r[2], Jc[2][NCP], Jp[2][3];
+        obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
+        sq += r[0] * r[0] + r[1] * r[1];
+        T v6[6], g3[3];
+        v6[0] = row16_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
+        v6[1] = row16_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
+        v6[2] = row16_sum(Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2]);
+        v6[3] = row16_sum(Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1]);
+        v6[4] = row16_sum(Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2]);
+        v6[5] = row16_sum(Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2]);
+        g3[0] = row16_sum(Jp[0][0] * r[0] + Jp[1][0] * r[1]);
+        g3[1] = row16_sum(Jp[0][1] * r[0] + Jp[1][1] * r[1]);
+        g3[2] = row16_sum(Jp[0][2] * r[0] + Jp[1][2] * r[1]);
+        gmx = fmaxf(gmx, fmaxf(fabsf(g3[0]), fmaxf(fabsf(g3[1]), fabsf(g3[2]))));
+        const double E0 = fmax(D0, (double)v6[0]), E1 = fmax(D1, (double)v6[3]), E2 = fmax(D2, (double)v6[5]);
+        T f[PF];
+        T li[6];
+        T vd[6] = {v6[0] + lam * (T)fmax_pos(E0), v6[1], v6[2], v6[3] + lam * (T)fmax_pos(E1), v6[4], v6[5] + lam * (T)fmax_pos(E2)};
+        const bool okp = have_pt && chol3_inv_fast(vd, li);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) f[k] = (T)0;
+        if (okp) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) f[k] = li[k];
+          f[6] = li[0] * g3[0];
+          f[7] = li[1] * g3[0] + li[2] * g3[1];
+          f[8] = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
+          f[9] = (T)1;
+        }
+        if (have_pt && c == 0) {
+          D2p[3 * (size_t)p] = E0; D2p[3 * (size_t)p + 1] = E1; D2p[3 * (size_t)p + 2] = E2;
+          gp[3 * (size_t)p] = (double)g3[0]; gp[3 * (size_t)p + 1] = (double)g3[1]; gp[3 * (size_t)p + 2] = (double)g3[2];
+          float4* o4 = reinterpret_cast<float4*>(pf + (size_t)p * PF);
+          o4[0] = make_float4(f[0], f[1], f[2], f[3]);
+          o4[1] = make_float4(f[4], f[5], f[6], f[7]);
+          o4[2] = make_float4(f[8], f[9], f[10], f[11]);
+        }
+        // Ytilde = Jc^T (Jp L^-T) (11x3; all zero for a degenerate point because f is), its three bf16 pieces into the planes,
+        // and the right-hand side  b_c += Ytilde z
+        T Jt[2][3];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          Jt[rr][0] = Jp[rr][0] * f[0];
+          Jt[rr][1] = Jp[rr][0] * f[1] + Jp[rr][1] * f[2];
+          Jt[rr][2] = Jp[rr][0] * f[3] + Jp[rr][1] * f[4] + Jp[rr][2] * f[5];
+        }
+        if (cam_ok) {
+          static_for<0, NCP>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            T y[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) y[d] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
+            Uacc[UPK + e] = __builtin_fmaf(y[2], f[8], __builtin_fmaf(y[1], f[7], __builtin_fmaf(y[0], f[6], Uacc[UPK + e])));
+            unsigned hb[3], mb[3], lb[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const unsigned yb = __builtin_bit_cast(unsigned, y[d]);
+              hb[d] = yb & 0xffff0000u;
+              const float r1 = y[d] - __builtin_bit_cast(float, hb[d]);          // exact: the low 16 mantissa bits
+              mb[d] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+              const float r2 = r1 - __builtin_bit_cast(float, mb[d]);            // exact: at most 8 significant bits left
+              lb[d] = __builtin_bit_cast(unsigned, r2);
+            }
+            unsigned char* dst = pbuf + lane_slot + e * (KP * 2);
+            *reinterpret_cast<uint2*>(dst) = make_uint2((hb[0] >> 16) | hb[1], hb[2] >> 16);
+            *reinterpret_cast<uint2*>(dst + Cfg::PLANE * 2) = make_uint2((mb[0] >> 16) | mb[1], mb[2] >> 16);
+            *reinterpret_cast<uint2*>(dst + 2 * Cfg::PLANE * 2) = make_uint2((lb[0] >> 16) | (lb[1] & 0xffff0000u), lb[2] >> 16);
+          });
+        }
+        static_for<0, NCP>([&](auto ac) {
+          constexpr int a = decltype(ac)::value;
+          static_for<a, NCP>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            constexpr int k = a * NCP - (a * (a - 1)) / 2 + (b - a);
+            Uacc[k] = __builtin_fmaf(Jc[1][a], Jc[1][b], __builtin_fmaf(Jc[0][a], Jc[0][b], Uacc[k]));
+          });
+          Uacc[NCP * (NCP + 1) / 2 + a] = __builtin_fmaf(Jc[1][a], r[1], __builtin_fmaf(Jc[0][a], r[0], Uacc[NCP * (NCP + 1) / 2 + a]));
+        });
+      }
+      if (stamp_wg && threadIdx.x == 0 && it < 20) dbg[2 * it] = clock64();
+      __syncthreads();
+    }
+    if (stamp_wg && threadIdx.x == 0) dbg[50] = clock64();
+    __syncthreads();                       // the consumers have read the last panel: the buffers become the hand-over area
+    static_for<0, UPKB>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * UPKB + k] = Uacc[k]; });
+    const double cs = wave_sum((double)sq), gm = wave_max((double)gmx);
+    if (lane == 0) { s_scr[0][wid] = cs; s_scr[1][wid] = gm; }
+    __syncthreads();
+    fold_u();
+    __syncthreads();
+  } else {
+    const int cw = wid - NPROD / 64;
+    typename Mfma<T>::acc_t acc[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) acc[s] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+    const int ct = threadIdx.x - NPROD;
+    // fragment of row tile b, k-step s: 8 consecutive k of row 16 b + (lane & 15), starting at 32 s + 8 (lane >> 4)
+    const int frag_off = ((lane & 15) * KP + 8 * (lane >> 4)) * 2;
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it >= 1) {
+        const unsigned char* pbuf = smem + ((it - 1) & 1) * Cfg::BUF_BYTES + frag_off;
+        static_for<0, Cfg::NV>([&](auto vc) {
+          constexpr int V = decltype(vc)::value;
+          if (cw == V) {
+            constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
+            constexpr int RMIN = schur_tile_R(true, LO);
+#pragma unroll
+            for (int s = 0; s < Cfg::K / 32; ++s) {
+              bf16x8_t fh[GROUP_TILES], fo[GROUP_TILES];
+              auto load = [&](bf16x8_t (&dst)[GROUP_TILES], int plane) {
+#pragma unroll
+                for (int b = RMIN; b < GROUP_TILES; ++b)
+                  dst[b] = *reinterpret_cast<const bf16x8_t*>(pbuf + plane * (Cfg::PLANE * 2) + (16 * b * KP + 32 * s) * 2);
+              };
+              load(fh, 0);
+              load(fo, 1);
+              // h h'
+              static_for<LO, HI>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fh[Tc], acc[t - LO], 0, 0, 0);
+              });
+              // h m' + m h' + m m'
+              static_for<LO, HI>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fo[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo[R], fh[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo[R], fo[Tc], acc[t - LO], 0, 0, 0);
+              });
+              load(fo, 2);
+              // h l' + l h'
+              static_for<LO, HI>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fo[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo[R], fh[Tc], acc[t - LO], 0, 0, 0);
+              });
+            }
+          }
+        });
+      }
+      if (stamp_wg && threadIdx.x == NPROD && it < 20) dbg[2 * it + 1] = clock64();
+      __syncthreads();
+    }
+    __syncthreads();                       // matches the producers' barrier in front of the hand-over
+    __syncthreads();                       // accumulators are in s_U
+    fold_u();
+    __syncthreads();
+    static_for<0, Cfg::NV>([&](auto vc) {
+      constexpr int V = decltype(vc)::value;
+      if (cw == V) {
+        constexpr int T0 = schur_lo(Cfg::NTILE, Cfg::NV, V), T1 = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
+        static_for<T0, T1>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+          if constexpr (Tc - R <= 1) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int i = 16 * R + Mfma<T>::row_of(lane, rg), j = 16 * Tc + (lane & 15);
+              const int ci_ = i / NCP, cj_ = j / NCP;
+              if (ci_ == cj_ && ci_ < C) {
+                const int a = min(i - ci_ * NCP, j - cj_ * NCP), b = max(i - ci_ * NCP, j - cj_ * NCP);
+                acc[t - T0][rg] -= s_Ured[ci_ * UPKB + (a * NCP - (a * (a - 1)) / 2 + (b - a))];
+              }
+            }
+          }
+        });
+      }
+    });
+    if (stamp_wg && threadIdx.x == NPROD) dbg[51] = clock64();
+    T* slab = slabs + (size_t)blockIdx.x * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
+    schur_store_v<Cfg>(cw, slab, lane, acc);
+    if (stamp_wg && threadIdx.x == NPROD) dbg[52] = clock64();
+    if (ct < GROUP_ROWS) {
+      const int c = ct / NCP, e = ct - c * NCP;
+      const double gpart = (c < C) ? (double)s_Ured[c * UPKB + NCP * (NCP + 1) / 2 + e] : 0.0;
+      const double dpart = (c < C) ? (double)s_Ured[c * UPKB + (e * NCP - (e * (e - 1)) / 2)] : 0.0;
+      const double bsum = (c < C) ? (double)s_Ured[c * UPKB + UPK + e] : 0.0;
+      bpart[(size_t)blockIdx.x * GROUP_ROWS + ct] = bsum - gpart;             // rhs = sum (b - g_c) over the workgroups
+      gdpart[((size_t)blockIdx.x * 2 + 0) * GROUP_ROWS + ct] = gpart;
+      gdpart[((size_t)blockIdx.x * 2 + 1) * GROUP_ROWS + ct] = dpart;
+    }
+  }
+  if (threadIdx.x == 0) {
+    double cs = 0, gm = 0;
+    for (int wv = 0; wv < NPROD / 64; ++wv) { cs += s_scr[0][wv]; gm = fmax(gm, s_scr[1][wv]); }
+    cost_part[blockIdx.x] = 0.5 * cs;
+    gmax_part[blockIdx.x] = gm;
+    if (stamp_wg) dbg[53] = clock64();
+  }
+}
 #endif  // SBA_NCP == 11 (fused linearise + Schur kernel)
 
 }  // namespace SBA_NS
