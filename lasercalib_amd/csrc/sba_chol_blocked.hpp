@@ -23,7 +23,8 @@ namespace SBA_NS {
 constexpr int CB = 16;                 // block edge
 constexpr int CLD = 17;                // row stride inside a block (doubles)
 constexpr int CBS = CB * CLD;          // doubles per block
-constexpr int CHOLB_THREADS = 512;
+constexpr int CHOLB_THREADS = 512;          // k_cholesky_stream
+constexpr int CHOLB_LDS_THREADS = 512;      // k_cholesky_blocked (1024 was measured: same 116k cycles, the pivot chain and the load set the time)
 constexpr int CHOLB_MAX_NB = 11;       // 176 rows
 
 __device__ inline int cb_off(int r, int c) { return (r * (r + 1) / 2 + c) * CBS; }
@@ -55,15 +56,24 @@ __device__ __forceinline__ bool chol16_wave(double* __restrict__ blk) {
   for (int j = 0; j < CB; ++j) { const double v = blk[i * CLD + j]; a[j] = ident ? ((j == i) ? 1.0 : 0.0) : v; }
   __builtin_amdgcn_wave_barrier();
   bool ok = true;
+  // The serial chain of the whole factorisation runs through here: pivot k+1 needs a[k+1] after column step k.  The source
+  // order puts that one critical update first and starts the next pivot's reciprocal square root right behind it, so that its
+  // latency (v_rsq_f64 + one Newton step) is covered by the 14 - k updates of the other columns, which nobody waits for.
+  double akk = readlane_f64(a[0], 0);
+  if (!(akk > 0.0) || !isfinite(akk)) ok = false;
+  double piv = rsqrt_nr(ok ? akk : 1.0);
 #pragma unroll
   for (int k = 0; k < CB; ++k) {
-    const double akk = readlane_f64(a[k], k);
-    if (!(akk > 0.0) || !isfinite(akk)) ok = false;
-    const double piv = rsqrt_nr(ok ? akk : 1.0);
     const double lik = a[k] * piv;
     a[k] = lik;
+    if (k + 1 < CB) {
+      a[k + 1] -= lik * readlane_f64(lik, k + 1);
+      akk = readlane_f64(a[k + 1], k + 1);
+      if (!(akk > 0.0) || !isfinite(akk)) ok = false;
+      piv = rsqrt_nr(ok ? akk : 1.0);
+    }
 #pragma unroll
-    for (int j = k + 1; j < CB; ++j) a[j] -= lik * readlane_f64(lik, j);
+    for (int j = k + 2; j < CB; ++j) a[j] -= lik * readlane_f64(lik, j);
   }
   if (lane >= 16 && lane < 32) {
 #pragma unroll
@@ -102,7 +112,7 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ Dt, const 
 }
 
 template <typename T>
-__global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
+__global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     const double* __restrict__ E /* summed exchange buffer [S | rhs | diagU | gc | cost] */, int C,
     LMState* __restrict__ st, double* __restrict__ D2c, const ParamSets<T> ps,
     double* __restrict__ delta_c, int n_sys /* size of the system in E: 11*C, or fewer when cameras share parameters */,
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   __shared__ int s_fail;
   __shared__ short s_rc[CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2];   // block index -> (r << 8 | c)
   __shared__ short s_cm[CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2];   // column-major list of the blocks with c >= 1
-  __shared__ double s_scr[4][CHOLB_THREADS / 64];
+  __shared__ double s_scr[4][CHOLB_LDS_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double* rhs = E + (size_t)n * n;
   const double* dU = rhs + n;
@@ -161,9 +171,10 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   // All loads are unconditional (out-of-range ones are clamped to a valid address and replaced afterwards) and sit in
   // straight-line code: only then can the compiler wait with vmcnt(N) for the first block column alone.
   const bool pair_ok = (n & 1) == 0;
-  constexpr int U0 = (CHOLB_MAX_NB + 3) / 4;                                   // 3 rounds of 4 blocks: first block column
+  constexpr int BPR = CHOLB_LDS_THREADS / 128;                                // blocks of the first column per load round (128 threads each)
+  constexpr int U0 = (CHOLB_MAX_NB + BPR - 1) / BPR;                           // rounds for the first block column
   constexpr int NREM = CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2;                  // 55 other blocks
-  constexpr int TREM = CHOLB_THREADS - 64;                                     // loaded by waves 1..7
+  constexpr int TREM = CHOLB_LDS_THREADS - 64;                                     // loaded by waves 1..7
   constexpr int U1 = (NREM * 128 + TREM - 1) / TREM;                           // 16 rounds
   double c0[U0][2], c1[U1][2];
   const int nlast = n - 1;
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   if (pair_ok) {
 #pragma unroll
     for (int u = 0; u < U0; ++u) {
-      const double2 t = *reinterpret_cast<const double2*>(addr((4 * u + s4) * CB + ii0, 2 * jp0));
+      const double2 t = *reinterpret_cast<const double2*>(addr((BPR * u + s4) * CB + ii0, 2 * jp0));
       c0[u][0] = t.x; c0[u][1] = t.y;
     }
     in_d = D2c[tclamp]; in_u = dU[tclamp]; in_r = rhs[tclamp];
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   } else {
 #pragma unroll
     for (int u = 0; u < U0; ++u) {
-      const double* q = addr((4 * u + s4) * CB + ii0, 2 * jp0);
+      const double* q = addr((BPR * u + s4) * CB + ii0, 2 * jp0);
       c0[u][0] = q[0]; c0[u][1] = q[(2 * jp0 + 1 < n) ? 1 : 0];
     }
     in_d = D2c[tclamp]; in_u = dU[tclamp]; in_r = rhs[tclamp];
@@ -206,9 +217,9 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
     }
   }
 #pragma unroll
-  for (int u = 0; u < U0; ++u) fix((4 * u + s4) * CB + ii0, 2 * jp0, c0[u][0], c0[u][1]);
+  for (int u = 0; u < U0; ++u) fix((BPR * u + s4) * CB + ii0, 2 * jp0, c0[u][0], c0[u][1]);
   // camera scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
-  if (tid < n16) {                                 // n16 <= 176 < CHOLB_THREADS
+  if (tid < n16) {                                 // n16 <= 176 < CHOLB_LDS_THREADS
     double dd = 0;
     if (tid >= n) in_r = 0;
     if (tid < n) {
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
     const int ii = ii0, jp = jp0;
 #pragma unroll
     for (int u = 0; u < U0; ++u) {
-      const int r = 4 * u + s4;
+      const int r = BPR * u + s4;
       if (r < nb) {
         const int I = r * CB + ii, J = 2 * jp;
         double* dst = Lb + cb_off(r, 0) + ii * CLD + J;
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   __syncthreads();
   CHOL_STAMP();
 
-  constexpr int NW = CHOLB_THREADS / 64;
+  constexpr int NW = CHOLB_LDS_THREADS / 64;
   for (int jb = 0; jb < nb && !s_fail; ++jb) {
     const int m = (nb - jb - 1) * CB;              // rows below the diagonal block
     const double* LinvT = Lb + cb_off(jb, jb);
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   __syncthreads();
   CHOL_STAMP();
   double pred = 0, dx2 = 0, x2 = 0, gm = 0;
-  if (tid < ncam) {                                  // 11*C <= 176 < CHOLB_THREADS: one camera parameter per thread
+  if (tid < ncam) {                                  // 11*C <= 176 < CHOLB_LDS_THREADS: one camera parameter per thread
     const double d = fail ? 0.0 : s_y[tie ? tie[tid] : tid];
     delta_c[tid] = d;
     cams_new[tid] = my_cam + d;
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_blocked(
   __syncthreads();      // also orders the cams_new stores before the CamPre rebuild below
   if (tid == 0) {
     double p = 0, d2 = 0, xx = 0, g = 0;
-    for (int w = 0; w < CHOLB_THREADS / 64; ++w) { p += s_scr[0][w]; d2 += s_scr[1][w]; xx += s_scr[2][w]; g = fmax(g, s_scr[3][w]); }
+    for (int w = 0; w < CHOLB_LDS_THREADS / 64; ++w) { p += s_scr[0][w]; d2 += s_scr[1][w]; xx += s_scr[2][w]; g = fmax(g, s_scr[3][w]); }
     st->pred_c = p; st->dx2_c = d2; st->x2_c = xx; st->gmax_c = g;
     st->chol_fail = fail ? 1 : 0;
     st->fresh = 0;

@@ -852,7 +852,7 @@ struct Engine : EngineBase {
         const int nb = (n_sys + CB - 1) / CB;
         const size_t lds = ((size_t)(nb * (nb + 1) / 2) * CBS + 2 * (size_t)nb * CB) * sizeof(double);
         if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }
-        hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
+        hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_LDS_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
                            ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr,
                            chol_debug ? chol_dbg.p : nullptr);
         if (chol_debug) {

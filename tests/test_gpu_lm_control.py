@@ -96,8 +96,11 @@ def test_nonfinite_trial_is_rejected_and_retried(golden, dtype):
         assert rows[2][0] is True                                         # the retry with the larger damping goes through
         assert status in (2, 3, 4) and np.all(np.isfinite(cams)) and np.all(np.isfinite(pts))
         c2, p2, clean, _ = _dev(p, dtype=dtype, ftol=1e-6)
-        # two damping histories stopped by the same ftol = 1e-6: they end within a few ftol of each other (observed 3.7e-6)
-        assert abs(rep.cost - clean.cost) <= (1e-5 if dtype == "f64" else 1e-4) * clean.cost
+        # two damping histories stopped by the same ftol = 1e-6: in fp64 they end within a few ftol of each other (observed
+        # 3.7e-6).  In fp32 a cost difference of 1e-6 relative is below the rounding noise of the cost itself, so where such a
+        # crawling solve (50+ iterations on this sparse 5 x 200 rig) stops is not reproducible between two trajectories:
+        # observed 5e-4 apart, both within 1e-3 of the fp64 optimum
+        assert abs(rep.cost - clean.cost) <= (1e-5 if dtype == "f64" else 1e-3) * clean.cost
 
 
 def test_far_start_with_outliers_ends_in_a_stationary_point():
