@@ -36,10 +36,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # f32-in MFMA = vector rate 157.3 TF; f64 MFMA is half that on CDNA4
-# HBM bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_*: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+# HBM bytes per launch from rocprofv3 PMC passes (profiles/r2_pmc_*: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
 # 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).  Valid for the default workload only
 # (16 cams x 50k points, f32, one GPU); other shapes report null.
-PMC_TRAFFIC_BYTES_16x50k_F32 = {"schur_fused": 30.56e6, "schur": 26.58e6, "resjac": 104.62e6, "linearize_points": 19.93e6,
+PMC_TRAFFIC_BYTES_16x50k_F32 = {"schur_fused": 30.58e6, "schur": 26.58e6, "resjac": 104.62e6, "linearize_points": 19.92e6,
                                 "linearize_cams": 15.52e6, "backsub": 14.54e6, "residual": 13.12e6}
 
 
@@ -215,12 +215,17 @@ def main():
             # share the SIMD's FMA lanes (tools/micro/mix_waves.hip: their times add), reported beside `frac`, not in it
             flops_valu = (870.0 * M_local + (50.0 + 198.0 * C) * Nloc) if fused else 0.0
             ach = flops_mfma / (kt["schur"] * 1e-6) / 1e12                     # roofline fraction = MFMA work only
-            roof = {"kernel": "k_schur_fused" if fused else ("k_schur_sym" if a.dtype == "f64" else "k_schur"), "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[a.dtype],
+            bf3 = fused and os.environ.get("SBA_FUSED_MFMA", "bf3") != "f32"
+            roof = {"kernel": ("k_schur_fused_bf3" if bf3 else "k_schur_fused") if fused else ("k_schur_sym" if a.dtype == "f64" else "k_schur"), "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[a.dtype],
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype], "traffic": traffic("schur_fused" if fused else "schur"),
                     "algorithmic_flops_per_launch": flops_mfma, "launch_us": kt["schur"],
                     # the linearisation the fused kernel also carries on the VALU (SURVEY 8d estimate), kept apart from `frac`
                     "valu_flops_estimate": flops_valu,
-                    "frac_with_valu_estimate": (flops_mfma + flops_valu) / (kt["schur"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS[a.dtype]}
+                    "frac_with_valu_estimate": (flops_mfma + flops_valu) / (kt["schur"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS[a.dtype],
+                    "note": ("algorithmic f32 flops of the symmetric Schur product against the f32-input MFMA peak (= f32 vector peak). "
+                             "k_schur_fused_bf3 forms every f32 product exactly from six bf16 partial products on the bf16 matrix pipe "
+                             "(3-way split of the f32 panel), so the f32 MFMA peak is the yardstick BASELINE/SURVEY name, not a hard ceiling "
+                             "for this kernel; its own limit is the producers' VALU work (DESIGN.md 4.2)") if bf3 else None}
         else:
             by = algorithmic_bytes_per_obs(dominant, s, C, shard["pts"].shape[0], M_local) * M_local
             ach = by / (kt[dominant] * 1e-6) / 1e9
