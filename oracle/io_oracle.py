@@ -4,8 +4,9 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 (lasercalib_amd/dataset.py, convert_params.py, report.py) never does.
 
 Pinning: the dataset-builder functions restate loops that live inside two reference SCRIPTS with top-level file and GUI
-I/O (scripts/get_points3d.py, scripts/calibrate_camera.py) which cannot be imported -- **parity unpinned** for those two
-(the loops below follow the reference line by line and the product is checked against them).  The conversion functions
+I/O (scripts/get_points3d.py, scripts/calibrate_camera.py) which cannot be imported; they are **pinned by
+tests/golden/f7_dataset.npz**, which oracle/make_golden.py f7 recorded by exec'ing the reference's own line ranges
+(get_points3d.py:48-61,73-86; calibrate_camera.py:35-44) on synthetic centroids.  The conversion functions
 are pinned by tests/golden/f6_convert.npz, produced by the reference's own ``sba_to_readable_format`` /
 ``readable_to_red_format`` (oracle/make_golden.py f6).
 """

@@ -31,6 +31,7 @@ from lasercalib_amd.synth import make_rig  # noqa: E402
 from oracle import sba_oracle as orc  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
+REF = "/root/reference"
 VERS = dict(scipy_version=scipy.__version__, numpy_version=np.__version__)
 
 
@@ -165,6 +166,53 @@ def f5_variants():
     np.savez_compressed(os.path.join(OUT, "f5_variants.npz"), **out, **VERS)
 
 
+
+def _reference_lines(rel_path, first, last, dedent=0):
+    """Source lines [first, last] (1-based, inclusive) of a reference script, de-indented -- executed here, never stored."""
+    with open(os.path.join(REF, rel_path)) as f:
+        lines = f.read().split("\n")[first - 1:last]
+    return "\n".join(l[dedent:] if l.strip() else "" for l in lines)
+
+
+def f7_dataset():
+    """Observation-list builder and dataset concatenation, recorded FROM THE REFERENCE'S OWN LOOPS.
+
+    The loops live inside two scripts with top-level I/O (not importable), so their line ranges are read from
+    /root/reference and exec'd on synthetic centroids: scripts/get_points3d.py:48-61 (flip, filter) and :73-86 (the
+    camera_ind / point_ind / points_2d double loop), scripts/calibrate_camera.py:35-44 (stacking with the non-cumulative
+    point offset).  Only the input and output ARRAYS are stored (tests/golden/f7_dataset.npz)."""
+    rng = np.random.default_rng(77)
+    out = {}
+    datasets = []
+    n_cams = 5
+    cam_names = [f"Cam{i}" for i in range(n_cams)]
+    for d, n_pts in enumerate((60, 45, 30)):
+        centroids = rng.uniform(0.0, 3000.0, (n_pts, 2, n_cams))
+        unseen = rng.random((n_pts, n_cams)) < 0.35                   # NaN pairs: camera did not see the spot
+        centroids[np.repeat(unseen[:, None, :], 2, axis=1)] = np.nan
+        out[f"d{d}_centroids"] = centroids.copy()
+        ns = dict(np=np, centroids=centroids.copy(), cam_names=cam_names, cam_name_for_3d_init="Cam2", n_pts=n_pts,
+                  min_num_cam_per_point=3, n_cams=n_cams, print=lambda *a, **k: None)
+        exec(_reference_lines("scripts/get_points3d.py", 48, 61, dedent=4), ns)
+        exec(_reference_lines("scripts/get_points3d.py", 73, 86, dedent=4), ns)
+        out[f"d{d}_keep"] = ns["keep"]
+        out[f"d{d}_in_pts"] = ns["in_pts"]
+        out[f"d{d}_camera_ind"] = ns["camera_ind"]
+        out[f"d{d}_point_ind"] = ns["point_ind"]
+        out[f"d{d}_points_2d"] = ns["points_2d"]
+        pts3 = rng.normal(0.0, 300.0, (ns["n_in_pts"], 3))
+        out[f"d{d}_points_3d"] = pts3
+        datasets.append({"n_cams": n_cams, "n_pts": ns["n_in_pts"], "points_2d": ns["points_2d"], "points_3d": pts3,
+                         "camera_ind": ns["camera_ind"], "point_ind": ns["point_ind"]})
+    for tag, sel in (("two", datasets[:2]), ("three", datasets)):
+        ns = dict(np=np, points_dataset=sel)
+        exec(_reference_lines("scripts/calibrate_camera.py", 35, 44), ns)
+        out[f"cat_{tag}_n_cams"] = np.array(ns["n_cams"])
+        for k in ("points_3d", "points_2d", "camera_ind", "point_ind"):
+            out[f"cat_{tag}_{k}"] = ns[k]
+    np.savez_compressed(os.path.join(OUT, "f7_dataset.npz"), **out, **VERS)
+
+
 def f6_convert():
     """Conversion functions of the reference (lasercalib/convert_params.py:7-27) on the shipped example calibration.
 
@@ -205,7 +253,7 @@ def f6_convert():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    stages = dict(f1=f1_project, f2=f2_fun, f3=f3_jacobian, f4=f4_f6_solves, f5=f5_variants, f6=f6_convert)
+    stages = dict(f1=f1_project, f2=f2_fun, f3=f3_jacobian, f4=f4_f6_solves, f5=f5_variants, f6=f6_convert, f7=f7_dataset)
     for name in (sys.argv[1:] or list(stages)):
         stages[name]()
     for f in sorted(os.listdir(OUT)):

@@ -182,3 +182,36 @@ def test_tangential_rows_export_p1_p2(tmp_path):
     back = cp.initialize_from_checkerboard(str(tmp_path), 1, ["B"], tangential=True)
     assert back.shape == (1, 13) and np.allclose(back[0, 6:], row13[6:], rtol=1e-12) and np.allclose(back[0, 3:6], row13[3:6])
     assert cp.initialize_from_checkerboard(str(tmp_path), 1, ["B"]).shape == (1, 11)
+
+
+# ----------------------------------------------------------------------------- pinned by the reference's own loops (F7)
+def test_dataset_builder_pinned_by_reference_loops(golden):
+    """tests/golden/f7_dataset.npz was recorded by exec'ing the reference's own line ranges -- scripts/get_points3d.py:48-61,
+    73-86 and scripts/calibrate_camera.py:35-44 -- on synthetic centroids (oracle/make_golden.py f7): the vectorised product
+    code and the restated oracle must both reproduce those arrays exactly, including the xy flip, the keep rule, the
+    point-major / camera-minor order, dtypes, and the NON-cumulative point offset with three datasets."""
+    g = golden("f7_dataset.npz")
+    datasets = []
+    for d in range(3):
+        cen = np.flip(g[f"d{d}_centroids"], axis=1)                    # get_points3d.py:48
+        keep = ds.filter_points(cen, 3, 2)
+        assert np.array_equal(keep, g[f"d{d}_keep"]) and np.array_equal(keep, orc.filter_points_loop(cen, 3, 2))
+        in_pts = cen[keep]
+        assert np.array_equal(in_pts, g[f"d{d}_in_pts"], equal_nan=True)
+        ci, pi, uv = ds.observation_list(in_pts)
+        for got, key in ((ci, "camera_ind"), (pi, "point_ind"), (uv, "points_2d")):
+            assert got.dtype == g[f"d{d}_{key}"].dtype and np.array_equal(got, g[f"d{d}_{key}"])
+        ci2, pi2, uv2 = orc.observation_list_loop(in_pts)
+        assert np.array_equal(ci2, ci) and np.array_equal(pi2, pi) and np.array_equal(uv2, uv)
+        assert ds.is_point_major(pi)
+        datasets.append(ds.make_dataset(in_pts, g[f"d{d}_points_3d"]))
+    for tag, sel in (("two", datasets[:2]), ("three", datasets)):
+        n_cams, p3, p2, ci, pi = ds.concatenate_datasets(sel)
+        assert n_cams == int(g[f"cat_{tag}_n_cams"])
+        for got, key in ((p3, "points_3d"), (p2, "points_2d"), (ci, "camera_ind"), (pi, "point_ind")):
+            assert np.array_equal(got, g[f"cat_{tag}_{key}"])
+        o = orc.concatenate_loop(sel)
+        assert np.array_equal(o[4], pi) and np.array_equal(o[3], ci)
+    # the quirk is real in the recorded data: with three datasets the last offset is n_pts of dataset 1 alone
+    assert g["cat_three_point_ind"].max() < sum(int(d["n_pts"]) for d in datasets) - 1
+    assert ds.concatenate_datasets(datasets, cumulative_offsets=True)[4].max() == sum(int(d["n_pts"]) for d in datasets) - 1
