@@ -195,6 +195,20 @@ int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_re
 /* Rows of the per-iteration log collected so far (filled in by sba_lm_poll / sba_lm_finish). */
 int sba_lm_get_log(sba_handle* h, sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows);
 
+/* ---------------------------------------------------------------- opt-in extensions; off by default
+ * sba_set_fixed_points: the reference accepts `points3Dfixed` and never uses it (pySBA.py:28,55), so all 7 degrees of freedom of
+ *     the similarity gauge float.  fixed_mask[p] != 0 holds point p at its uploaded coordinates: it drops out of the unknowns (no
+ *     3x3 block, no step, not counted in x / gradient norms) while its observations keep constraining the cameras.  NULL clears.
+ * sba_set_robust_loss: the objective of scipy.optimize.least_squares(loss='huber', f_scale), on every residual component
+ *     (rho(z) = z for z <= 1, 2 sqrt(z) - 1 beyond, z = (f / f_scale)^2; cost = 0.5 f_scale^2 sum rho), minimised by
+ *     iteratively re-weighted Gauss-Newton steps (rows scaled by sqrt(rho')); the reference calls least_squares with the
+ *     default linear loss (pySBA.py:141).  sba_residual keeps returning the plain residual vector;
+ *     reported costs are the robust ones.  Applies to modes FULL / POINTS_ONLY / SHARED_INTR.
+ * Both persist on the handle until changed. */
+typedef enum { SBA_LOSS_LINEAR = 0, SBA_LOSS_HUBER = 1 } sba_loss;
+int sba_set_fixed_points(sba_handle* h, const uint8_t* fixed_mask /*N bytes or NULL*/);
+int sba_set_robust_loss(sba_handle* h, int32_t loss /*sba_loss*/, double f_scale);
+
 /* ---------------------------------------------------------------- multi-GPU inside the library (RCCL over xGMI)
  * One process per GPU, one handle per process holding a contiguous slice of the points and all their observations
  * (cameras replicated).  After sba_comm_init the handle's sba_solve_lm runs the sharded loop itself: per LM trial ONE

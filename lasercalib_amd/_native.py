@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsba_hip.so")
 
 SBA_F64, SBA_F32 = 0, 1
 CAM_RADIAL, CAM_RADIAL_TANGENTIAL = 0, 1        # sba_cam_model: 11 / 13 parameters per camera
+LOSS_LINEAR, LOSS_HUBER = 0, 1                   # sba_loss
 MODE_FULL, MODE_POINTS_ONLY, MODE_SHARED_INTR, MODE_CAMS_ONLY_SQ, MODE_TRANSFORM_SQ = 0, 1, 2, 3, 4
 NSCALARS = 8
 
@@ -26,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "sba_get_gradient", "sba_get_transform", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
     "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_finish", "sba_lm_get_log", "sba_time_kernel", "sba_get_kernel_profile",
-    "sba_comm_get_unique_id", "sba_comm_init",
+    "sba_comm_get_unique_id", "sba_comm_init", "sba_set_fixed_points", "sba_set_robust_loss",
 )
 
 
@@ -133,6 +134,8 @@ def load():
         "sba_get_kernel_profile": (C.c_int, [H, dp, ip]),
         "sba_comm_get_unique_id": (C.c_int, [C.c_char_p]),
         "sba_comm_init": (C.c_int, [H, C.c_char_p, C.c_int32, C.c_int32]),
+        "sba_set_fixed_points": (C.c_int, [H, C.c_void_p]),
+        "sba_set_robust_loss": (C.c_int, [H, C.c_int32, C.c_double]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -263,6 +266,24 @@ class Problem:
             raise ValueError("unique_id must be the 128 bytes comm_unique_id() returned on rank 0")
         _check(self._lib.sba_comm_init(self._h, bytes(unique_id), int(rank), int(n_ranks)), self._h)
         self.comm_rank, self.comm_n = int(rank), int(n_ranks)
+
+    # -- opt-in extensions (off by default: the reference ignores points3Dfixed and uses the linear loss)
+    def set_fixed_points(self, mask):
+        """mask: (N,) booleans / 0-1, True = the point is held at its uploaded coordinates (gauge anchor); None clears."""
+        if mask is None:
+            _check(self._lib.sba_set_fixed_points(self._h, None), self._h)
+            return
+        m = np.ascontiguousarray(np.asarray(mask).reshape(-1) != 0, dtype=np.uint8)
+        if m.shape[0] != self.N:
+            raise ValueError("fixed-point mask must have one entry per 3-D point")
+        _check(self._lib.sba_set_fixed_points(self._h, m.ctypes.data_as(C.c_void_p)), self._h)
+
+    def set_robust_loss(self, loss="huber", f_scale=1.0):
+        """scipy.optimize.least_squares(loss=..., f_scale=...) semantics; loss in ('linear', 'huber')."""
+        code = {"linear": LOSS_LINEAR, "huber": LOSS_HUBER}.get(loss)
+        if code is None:
+            raise ValueError("loss must be 'linear' or 'huber'")
+        _check(self._lib.sba_set_robust_loss(self._h, code, float(f_scale)), self._h)
 
     # -- lifetime
     def close(self):

@@ -230,6 +230,16 @@ int sba_comm_init(sba_handle* h, const uint8_t* id, int32_t rank, int32_t n_rank
   return guarded(h, [&] { return h->eng->comm_init(id, rank, n_ranks); });
 }
 
+int sba_set_fixed_points(sba_handle* h, const uint8_t* fixed_mask) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return h->eng->set_fixed_points(fixed_mask); });
+}
+
+int sba_set_robust_loss(sba_handle* h, int32_t loss, double f_scale) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return h->eng->set_robust_loss(loss, f_scale); });
+}
+
 int sba_time_kernel(sba_handle* h, const char* name, int32_t reps, double* mean_us_out) {
   if (!h || !name || !mean_us_out) return SBA_ERR_INVALID;
   return guarded(h, [&] { return h->eng->time_kernel(name, reps, mean_us_out); });

@@ -66,6 +66,9 @@ struct Engine : EngineBase {
   bool chol_debug = false;
   bool schur_debug = false;
   // multi-rank (one handle per GPU, points sharded, cameras replicated): RCCL communicator + exchange buffers
+  DevBuf<unsigned char> pt_fixed_mask;   // sba_set_fixed_points: 1 = the point is a gauge anchor (never moves, not an unknown)
+  bool has_fixed = false;
+  double loss_delta = 0;                // sba_set_robust_loss: Huber f_scale, 0 = linear loss
   Rccl::comm_t comm = nullptr;
   int comm_rank = 0, comm_n = 1;
   DevBuf<double> xpack, sc_loc, sc_all, comm_tmp;
@@ -377,6 +380,8 @@ struct Engine : EngineBase {
   void push_ptrs() {                 // (re)build the by-value kernel argument for the host's notion of `cur`
     for (int b = 0; b < 2; ++b) { psets.cams[b] = cams[b].p; psets.pts[b] = pts[b].p; psets.ptsT[b] = ptsT[b].p; psets.campre[b] = campre[b].p; }
     psets.base = cur;
+    psets.loss_delta = (float)loss_delta;
+    psets.fixed = has_fixed ? pt_fixed_mask.p : nullptr;
   }
   // argument for launches inside the LM loop (side = base ^ LMState::cur) ...
   ParamSets<T> ps_lm() const { return psets; }
@@ -386,7 +391,7 @@ struct Engine : EngineBase {
     const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
     if (g == 0) return;
     hipLaunchKernelGGL(k_residual<T>, dim3(g), dim3(PM_BLOCK), lds_cams(), stream, campre[cur].p, C, ptsT[cur].p,
-                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, r_out, cost_part.p);
+                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, r_out, cost_part.p, (T)loss_delta);
   }
   void launch_resjac(T2* r_out) {
     const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
@@ -453,7 +458,8 @@ struct Engine : EngineBase {
       }
     }
     if (N > 0)
-      hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
+      hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p,
+                         has_fixed ? pt_fixed_mask.p : (const unsigned char*)nullptr);
     // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
     // a camera count that is not a multiple of 16 leaves the last group's panel mostly empty: the PARTIAL
     // instantiations skip the MFMAs of empty tiles (kept apart so that the full-group kernels pay nothing for it)
@@ -902,7 +908,8 @@ struct Engine : EngineBase {
     } else {
       hipLaunchKernelGGL(k_nocam_step, dim3(1), dim3(64), 0, stream, d_state.p, E, n);
       if (N > 0)
-        hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p);
+        hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p,
+                         has_fixed ? pt_fixed_mask.p : (const unsigned char*)nullptr);
     }
     if (sq_mode()) { launch_sq_trial(); return SBA_OK; }
     prof_begin(KP_BACKSUB);
@@ -1124,6 +1131,26 @@ struct Engine : EngineBase {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
     *mean_us = (double)ms * 1e3 / reps;
+    return SBA_OK;
+  }
+
+  // ------------------------------------------------------------------ opt-in extensions
+  int set_fixed_points(const uint8_t* mask) override {
+    if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
+    has_fixed = false;
+    if (mask) {
+      std::vector<unsigned char> m(mask, mask + N);
+      for (auto& v : m) { v = v ? 1 : 0; has_fixed = has_fixed || v; }
+      if (has_fixed) { pt_fixed_mask.upload(m, stream); sync(); }
+    }
+    push_ptrs();
+    return SBA_OK;
+  }
+  int set_robust_loss(int loss, double f_scale) override {
+    if (loss != SBA_LOSS_LINEAR && loss != SBA_LOSS_HUBER) { err = "unknown loss"; return SBA_ERR_INVALID; }
+    if (loss == SBA_LOSS_HUBER && !(f_scale > 0 && std::isfinite(f_scale))) { err = "f_scale must be positive"; return SBA_ERR_INVALID; }
+    loss_delta = loss == SBA_LOSS_HUBER ? f_scale : 0.0;
+    push_ptrs();
     return SBA_OK;
   }
 

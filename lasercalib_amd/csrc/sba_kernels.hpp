@@ -40,7 +40,10 @@ constexpr int NSCAL = 8;
 template <typename T> struct ParamSets {
   double* cams[2]; double* pts[2]; T* ptsT[2]; T* campre[2];
   int base;
+  float loss_delta;                 // > 0: Huber loss with this f_scale on every residual component (sba_set_robust_loss); 0: linear
+  const unsigned char* fixed;       // per point: 1 = held fixed (gauge anchor, sba_set_fixed_points); NULL: every point is free
 };
+template <typename T> __device__ inline bool pt_fixed(const ParamSets<T>& ps, size_t p) { return ps.fixed != nullptr && ps.fixed[p] != 0; }
 
 struct LMState {
   double lam, nu;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_residual(
     const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, int64_t M,
-    typename Vec2<T>::type* __restrict__ r_out, double* __restrict__ cost_part) {
+    typename Vec2<T>::type* __restrict__ r_out, double* __restrict__ cost_part, T loss_delta) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* s_cam = reinterpret_cast<T*>(smem);
   __shared__ double s_red[PM_BLOCK / 64];
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_residual(
     obs_project<T>(s_cam + c * CAMPRE, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2], u, v);
     const T r0 = ww * (u - m.x), r1 = ww * (v - m.y);
     if (r_out) { typename Vec2<T>::type rr; rr.x = r0; rr.y = r1; r_out[o] = rr; }
-    sq = (double)r0 * (double)r0 + (double)r1 * (double)r1;
+    sq = (loss_delta > (T)0) ? (double)robust_cost<T>(loss_delta, r0, r1) : (double)r0 * (double)r0 + (double)r1 * (double)r1;
   }
   const double s = block_sum(sq, s_red);
   if (threadIdx.x == 0) cost_part[blockIdx.x] = 0.5 * s;
@@ -288,7 +291,8 @@ __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points(
     T r[2], Jc[2][NCP], Jp[2][3];
     obs_resjac<T>(s_cam + c * CAMPRE, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2],
                   m.x, m.y, ww, r, Jc, Jp);
-    sq = (double)r[0] * r[0] + (double)r[1] * r[1];
+    if (ps.loss_delta > 0.f) sq = (double)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+    else sq = (double)r[0] * r[0] + (double)r[1] * r[1];
     double* d = s_red + threadIdx.x * 9;
     d[0] = (double)Jp[0][0] * Jp[0][0] + (double)Jp[1][0] * Jp[1][0];
     d[1] = (double)Jp[0][0] * Jp[0][1] + (double)Jp[1][0] * Jp[1][1];
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points(
       if (dsel >= 0) D2p[p * 3 + dsel] = fmax(D2p[p * 3 + dsel], s);
     } else {
       gp[p * 3 + (e - 6)] = s;
-      gmax = fmax(gmax, fabs(s));
+      if (!pt_fixed(ps, p)) gmax = fmax(gmax, fabs(s));      // a fixed point is not an unknown: its gradient does not count
     }
   }
   const double cs = block_sum(sq, s_scr);
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(256) void k_linearize_cams(
       const T ww = w_cm ? w_cm[o] : (T)1;
       T r[2], Jc[2][NCP], Jp[2][3];
       obs_resjac<T>(s_cam, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2], m.x, m.y, ww, r, Jc, Jp);
+      if (ps.loss_delta > 0.f) (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
 #pragma unroll
       for (int k = 0; k < NCP; ++k) { row0[k] = Jc[0][k]; row1[k] = Jc[1][k]; }
       row0[NCP] = r[0]; row1[NCP] = r[1];
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(1024) void k_reduce_cams(const double* __restrict__
 constexpr int PF = 12;
 template <typename T>
 __global__ void k_point_factor(const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
-                               const LMState* __restrict__ st, int N, T* __restrict__ pf) {
+                               const LMState* __restrict__ st, int N, T* __restrict__ pf, const unsigned char* __restrict__ fixed) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= N || st->status >= 0) return;
   const double lam = st->lam;
@@ -452,7 +457,8 @@ __global__ void k_point_factor(const double* __restrict__ V, const double* __res
   v6[4] = V[(size_t)p * 6 + 4];
   v6[5] = V[(size_t)p * 6 + 5] + lam * fmax_pos(D2p[(size_t)p * 3 + 2]);
   T* o = pf + (size_t)p * PF;
-  if (!chol3_inv<double>(v6, li)) {      // degenerate point: contributes nothing (its step is zeroed in back-substitution too)
+  // degenerate point, or a point held fixed: contributes nothing to the Schur complement, its step is zero in the back substitution
+  if ((fixed && fixed[p]) || !chol3_inv<double>(v6, li)) {
 #pragma unroll
     for (int k = 0; k < PF; ++k) o[k] = (T)0;
     return;
@@ -710,7 +716,7 @@ __device__ __forceinline__ void schur_emit_block(T* __restrict__ pan, int q, int
 template <typename T, bool DIAG>
 __device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict__ panelB, T* __restrict__ s_z,
                                            const T* __restrict__ s_cam, int camA0, int nA, int camB0, int nB, int dense,
-                                           int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f) {
+                                           int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f, T loss_delta = (T)0) {
   const bool inA = (c >= camA0 && c < camA0 + nA);
   const bool inB = !DIAG && (c >= camB0 && c < camB0 + nB);
   if (!inA && !inB) return;
@@ -720,6 +726,7 @@ __device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict
   if (f[9] != (T)0) {
     const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
     obs_resjac<T>(cp, X0, X1, X2, ux, uy, ww, r, Jc, Jp);
+    if (loss_delta > (T)0) (void)robust_apply<T>(loss_delta, r, Jc, Jp);
   }
   schur_emit_block<T>(pan, q, col0, dense, Jc, Jp, f);
   if (DIAG && f[9] != (T)0) { s_z[3 * q + 0] = f[6]; s_z[3 * q + 1] = f[7]; s_z[3 * q + 2] = f[8]; }   // same 3 values from every observation of the point
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
             if (rowi >= 3 * (p1 - p0)) buf[i] = (T)0;
           }
         auto emit = [&](int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f) {
-          schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, c, q, ux, uy, ww, X0, X1, X2, f);
+          schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, c, q, ux, uy, ww, X0, X1, X2, f, (T)ps.loss_delta);
         };
         if (piped) {
           // <= 16 points x 16 cameras = 256 observations = one per producer lane; operands of the NEXT chunk were
@@ -1024,7 +1031,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
 #pragma unroll
       for (int d = 0; d < 3; ++d) { Jp[0][d] = 0; Jp[1][d] = 0; }
       if (valid) obs_resjac<T>(s_cam + lc * CAMPRE, X0, X1, X2, m.x, m.y, ww, r, Jc, Jp);
-      l_sq += (double)r[0] * r[0] + (double)r[1] * r[1];
+      if (ps.loss_delta > 0.f) l_sq += (double)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+      else l_sq += (double)r[0] * r[0] + (double)r[1] * r[1];
       double v6[6], g3[3];
       v6[0] = row16_sum((double)(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]));
       v6[1] = row16_sum((double)(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]));
@@ -1035,12 +1043,13 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
       g3[0] = row16_sum((double)(Jp[0][0] * r[0] + Jp[1][0] * r[1]));
       g3[1] = row16_sum((double)(Jp[0][1] * r[0] + Jp[1][1] * r[1]));
       g3[2] = row16_sum((double)(Jp[0][2] * r[0] + Jp[1][2] * r[1]));
-      l_gmx = fmax(l_gmx, fmax(fabs(g3[0]), fmax(fabs(g3[1]), fabs(g3[2]))));
+      const bool fixedp = have_pt && pt_fixed(ps, (size_t)p);
+      if (!fixedp) l_gmx = fmax(l_gmx, fmax(fabs(g3[0]), fmax(fabs(g3[1]), fabs(g3[2]))));
       // point scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
       const double E0 = fmax(D0, v6[0]), E1 = fmax(D1, v6[3]), E2 = fmax(D2, v6[5]);
       double vd[6] = {v6[0] + lam * fmax_pos(E0), v6[1], v6[2], v6[3] + lam * fmax_pos(E1), v6[4], v6[5] + lam * fmax_pos(E2)};
       double li[6];
-      const bool okp = have_pt && chol3_inv<double>(vd, li);
+      const bool okp = have_pt && !fixedp && chol3_inv<double>(vd, li);
       T f[PF];
 #pragma unroll
       for (int k = 0; k < PF; ++k) f[k] = (T)0;
@@ -1066,7 +1075,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
     } else if (piped) {
       if (cur_valid)
         schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, cur_c, cur_p - p0, cur_uv.x, cur_uv.y, cur_w,
-                            cur_X[0], cur_X[1], cur_X[2], cur_f);
+                            cur_X[0], cur_X[1], cur_X[2], cur_f, (T)ps.loss_delta);
       cur_valid = n1_valid; cur_c = n1_c; cur_p = n1_p; cur_uv = n1_uv; cur_w = n1_w;
       load_point();
       load_idx(it + 2, n1_valid, n1_c, n1_p, n1_uv, n1_w);
@@ -1081,7 +1090,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
         for (int k = 0; k < PF; ++k) f[k] = pf[(size_t)pp * PF + k];
         const auto m = uv[o];
         schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, c, pp - p0, m.x, m.y, w ? w[o] : (T)1,
-                            ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f);
+                            ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f, (T)ps.loss_delta);
       }
     }
     const bool stamp = dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && it < 20 && threadIdx.x == 0;
@@ -1241,7 +1250,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
         // harmless depth: no branch, no zero-initialised outputs
         T r[2], Jc[2][NCP], Jp[2][3];
         obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
-        sq += r[0] * r[0] + r[1] * r[1];
+        sq += robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
         // per-point blocks: V (6) and g_p (3), summed over the 16 cameras of the DPP row
         T v6[6], g3[3];
         v6[0] = row16_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
@@ -1253,13 +1262,14 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
         g3[0] = row16_sum(Jp[0][0] * r[0] + Jp[1][0] * r[1]);
         g3[1] = row16_sum(Jp[0][1] * r[0] + Jp[1][1] * r[1]);
         g3[2] = row16_sum(Jp[0][2] * r[0] + Jp[1][2] * r[1]);
-        gmx = fmaxf(gmx, fmaxf(fabsf(g3[0]), fmaxf(fabsf(g3[1]), fabsf(g3[2]))));
+        const bool fixedp = have_pt && pt_fixed(ps, (size_t)p);
+        if (!fixedp) gmx = fmaxf(gmx, fmaxf(fabsf(g3[0]), fmaxf(fabsf(g3[1]), fabsf(g3[2]))));
         // point scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
         const double E0 = fmax(D0, (double)v6[0]), E1 = fmax(D1, (double)v6[3]), E2 = fmax(D2, (double)v6[5]);
         T f[PF];
         T li[6];
         T vd[6] = {v6[0] + lam * (T)fmax_pos(E0), v6[1], v6[2], v6[3] + lam * (T)fmax_pos(E1), v6[4], v6[5] + lam * (T)fmax_pos(E2)};
-        const bool okp = have_pt && chol3_inv_fast(vd, li);
+        const bool okp = have_pt && !fixedp && chol3_inv_fast(vd, li);
 #pragma unroll
         for (int k = 0; k < PF; ++k) f[k] = (T)0;
         if (okp) {
@@ -1504,7 +1514,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
         request(it + 1);
         T r[2], Jc[2][NCP], Jp[2][3];
         obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
-        sq += r[0] * r[0] + r[1] * r[1];
+        sq += robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
         T v6[6], g3[3];
         v6[0] = row16_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
         v6[1] = row16_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
@@ -1515,12 +1525,13 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
         g3[0] = row16_sum(Jp[0][0] * r[0] + Jp[1][0] * r[1]);
         g3[1] = row16_sum(Jp[0][1] * r[0] + Jp[1][1] * r[1]);
         g3[2] = row16_sum(Jp[0][2] * r[0] + Jp[1][2] * r[1]);
-        gmx = fmaxf(gmx, fmaxf(fabsf(g3[0]), fmaxf(fabsf(g3[1]), fabsf(g3[2]))));
+        const bool fixedp = have_pt && pt_fixed(ps, (size_t)p);
+        if (!fixedp) gmx = fmaxf(gmx, fmaxf(fabsf(g3[0]), fmaxf(fabsf(g3[1]), fabsf(g3[2]))));
         const double E0 = fmax(D0, (double)v6[0]), E1 = fmax(D1, (double)v6[3]), E2 = fmax(D2, (double)v6[5]);
         T f[PF];
         T li[6];
         T vd[6] = {v6[0] + lam * (T)fmax_pos(E0), v6[1], v6[2], v6[3] + lam * (T)fmax_pos(E1), v6[4], v6[5] + lam * (T)fmax_pos(E2)};
-        const bool okp = have_pt && chol3_inv_fast(vd, li);
+        const bool okp = have_pt && !fixedp && chol3_inv_fast(vd, li);
 #pragma unroll
         for (int k = 0; k < PF; ++k) f[k] = (T)0;
         if (okp) {

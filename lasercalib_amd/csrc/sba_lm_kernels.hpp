@@ -441,6 +441,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
       T r[2], Jc[2][NCP], Jp[2][3];
       obs_resjac<T>(s_cam + my_c * CAMPRE, ptsT[3 * (size_t)my_p], ptsT[3 * (size_t)my_p + 1],
                     ptsT[3 * (size_t)my_p + 2], my_uv.x, my_uv.y, my_w, r, Jc, Jp);
+      if (ps.loss_delta > 0.f) (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
       T s0 = 0, s1 = 0;
 #pragma unroll
       for (int e = 0; e < NCP; ++e) { s0 += Jc[0][e] * s_dc[my_c * NCP + e]; s1 += Jc[1][e] * s_dc[my_c * NCP + e]; }
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
     const double lam_ = lam;
     pred = 0.5 * (e0 * (lam_ * dd0 * e0 - g0) + e1 * (lam_ * dd1 * e1 - g1) + e2 * (lam_ * dd2 * e2 - g2));
     dx2 = e0 * e0 + e1 * e1 + e2 * e2;
-    x2 = X0 * X0 + X1 * X1 + X2 * X2;
+    x2 = pt_fixed(ps, p) ? 0.0 : X0 * X0 + X1 * X1 + X2 * X2;      // a fixed point is not part of x
   }
   __syncthreads();
   double sq = 0;
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
     T u, v;
     obs_project<T>(s_camn + my_c * CAMPRE, (T)s_xn[q * 3], (T)s_xn[q * 3 + 1], (T)s_xn[q * 3 + 2], u, v);
     const T r0 = my_w * (u - my_uv.x), r1 = my_w * (v - my_uv.y);
-    sq = (double)r0 * r0 + (double)r1 * r1;
+    sq = (ps.loss_delta > 0.f) ? (double)robust_cost<T>((T)ps.loss_delta, r0, r1) : (double)r0 * r0 + (double)r1 * r1;
   }
   const double c_new = block_sum(sq, s_scr);
   const double b_pred = block_sum(pred, s_scr);
@@ -575,6 +576,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
     if (free_cams && valid) {
       T r[2], Jc[2][NCP], Jp[2][3];
       obs_resjac<T>(cp, ptsT[pp * 3], ptsT[pp * 3 + 1], ptsT[pp * 3 + 2], m.x, m.y, ww, r, Jc, Jp);
+      if (ps.loss_delta > 0.f) (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
       T s0 = 0, s1 = 0;
 #pragma unroll
       for (int e = 0; e < NCP; ++e) { s0 += Jc[0][e] * dc[e]; s1 += Jc[1][e] * dc[e]; }
@@ -599,13 +601,13 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
       ptsT_new[pp * 3] = (T)n0; ptsT_new[pp * 3 + 1] = (T)n1; ptsT_new[pp * 3 + 2] = (T)n2;
       pred += 0.5 * (e0 * (lam * dd0 * e0 - g0) + e1 * (lam * dd1 * e1 - g1) + e2 * (lam * dd2 * e2 - g2));
       dx2 += e0 * e0 + e1 * e1 + e2 * e2;
-      x2 += X0 * X0 + X1 * X1 + X2 * X2;
+      if (!pt_fixed(ps, pp)) x2 += X0 * X0 + X1 * X1 + X2 * X2;      // a fixed point is not part of x
     }
     if (valid) {
       T u, v;
       obs_project<T>(cpn, (T)n0, (T)n1, (T)n2, u, v);
       const T r0 = ww * (u - m.x), r1 = ww * (v - m.y);
-      sq += (double)r0 * r0 + (double)r1 * r1;
+      sq += (ps.loss_delta > 0.f) ? (double)robust_cost<T>((T)ps.loss_delta, r0, r1) : (double)r0 * r0 + (double)r1 * r1;
     }
   }
   const double c_new = block_sum(sq, s_scr);

@@ -172,7 +172,7 @@ def run_lm(engine, comm, max_iter=0):
 class HipEngine:
     """libsba_hip.so phase calls on this rank's shard; exchange buffers are torch CUDA tensors."""
 
-    def __init__(self, cams, shard, dtype, device, opts_kwargs):
+    def __init__(self, cams, shard, dtype, device, opts_kwargs, before_begin=None):
         import torch
         from . import _native
         self.torch = torch
@@ -187,6 +187,8 @@ class HipEngine:
         self.sc = torch.empty(NSCALARS, dtype=torch.float64, device=dev)
         self.batch = 1 if opts_kwargs.get("profile") else 4
         self.begin_error = None
+        if before_begin is not None:
+            before_begin(self.prob)
         try:
             self.prob.lm_begin(self.opts)
         except ValueError as e:          # "Residuals are not finite in the initial point." on THIS shard
@@ -272,6 +274,8 @@ def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device,
         prob = _native.Problem(cams, shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], weights=shard["w"],
                                dtype=dtype, device=device)
         try:
+            fm = sba._fixed_mask(pts.shape[0])
+            sba._apply_extensions(prob, shard["pts"].shape[0], None if fm is None else fm[shard["p0"]:shard["p1"]])
             prob.comm_init(ids[0], comm.r, comm.n)
             bad = None
             try:
@@ -286,7 +290,8 @@ def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device,
         status, cost, opt, cost0 = rep.status, rep.cost, rep.optimality, rep.initial_cost     # whole-job figures already
         parts = comm.all_gather_var((shard["p0"], pts_loc, shard["obs_index"], fvec_loc))
     else:
-        eng = HipEngine(cams, shard, dtype, device, kw)
+        eng = HipEngine(cams, shard, dtype, device, kw, before_begin=lambda prob: sba._apply_extensions(
+            prob, shard["pts"].shape[0], None if sba._fixed_mask(pts.shape[0]) is None else sba._fixed_mask(pts.shape[0])[shard["p0"]:shard["p1"]]))
         try:
             # a non-finite initial cost on ANY rank must fail the solve on ALL ranks before the first collective of the loop
             raise_everywhere(comm, eng.begin_error)

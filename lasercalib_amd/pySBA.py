@@ -15,6 +15,11 @@ below then works on 13-parameter rows; with the reference's 11 columns nothing c
 Environment knobs (the script itself stays unchanged):
   LASERCALIB_SBA_DTYPE   f64 (default) | f32   arithmetic type of the per-observation math
   LASERCALIB_SBA_DEVICE  HIP device ordinal (default: LOCAL_RANK or 0)
+  LASERCALIB_SBA_USE_FIXED 1: honour ``points3Dfixed`` (a boolean mask over the 3-D points, or an array of point indices) as gauge
+                         anchors: those points keep their coordinates and drop out of the unknowns.  Default 0: stored and
+                         ignored, exactly like the reference (pySBA.py:28,55).
+  LASERCALIB_SBA_LOSS    linear (default, the reference's) | huber, with LASERCALIB_SBA_F_SCALE (default 1.0 px): scipy's
+                         ``least_squares(loss=, f_scale=)`` semantics for bundleAdjust / _nocam / _sharedcam.
   LASERCALIB_SBA_SHARD   1: with a torch.distributed process group up, bundleAdjust / _nocam / _sharedcam shard the points
                          over the ranks (every rank calls with the same full problem).  Default 0: never implicit.
                          The squared-error variants (bundle_adjustment_camonly, bundleAdjust_transform_points_3d) always
@@ -172,6 +177,32 @@ class PySBA:
             return None          # unit weights: the kernels skip the multiply and the 8 B/obs read
         return w.astype(np.float64)
 
+    def _fixed_mask(self, n_points):
+        """points3Dfixed -> boolean mask, only when LASERCALIB_SBA_USE_FIXED=1 (the reference never reads the attribute)."""
+        if os.environ.get("LASERCALIB_SBA_USE_FIXED", "0") in ("", "0") or self.points3Dfixed is None:
+            return None
+        f = np.asarray(self.points3Dfixed)
+        if f.dtype == bool:
+            if f.shape != (n_points,):
+                raise ValueError("a boolean points3Dfixed must have one entry per 3-D point")
+            return f
+        mask = np.zeros(n_points, dtype=bool)
+        mask[f.astype(np.int64).reshape(-1)] = True
+        return mask
+
+    @staticmethod
+    def _loss():
+        loss = os.environ.get("LASERCALIB_SBA_LOSS", "linear")
+        return (loss, float(os.environ.get("LASERCALIB_SBA_F_SCALE", "1.0"))) if loss != "linear" else None
+
+    def _apply_extensions(self, prob, n_points, mask=None):
+        mask = self._fixed_mask(n_points) if mask is None else mask
+        if mask is not None:
+            prob.set_fixed_points(mask)
+        loss = self._loss()
+        if loss is not None:
+            prob.set_robust_loss(*loss)
+
     def _solve(self, mode, ftol, verbose=2, xtol=1e-8, gtol=1e-8, max_nfev=None):
         cams = np.ascontiguousarray(self.cameraArray, dtype=np.float64)
         pts = np.ascontiguousarray(self.points3D, dtype=np.float64)
@@ -180,6 +211,7 @@ class PySBA:
             return dist.solve_sharded(self, mode, ftol, xtol, gtol, max_nfev, verbose, _env_dtype(), _env_device())
         with _native.Problem(cams, pts, self.points2D, self.cameraIndices, self.point2DIndices,
                              weights=self._weights_or_none(), dtype=_env_dtype(), device=_env_device()) as prob:
+            self._apply_extensions(prob, pts.shape[0])
             opts = prob.make_opts(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev or 0, mode=mode, verbose=verbose)
             cams_opt, pts_opt, rep, log = prob.solve_lm(opts)
             fvec, _ = prob.residual()

@@ -108,6 +108,44 @@ def bundle_adjust(cams, pts, uv, cam_ind, pt_ind, weights=None, ftol=1e-4, verbo
     return res, c_opt, p_opt
 
 
+def bundle_adjust_ext(cams, pts, uv, cam_ind, pt_ind, fixed_mask=None, loss="linear", f_scale=1.0, weights=None,
+                      ftol=1e-4, verbose=0, max_nfev=None, **lsq_kw):
+    """EXTENSION oracle -- not a restatement of reference behaviour: the reference stores ``points3Dfixed``
+    without using it (pySBA.py:28,55) and calls least_squares with the default linear loss (pySBA.py:141).  This is the same
+    least_squares call with (i) the fixed points removed from the parameter vector (their coordinates enter ``fun`` as
+    constants) and (ii) scipy's own ``loss=`` / ``f_scale=`` keywords.  With no fixed point and the linear loss it IS
+    ``bundle_adjust`` (pinned by f4_solves.npz).  Returns (res, cams_opt, pts_opt)."""
+    if weights is None:
+        weights = default_weights(pt_ind)
+    C, N = cams.shape[0], pts.shape[0]
+    free = np.ones(N, dtype=bool) if fixed_mask is None else ~np.asarray(fixed_mask, dtype=bool)
+    free_idx = np.nonzero(free)[0]
+    col_of_pt = np.full(N, -1, dtype=np.int64)
+    col_of_pt[free_idx] = np.arange(free_idx.size)
+    nc = C * N_CAM_PARAMS
+
+    def fun_ext(x):
+        full = pts.copy()
+        full[free_idx] = x[nc:].reshape((-1, 3))
+        return (weights * (project(full[pt_ind], x[:nc].reshape((C, N_CAM_PARAMS))[cam_ind]) - uv)).ravel()
+
+    A = lil_matrix((cam_ind.size * 2, nc + 3 * free_idx.size), dtype=int)
+    row = np.arange(cam_ind.size)
+    for s in range(N_CAM_PARAMS):
+        A[2 * row, cam_ind * N_CAM_PARAMS + s] = 1
+        A[2 * row + 1, cam_ind * N_CAM_PARAMS + s] = 1
+    sel = free[pt_ind]
+    for s in range(3):
+        A[2 * row[sel], nc + col_of_pt[pt_ind[sel]] * 3 + s] = 1
+        A[2 * row[sel] + 1, nc + col_of_pt[pt_ind[sel]] * 3 + s] = 1
+    x0 = np.hstack((cams.ravel(), pts[free_idx].ravel()))
+    res = least_squares(fun_ext, x0, jac_sparsity=A, verbose=verbose, x_scale="jac", ftol=ftol, method="trf", jac="3-point",
+                        max_nfev=max_nfev, loss=loss, f_scale=f_scale, **lsq_kw)
+    p_opt = pts.copy()
+    p_opt[free_idx] = res.x[nc:].reshape((-1, 3))
+    return res, res.x[:nc].reshape((C, N_CAM_PARAMS)), p_opt
+
+
 def sparsity_nocam(n_pts, pt_ind):
     """pySBA.py:216-226."""
     A = lil_matrix((pt_ind.size * 2, n_pts * 3), dtype=int)
