@@ -38,7 +38,7 @@ def _example_problem(seed=0, n_frames=(900, 700), noise_px=0.3):
     cams0[:, 3:6] += rng.normal(0, 3.0, (C, 3))
     cams0[:, 6] += rng.normal(0, 10.0, C)
     return dict(n_cams=n_cams, cams0=cams0, pts0=p3, uv=p2, ci=ci, pi=pi, cams_true=cams_true,
-                pts_true=np.vstack(truth_pts), noise=noise_px)
+                pts_true=np.vstack(truth_pts), noise=noise_px, sets=sets)
 
 
 def test_example_rig_flow_end_to_end(tmp_path):
