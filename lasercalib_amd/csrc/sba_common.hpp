@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,9 +33,41 @@ struct HipError { hipError_t e; const char* what; const char* file; int line; };
 
 // Device memory of one handle comes from a few large slabs (bump allocation, released together when the handle dies):
 // a handle owns ~40 buffers, and at ~80 us per hipMalloc / hipFree they used to cost more wall time than the solve.
+// Slabs released by a dying handle are parked in a small per-process pool instead of going back to the driver: a drop-in
+// call creates and destroys a handle around every solve (the instance must stay picklable), and at ~0.3 ms per hipFree /
+// hipMalloc of a large block the teardown used to cost more than the solve.  The pool keeps at most POOL_MAX_BYTES.
+struct SlabPool {
+  struct Slab { char* base; size_t size; int device; };
+  static constexpr size_t POOL_MAX_BYTES = (size_t)2 << 30;
+  std::mutex mu;
+  std::vector<Slab> free_slabs;
+  size_t bytes = 0;
+  static SlabPool& get() { static SlabPool* p = new SlabPool(); return *p; }     // never destroyed: no HIP calls at process exit
+  char* take(size_t min_size, int device, size_t* got) {
+    std::lock_guard<std::mutex> lk(mu);
+    int best = -1;
+    for (int i = 0; i < (int)free_slabs.size(); ++i)
+      if (free_slabs[i].device == device && free_slabs[i].size >= min_size && (best < 0 || free_slabs[i].size < free_slabs[best].size)) best = i;
+    if (best < 0) return nullptr;
+    Slab sl = free_slabs[best];
+    free_slabs.erase(free_slabs.begin() + best);
+    bytes -= sl.size;
+    *got = sl.size;
+    return sl.base;
+  }
+  bool give(char* base, size_t size, int device) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (bytes + size > POOL_MAX_BYTES) return false;
+    free_slabs.push_back({base, size, device});
+    bytes += size;
+    return true;
+  }
+};
+
 struct Arena {
   struct Slab { char* base; size_t size, used; };
   std::vector<Slab> slabs;
+  int device = 0;
   // slab sizes double from 8 MB to 64 MB: few hipMalloc calls (each large one costs milliseconds on this driver, whatever
   // its size) without grabbing much more than the handle needs
   size_t next_size = (size_t)8 << 20;
@@ -42,15 +75,52 @@ struct Arena {
     bytes = (bytes + 255) & ~(size_t)255;
     for (auto& sl : slabs)
       if (sl.size - sl.used >= bytes) { void* p = sl.base + sl.used; sl.used += bytes; return p; }
-    const size_t sz = std::max(bytes, next_size);
-    void* base = nullptr;
-    HIPCHK(hipMalloc(&base, sz));
+    const size_t want = std::max(bytes, next_size);
+    size_t sz = 0;
+    char* base = SlabPool::get().take(bytes, device, &sz);
+    if (base) {       // a recycled slab looks like a fresh allocation (tens of microseconds).  hipMemset on device memory may return
+      HIPCHK(hipMemsetAsync(base, 0, sz, nullptr));     // before it has run, and the engine's stream does not wait for the null
+      HIPCHK(hipStreamSynchronize(nullptr));            // stream: make sure the zeros are down before anything is uploaded
+    }
+    if (!base) {
+      sz = want;
+      void* b = nullptr;
+      HIPCHK(hipMalloc(&b, sz));
+      base = static_cast<char*>(b);
+    }
     next_size = std::min(next_size * 2, (size_t)64 << 20);
-    slabs.push_back({static_cast<char*>(base), sz, bytes});
+    slabs.push_back({base, sz, bytes});
     return base;
   }
-  ~Arena() { for (auto& sl : slabs) (void)hipFree(sl.base); }
+  ~Arena() { for (auto& sl : slabs) if (!SlabPool::get().give(sl.base, sl.size, device)) (void)hipFree(sl.base); }
 };
+// The per-handle stream, events and pinned state record are recycled the same way (creating and destroying them costs
+// about as much as a small solve).  Entries are only taken back after the stream has drained.
+struct HostRes {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2 + 12] = {};
+  void* pinned = nullptr;            // 1 KB of pinned host memory (LM state mirror)
+  int device = 0;
+};
+struct HostResPool {
+  std::mutex mu;
+  std::vector<HostRes> free_res;
+  static HostResPool& get() { static HostResPool* p = new HostResPool(); return *p; }
+  bool take(int device, HostRes* out) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < free_res.size(); ++i)
+      if (free_res[i].device == device) { *out = free_res[i]; free_res.erase(free_res.begin() + i); return true; }
+    return false;
+  }
+  void give(const HostRes& r) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_res.size() < 8) { free_res.push_back(r); return; }
+    for (auto e : r.ev) if (e) (void)hipEventDestroy(e);
+    if (r.stream) (void)hipStreamDestroy(r.stream);
+    if (r.pinned) (void)hipHostFree(r.pinned);
+  }
+};
+
 inline thread_local Arena* tl_arena = nullptr;      // set for the duration of a call on a handle (ArenaScope)
 struct ArenaScope {
   Arena* prev;

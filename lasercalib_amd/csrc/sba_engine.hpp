@@ -66,6 +66,9 @@ struct Engine : EngineBase {
   bool chol_debug = false;
   bool schur_debug = false;
   // multi-rank (one handle per GPU, points sharded, cameras replicated): RCCL communicator + exchange buffers
+  DevBuf<double> raw_uv, raw_w;         // the caller's raw arrays on the device (dense fast path of upload)
+  DevBuf<long long> raw_ci, raw_pi;
+  DevBuf<int> up_flag;
   DevBuf<unsigned char> pt_fixed_mask;   // sba_set_fixed_points: 1 = the point is a gauge anchor (never moves, not an unknown)
   bool has_fixed = false;
   double loss_delta = 0;                // sba_set_robust_loss: Huber f_scale, 0 = linear loss
@@ -100,27 +103,50 @@ struct Engine : EngineBase {
       }
   }
 
+  HostRes hres;
+  bool have_hres = false;
   ~Engine() override {
-    for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) if (pev[k][j]) (void)hipEventDestroy(pev[k][j]);
-    if (h_state) (void)hipHostFree(h_state);
-    if (h_comm) (void)hipHostFree(h_comm);
     if (comm) (void)Rccl::get().comm_destroy(comm);
-
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    if (h_comm) (void)hipHostFree(h_comm);
+    if (have_hres) {
+      if (stream) (void)hipStreamSynchronize(stream);     // nothing of this handle may still be in flight when its buffers are recycled
+      (void)hipStreamSynchronize(hres.stream);
+      HostResPool::get().give(hres);
+    }
   }
 
   void init(const sba_problem_desc& d) override {
     C = d.n_cams; N = d.n_points; M = d.n_obs; device = d.device; n = C * NCP;
+    arena.device = device;
     HIPCHK(hipSetDevice(device));
+    static_assert(sizeof(LMState) <= 1024 && KP_N * 2 + 2 <= (int)(sizeof(HostRes::ev) / sizeof(hipEvent_t)), "HostRes sizes");
+    if (!HostResPool::get().take(device, &hres)) {
+      hres.device = device;
+      HIPCHK(hipStreamCreateWithFlags(&hres.stream, hipStreamNonBlocking));
+      HIPCHK(hipHostMalloc(&hres.pinned, 1024, hipHostMallocDefault));
+      for (auto& e : hres.ev) HIPCHK(hipEventCreate(&e));
+    }
+    have_hres = true;
     if (d.use_stream) { stream = reinterpret_cast<hipStream_t>(d.stream); own_stream = false; }
-    else { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(LMState), hipHostMallocDefault));
-    HIPCHK(hipEventCreate(&ev0));
-    HIPCHK(hipEventCreate(&ev1));
-    for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) HIPCHK(hipEventCreate(&pev[k][j]));
+    else { stream = hres.stream; own_stream = true; }
+    h_state = static_cast<LMState*>(hres.pinned);
+    ev0 = hres.ev[0]; ev1 = hres.ev[1];
+    for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) pev[k][j] = hres.ev[2 + 2 * k + j];
     d_state.alloc(1);
+#if SBA_NCP == 11
+    // SBA_FUSED_MFMA=f32 keeps the f32-input MFMA kernel (A/B measurements, equivalence test); default: bf16 x 3 split
+    if (const char* e = getenv("SBA_FUSED_MFMA")) fused_bf3 = (std::string(e) != "f32");
+#endif
+    if (const char* e = getenv("SBA_CHOL")) chol_old = (std::string(e) == "old");
+    if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
+    if (const char* e = getenv("SBA_CHOL_BIG_MIN_N")) {      // diagnostic: route smaller systems through the big path too
+      char* end = nullptr;
+      const long v = strtol(e, &end, 10);
+      if (end != e && *end == 0 && v >= 0) chol_big_min_n = (int)std::min<long>(v, CS_MAX_NB * CB);
+    }
+    if (getenv("SBA_SCHUR_DEBUG")) { schur_debug = true; schur_dbg.alloc(64); schur_dbg.zero(stream); }
+    static bool attrs_set[16] = {};          // the function attributes are per process (and device), not per handle
+    if (device < 16 && attrs_set[device]) return;
     // kernels whose dynamic LDS can exceed the 64 KB default
     // only the Schur flavours this dtype launches are instantiated (f32: producer/consumer + fused; f64: symmetric + PARTIAL)
     auto big_lds = [&](const void* fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); };
@@ -136,23 +162,13 @@ struct Engine : EngineBase {
 #if SBA_NCP == 11
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
-      // SBA_FUSED_MFMA=f32 keeps the f32-input MFMA kernel (A/B measurements, equivalence test); default: bf16 x 3 split
-      if (const char* e = getenv("SBA_FUSED_MFMA")) fused_bf3 = (std::string(e) != "f32");
 #endif
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    if (const char* e = getenv("SBA_CHOL")) chol_old = (std::string(e) == "old");
-    if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
-    if (const char* e = getenv("SBA_CHOL_BIG_MIN_N")) {      // diagnostic: route smaller systems through the big path too
-      char* end = nullptr;
-      const long v = strtol(e, &end, 10);
-      if (end != e && *end == 0 && v >= 0) chol_big_min_n = (int)std::min<long>(v, CS_MAX_NB * CB);
-    }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
-    if (getenv("SBA_SCHUR_DEBUG")) { schur_debug = true; schur_dbg.alloc(64); schur_dbg.zero(stream); }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residual<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -160,6 +176,7 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_linearize<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_trial<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sq_trial<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    if (device < 16) attrs_set[device] = true;
   }
 
   void sync() { HIPCHK(hipStreamSynchronize(stream)); }
@@ -179,9 +196,47 @@ struct Engine : EngineBase {
     if (C <= 0 || N < 0 || M < 0) { err = "bad problem size"; return SBA_ERR_INVALID; }
     if (C > 128) { err = "more than 128 cameras is not supported yet"; return SBA_ERR_UNSUPPORTED; }
     if (M > (int64_t)0x7fffffff - 1024) { err = "too many observations for int32 device indices"; return SBA_ERR_UNSUPPORTED; }
+    has_w = (w_h != nullptr);
+    // Device-side layout: when the list can only be the canonical dense one -- M = N*C -- the caller's raw
+    // float64 / int64 arrays go to the GPU as they are and ONE kernel validates them (observation i must be point i / C, camera
+    // i % C: that single test implies in-range, point-major, camera-minor, no duplicates, every camera sees every point),
+    // narrows them to the device types and writes the point-major and the camera-major copies.  Anything else (sparse
+    // visibility, unsorted or duplicated observations) takes the host path below.
+    bool dev_dense = false;
+    std::vector<int32_t> ptstart;
+    bool sorted = true, cam_sorted = true;
+    std::vector<uint16_t> vmask;
+    bool nodup = (C <= GROUP_CAMS);
+    if (M > 0 && M == (int64_t)N * C && !getenv("SBA_HOST_LAYOUT")) {
+      raw_uv.alloc((size_t)M * 2); raw_ci.alloc(M); raw_pi.alloc(M);
+      if (has_w) raw_w.alloc(M);
+      uv_pm.alloc(M); ci_pm.alloc(M); pi_pm.alloc(M); uv_cm.alloc(M); pi_cm.alloc(M); pt_start.alloc((size_t)N + 1);
+      if (has_w) { w_pm.alloc(M); w_cm.alloc(M); }
+      if (up_flag.n == 0) up_flag.alloc(1);
+      up_flag.zero(stream);
+      HIPCHK(hipMemcpyAsync(raw_uv.p, uv_h, sizeof(double) * 2 * M, hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(raw_ci.p, ci_h, sizeof(int64_t) * M, hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(raw_pi.p, pi_h, sizeof(int64_t) * M, hipMemcpyHostToDevice, stream));
+      if (has_w) HIPCHK(hipMemcpyAsync(raw_w.p, w_h, sizeof(double) * M, hipMemcpyHostToDevice, stream));
+      up_lap("raw H2D");
+      hipLaunchKernelGGL(k_upload_dense<T>, dim3((unsigned)((std::max<int64_t>(M, N + 1) + 255) / 256)), dim3(256), 0, stream,
+                         reinterpret_cast<const double2*>(raw_uv.p), raw_ci.p, raw_pi.p, has_w ? raw_w.p : (const double*)nullptr, C, N, (long long)M,
+                         uv_pm.p, ci_pm.p, pi_pm.p, has_w ? w_pm.p : (T*)nullptr, uv_cm.p, pi_cm.p, has_w ? w_cm.p : (T*)nullptr,
+                         pt_start.p, up_flag.p);
+      int flag = 1;
+      HIPCHK(hipMemcpyAsync(&flag, up_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      sync();
+      up_lap("device validate + layout");
+      dev_dense = (flag == 0);
+    }
+    if (dev_dense) {
+      ptstart.resize((size_t)N + 1);
+      for (int p = 0; p <= N; ++p) ptstart[p] = p * C;
+      dense = true; identity_perm = true; perm.clear();
+      if (C > PM_BLOCK) { err = "a point has more than 256 observations"; return SBA_ERR_UNSUPPORTED; }
+    } else {
     // one pass: range check, point-major order, and camera order inside a point (strictly increasing cameras inside every
     // point = no duplicate (point, camera) pair and already canonical: what get_points3d.py:78-86 emits)
-    bool sorted = true, cam_sorted = true;
     {
       int64_t bad[4] = {-1, -1, -1, -1};
       bool uns[4] = {false, false, false, false}, cuns[4] = {false, false, false, false};
@@ -201,7 +256,7 @@ struct Engine : EngineBase {
       }
     }
     // point-major order (stable counting sort by point)
-    std::vector<int32_t> ptstart(N + 1, 0);
+    ptstart.assign((size_t)N + 1, 0);
     for (int64_t i = 0; i < M; ++i) ptstart[pi_h[i] + 1]++;
     int maxdeg = 0;
     for (int p = 0; p < N; ++p) { maxdeg = std::max(maxdeg, ptstart[p + 1]); ptstart[p + 1] += ptstart[p]; }
@@ -210,7 +265,7 @@ struct Engine : EngineBase {
     if (maxdeg > PM_BLOCK) { err = "a point has more than 256 observations"; return SBA_ERR_UNSUPPORTED; }
     perm.resize(M);
     identity_perm = sorted;
-    if (sorted) par_for(M, [&](int64_t lo, int64_t hi, int) { for (int64_t i = lo; i < hi; ++i) perm[i] = i; });
+    if (sorted) par_for(M, [&](int64_t lo, int64_t hi, int) { for (int64_t i = lo; i < hi; ++i) perm[i] = i; });   // (the canonical pass below may still reorder)
     else {
       std::vector<int32_t> fill(ptstart.begin(), ptstart.end() - 1);
       for (int64_t i = 0; i < M; ++i) perm[fill[pi_h[i]]++] = i;
@@ -218,8 +273,6 @@ struct Engine : EngineBase {
     // One camera group: put the observations of every point in camera order (what get_points3d.py:78-86 emits anyway) and
     // record which cameras see it.  Without duplicate (point, camera) pairs the lane = (point, camera) kernels apply:
     // dense = every camera sees every point (observation (p, c) at p*C + c), else through the visibility mask.
-    std::vector<uint16_t> vmask;
-    bool nodup = (C <= GROUP_CAMS);
     if (nodup && sorted && cam_sorted) {           // already canonical: only the visibility masks are needed
       vmask.assign(N, 0);
       for (int64_t i = 0; i < M; ++i) vmask[pi_h[i]] |= (uint16_t)(1u << ci_h[i]);
@@ -242,13 +295,13 @@ struct Engine : EngineBase {
       }
     }
     dense = dense && nodup;
-    masked_ok = nodup && !dense;
     up_lap("validate + sort + canonical");
-    has_w = (w_h != nullptr);
-    std::vector<T2> uvp(M);
-    std::vector<T> wp(has_w ? M : 0);
-    std::vector<int32_t> cip(M), pip(M);
-    par_for(M, [&](int64_t lo, int64_t hi, int) {
+    }   // host validation
+    masked_ok = nodup && !dense;
+    std::vector<T2> uvp(dev_dense ? 0 : M);
+    std::vector<T> wp(has_w && !dev_dense ? M : 0);
+    std::vector<int32_t> cip(dev_dense ? 0 : M), pip(dev_dense ? 0 : M);
+    if (!dev_dense) par_for(M, [&](int64_t lo, int64_t hi, int) {
       for (int64_t k = lo; k < hi; ++k) {
         const int64_t i = perm[k];
         uvp[k].x = (T)uv_h[2 * i]; uvp[k].y = (T)uv_h[2 * i + 1];
@@ -275,12 +328,15 @@ struct Engine : EngineBase {
     for (int b = 0; b < nblk; ++b) bdesc[b] = make_int4(blk[b], blk[b + 1], ptstart[blk[b]], ptstart[blk[b + 1]]);
     // camera-major order of the pm list (stable => points ascending inside a camera)
     std::vector<int32_t> camcount(C + 1, 0);
-    for (int64_t k = 0; k < M; ++k) camcount[cip[k] + 1]++;
-    for (int c = 0; c < C; ++c) camcount[c + 1] += camcount[c];
-    std::vector<T2> uvc(M);
-    std::vector<T> wc(has_w ? M : 0);
-    std::vector<int32_t> pic(M);
-    {
+    if (dev_dense) { for (int c = 0; c <= C; ++c) camcount[c] = c * N; }
+    else {
+      for (int64_t k = 0; k < M; ++k) camcount[cip[k] + 1]++;
+      for (int c = 0; c < C; ++c) camcount[c + 1] += camcount[c];
+    }
+    std::vector<T2> uvc(dev_dense ? 0 : M);
+    std::vector<T> wc(has_w && !dev_dense ? M : 0);
+    std::vector<int32_t> pic(dev_dense ? 0 : M);
+    if (!dev_dense) {
       std::vector<int32_t> fill(camcount.begin(), camcount.end() - 1);
       for (int64_t k = 0; k < M; ++k) {
         const int32_t d = fill[cip[k]]++;
@@ -316,10 +372,13 @@ struct Engine : EngineBase {
     }
 
     up_lap("blocks + camera-major copies");
-    uv_pm.upload(uvp, stream); ci_pm.upload(cip, stream); pi_pm.upload(pip, stream);
-    if (has_w) { w_pm.upload(wp, stream); w_cm.upload(wc, stream); }
-    pt_start.upload(ptstart, stream); blk_pt.upload(blk, stream); blk_desc.upload(bdesc, stream);
-    uv_cm.upload(uvc, stream); pi_cm.upload(pic, stream);
+    if (!dev_dense) {
+      uv_pm.upload(uvp, stream); ci_pm.upload(cip, stream); pi_pm.upload(pip, stream);
+      if (has_w) { w_pm.upload(wp, stream); w_cm.upload(wc, stream); }
+      pt_start.upload(ptstart, stream);
+      uv_cm.upload(uvc, stream); pi_cm.upload(pic, stream);
+    }
+    blk_pt.upload(blk, stream); blk_desc.upload(bdesc, stream);
     chunk_cam.upload(ch_cam, stream); chunk_begin.upload(ch_beg, stream); chunk_end.upload(ch_end, stream);
     cam_chunk_start.upload(cam_ch, stream);
     pair_ga.upload(pga, stream); pair_gb.upload(pgb, stream);
@@ -546,7 +605,9 @@ struct Engine : EngineBase {
     for (double v : part) c += v;
     if (cost_out) *cost_out = c;
     if (r_out)
-      for (int64_t k = 0; k < M; ++k) { const int64_t i = perm[k]; r_out[2 * i] = (double)r[k].x; r_out[2 * i + 1] = (double)r[k].y; }
+      par_for(M, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t k = lo; k < hi; ++k) { const int64_t i = identity_perm ? k : perm[k]; r_out[2 * i] = (double)r[k].x; r_out[2 * i + 1] = (double)r[k].y; }
+      });
     return SBA_OK;
   }
 
@@ -567,7 +628,7 @@ struct Engine : EngineBase {
     sync();
     HIPCHK(hipGetLastError());
     for (int64_t k = 0; k < M; ++k) {
-      const int64_t i = perm[k];
+      const int64_t i = identity_perm ? k : perm[k];
       if (r_out) { r_out[2 * i] = (double)r[k].x; r_out[2 * i + 1] = (double)r[k].y; }
       if (Jc_out) for (int e = 0; e < 2 * NCP; ++e) Jc_out[(size_t)i * 2 * NCP + e] = (double)jc[(size_t)k * 2 * NCP + e];
       if (Jp_out) for (int e = 0; e < 6; ++e) Jp_out[(size_t)i * 6 + e] = (double)jp[(size_t)k * 6 + e];

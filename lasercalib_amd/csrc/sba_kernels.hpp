@@ -181,6 +181,28 @@ __global__ void k_project_rows(const double* __restrict__ pts, const double* __r
   }
 }
 
+// ------------------------------------------------------------------ device-side layout of a dense observation list (sba_upload)
+// The caller's raw arrays (float64 pixels / weights, int64 indices; scripts/get_points3d.py:73-86 order) -> device layout.
+// Observation i must be (point i / C, camera i % C); any deviation raises the flag and the host path takes over.
+template <typename T>
+__global__ void k_upload_dense(const double2* __restrict__ uv, const long long* __restrict__ ci, const long long* __restrict__ pi,
+                               const double* __restrict__ w, int C, int N, long long M,
+                               typename Vec2<T>::type* __restrict__ uv_pm, int32_t* __restrict__ ci_pm, int32_t* __restrict__ pi_pm,
+                               T* __restrict__ w_pm, typename Vec2<T>::type* __restrict__ uv_cm, int32_t* __restrict__ pi_cm,
+                               T* __restrict__ w_cm, int32_t* __restrict__ pt_start, int* __restrict__ flag) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= N) pt_start[i] = (int32_t)(i * C);
+  if (i >= M) return;
+  const int p = (int)(i / C), c = (int)(i - (long long)p * C);
+  if (pi[i] != p || ci[i] != c) *flag = 1;
+  const double2 m = uv[i];
+  typename Vec2<T>::type v; v.x = (T)m.x; v.y = (T)m.y;
+  uv_pm[i] = v; ci_pm[i] = c; pi_pm[i] = p;
+  const size_t d = (size_t)c * N + p;                 // camera-major position: points ascending inside a camera
+  uv_cm[d] = v; pi_cm[d] = p;
+  if (w) { const T ww = (T)w[i]; w_pm[i] = ww; w_cm[d] = ww; }
+}
+
 // ------------------------------------------------------------------ K1: residual (+ cost partial)
 // One thread per observation in pm order; grid-strided is unnecessary: grid = ceil(M/256).
 // r_out (if non-null) is written in pm order as T2 -> fully coalesced.
