@@ -144,13 +144,34 @@ def main():
     x0 = np.hstack((rig["cams0"].ravel(), shard["pts"].ravel()))
     rehearsal = world > 1 and os.environ.get("SBA_BENCH_BACKEND", "nccl") != "nccl"     # gloo on one card: phase API + torch collectives
     phase_api = rehearsal or bool(os.environ.get("SBA_BENCH_PHASE_API"))
+    comm_note = None
     if world > 1 and not rehearsal:
-        ids = [_native.comm_unique_id() if rank == 0 else None]
+        # the library's own RCCL communicator; should binding or initialising it fail on ANY rank, every rank falls back to the
+        # phase-API loop with torch.distributed collectives (slower, but the run still measures the sharded solve) and says so
+        failed = 0
+        try:
+            ids = [_native.comm_unique_id() if rank == 0 else None]
+        except Exception as e:       # noqa: BLE001
+            ids, failed, comm_note = [None], 1, f"sba_comm_get_unique_id failed: {e}"
         dist.broadcast_object_list(ids, src=0)
-        prob.comm_init(ids[0], rank, world)
+        if ids[0] is None:
+            failed = 1
+        else:
+            try:
+                prob.comm_init(ids[0], rank, world)
+            except Exception as e:   # noqa: BLE001
+                failed, comm_note = 1, f"sba_comm_init failed: {e}"
+        flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            phase_api = True
+            comm_note = comm_note or "another rank could not initialise the library's RCCL communicator"
+            prob.close()             # a half-initialised communicator must not take part in the solve
+            prob = _native.Problem(rig["cams0"], shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], dtype=a.dtype,
+                                   device=local, stream=stream)
     elif os.environ.get("SBA_BENCH_RCCL_1"):          # one GPU through the same RCCL code path (a 1-rank communicator)
         prob.comm_init(_native.comm_unique_id(), 0, 1)
-    comm = sdist.TorchComm() if rehearsal else sdist.SoloComm()
+    comm = sdist.TorchComm() if (world > 1 and phase_api) else sdist.SoloComm()
     E = torch.empty(prob.exchange_size(), dtype=torch.float64, device="cuda")
     sc = torch.empty(sdist.NSCALARS, dtype=torch.float64, device="cuda")
 
@@ -244,9 +265,10 @@ def main():
             "config": {"workload": f"{C} cams x {Np} points per GPU, full visibility ({M_local} obs per GPU, {M_total} total), "
                                    "full on-device Schur-complement LM iteration", "cams": C, "points_per_gpu": Np,
                        "observations_total": int(M_total), "parallelism": f"points sharded x{world}, cameras replicated",
-                       "collectives": ("none" if world == 1 else "torch.distributed (rehearsal)" if phase_api else
+                       "collectives_fallback_reason": comm_note,
+                       "collectives": ("none" if world == 1 else "torch.distributed through the phase C ABI (rehearsal / fallback)" if phase_api else
                                        "RCCL inside libsba_hip.so: per step 1 all-reduce of n(n+1)/2+3n+1 doubles + 1 all-gather of 8 doubles per rank"),
-                       "exchange_doubles_per_step": (0 if world == 1 else n * (n + 1) // 2 + 3 * n + 1)},
+                       "exchange_doubles_per_step": (0 if world == 1 else n * n + 3 * n + 1 if phase_api else n * (n + 1) // 2 + 3 * n + 1)},
             "lm_iters_per_s": a.steps / dt,
             "resjac_mobs_per_s": M_local / kt["resjac"],
             "fused_linearize_mobs_per_s": M_local / (kt["schur"] if fused else (kt["linearize_points"] + kt["linearize_cams"])),
