@@ -352,10 +352,12 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   __syncthreads();
   CHOL_STAMP();
   double pred = 0, dx2 = 0, x2 = 0, gm = 0;
-  if (tid < ncam) {                                  // 11*C <= 176 < CHOLB_LDS_THREADS: one camera parameter per thread
+  __shared__ double s_cnew[CHOLB_MAX_NB * CB];       // the trial cameras once more in LDS: the CamPre rebuild below reads them
+  if (tid < ncam) {                                  // from there instead of waiting for its own global stores to come back
     const double d = fail ? 0.0 : s_y[tie ? tie[tid] : tid];
     delta_c[tid] = d;
     cams_new[tid] = my_cam + d;
+    s_cnew[tid] = my_cam + d;
   }
   if (tid < n) {                                     // scalars of the step live in the system's own unknowns
     const double d = fail ? 0.0 : s_y[tid];
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   }
   pred = wave_sum(pred); dx2 = wave_sum(dx2); x2 = wave_sum(x2); gm = wave_max(gm);
   if (lane == 0) { s_scr[0][wid] = pred; s_scr[1][wid] = dx2; s_scr[2][wid] = x2; s_scr[3][wid] = gm; }
-  __syncthreads();      // also orders the cams_new stores before the CamPre rebuild below
+  __syncthreads();      // s_cnew and the wave partials are in LDS
   if (tid == 0) {
     double p = 0, d2 = 0, xx = 0, g = 0;
     for (int w = 0; w < CHOLB_LDS_THREADS / 64; ++w) { p += s_scr[0][w]; d2 += s_scr[1][w]; xx += s_scr[2][w]; g = fmax(g, s_scr[3][w]); }
@@ -374,7 +376,8 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     st->chol_fail = fail ? 1 : 0;
     st->fresh = 0;
   }
-  if (tid < C) campre_build<T>(cams_new + (size_t)tid * NCP, campre_new + (size_t)tid * CAMPRE);
+  if (tid >= 64 && tid < 64 + C)          // one camera per lane of wave 1 (wave 0 is busy writing the state record)
+    campre_build<T>(s_cnew + (size_t)(tid - 64) * NCP, campre_new + (size_t)(tid - 64) * CAMPRE);
   CHOL_STAMP();
 #undef CHOL_STAMP
 }

@@ -634,7 +634,6 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* st,
                                                 const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
                                                 int nblk, int n_gmax /* entries of gmax_part (one per linearisation workgroup) */,
                                                 LMLogRow* __restrict__ log, int log_cap) {
-  __shared__ double scr[16];
   // The decision logic is a chain of dependent reads and writes of the state record; done against global memory every
   // link costs a memory round trip.  The record is staged in LDS by the whole block (its load overlaps the partial
   // sums), thread 0 works on that copy, writes it back with fire-and-forget stores and publishes `status` last.
@@ -658,8 +657,14 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* st,
   st = &s_st;
   double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
   if (scal_all == nullptr) {
-    cost_new = block_sum(a, scr); pred = block_sum(b, scr); dx2 = block_sum(c, scr); x2 = block_sum(d, scr);
-    gmax = block_max(g, scr);
+    // one LDS exchange for all five reductions (five block_sum calls were ten barriers)
+    __shared__ double s_red[5][16];
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d); g = wave_max(g);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) { s_red[0][wid] = a; s_red[1][wid] = b; s_red[2][wid] = c; s_red[3][wid] = d; s_red[4][wid] = g; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int i = 0; i < nw; ++i) { cost_new += s_red[0][i]; pred += s_red[1][i]; dx2 += s_red[2][i]; x2 += s_red[3][i]; gmax = fmax(gmax, s_red[4][i]); }
     failv = (double)st->chol_fail;
   }
   if (threadIdx.x != 0) return;
