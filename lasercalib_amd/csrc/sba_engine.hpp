@@ -868,7 +868,7 @@ struct Engine : EngineBase {
       const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 15) / 16 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, npairs, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? gdpart.p : (const double*)nullptr, Pk);
+                         fused() ? gdpart.p : (const double*)nullptr, Pk, (int)(fused() && fused_bf3));
     }
     prof_end(KP_REDUCE);
     return SBA_OK;

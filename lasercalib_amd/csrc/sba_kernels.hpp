@@ -1417,15 +1417,28 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
 // On gfx950 the f32-input MFMA runs on the SIMD's f32 FMA lanes (tools/micro/mix_waves.hip: a VALU-only wave beside a
 // saturating f32-MFMA wave makes no progress at all), so the 6.3k MFMA cycles of a 16-point chunk and the ~5k cycles of
 // producer arithmetic simply add up.  The bf16 MFMA is a separate pipe.  Each f32 panel value y is therefore split EXACTLY
-// into three bf16 pieces by truncation, y = h + m + l (8 + 8 + 8 mantissa bits; h = top half of y's bit pattern,
-// m = top half of (y - h), l = (y - h) - m), and a product of two panel values is accumulated in f32 as the six partial
+// into three bf16 pieces, y = h + m + l exactly (8 + 8 + 8 mantissa bits; h = bf16(y), m = bf16(y - h), l = (y - h) - m,
+// round to nearest), and a product of two panel values is accumulated in f32 as the six partial
 // products of combined order <= 2,
 //     y y' ~= h h' + h m' + m h' + h l' + l h' + m m'        (dropped: m l', l m', l l' <= 2^-24 |y y'|),
 // each of them exact in f32 (8 x 8 bits).  Error per product <= 3 * 2^-24 relative, the order of the f32 MFMA's own
 // rounding -- this is f32 arithmetic carried by six 16x16x32 bf16 MFMAs (16 cycles each, K = 32 = 8 points x (3 + 1 pad))
 // instead of eight 16x16x4 f32 MFMAs (32 cycles each): 2.7x fewer matrix cycles, and they overlap with the producers.
-//   LDS: three bf16 planes [176 rows][72] per buffer (k = 4 q + d inside a 16-point chunk, d = 3 is a zero pad; 72 = 64 + 8
-//   keeps the 16-byte fragment reads of 16 consecutive rows on distinct banks), double-buffered: 2 x 76,032 B.
+//   LDS: three bf16 planes per buffer, double-buffered: 2 x 67,584 B.  A plane is [11 tiles][2 halves][16 rows][8 slots] of
+//   8-byte point slots (3 values + a zero pad): point q of a 16-point chunk goes to half (q >> 2) & 1, slot
+//   sigma = (q & 3) | ((q >> 3) << 2), so that the two points a consumer lane needs for one k-step (q = 8 s + g and
+//   8 s + g + 4, g = lane >> 4; the k order inside a k-step is arbitrary as long as both operands agree) are the same slot
+//   of the two halves, 1024 bytes apart: one ds_read2st64_b64 returns the whole 16-byte MFMA operand (the halves of one tile
+//   are neighbours so that the compiler's load merging pairs them and not two tiles).  Rows are PARAMETER-major, row = 16 e + c
+//   (tile b of the MFMA = parameter b of all 16 cameras; 11 parameters = 11 tiles), and slot sigma of row (e, c) is stored
+//   at sigma ^ (c >> 1):
+//     * a producer ds_write_b64 is issued by 16 lanes with the same q and c = 0..15: rows are 64 bytes, so the row parity
+//       picks the bank half and the 8 cameras of one parity hit 8 different slots -> all 32 banks, no conflict (the
+//       camera-major [176][72] layout of the first version measured 44 % of its LDS cycles as bank conflicts,
+//       SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE);
+//     * one 32-lane pass of a consumer read covers rows i = 0..15 and g = 0, 1: i & 3 picks the 16-bank quarter and the 8
+//       lanes that share it read 8 different slots -> no conflict.
+//   k_build_exchange undoes the row order (flag emajor).
 //   The right-hand side b = panel^T z moves into the producers (11 more register accumulators per lane), so the
 //   consumers touch nothing but bf16 fragments.
 struct SchurBf3Cfg {
@@ -1435,14 +1448,15 @@ struct SchurBf3Cfg {
   static constexpr int NTILE = (GROUP_TILES * (GROUP_TILES + 1)) / 2;
   static constexpr int TPW = (NTILE + NV - 1) / NV;
   static constexpr int PTS = 16, KQ = 4, K = PTS * KQ;            // 64 panel columns per chunk = 2 MFMA k-steps of 32
-  static constexpr int KP = K + 8;                                 // row stride in bf16 elements (144 B)
-  static constexpr int PLANE = GROUP_ROWS * KP;                    // bf16 elements per plane
+  static constexpr int HALF_BYTES = 16 * 64;                       // one half of a tile: [16 rows][8 slots][4 bf16]
+  static constexpr int PLANE = GROUP_ROWS * K;                     // bf16 elements per plane (two half-planes)
   static constexpr int BUF_BYTES = 3 * PLANE * 2;                  // h, m, l
   static constexpr int UPKB = UPK + NCP;                           // per-lane accumulators handed over at the end: U (66) + g (11) + b (11)
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES + (size_t)GROUP_CAMS * CAMPRE * sizeof(float);
   static_assert(2 * (size_t)BUF_BYTES >= (size_t)(NPROD + GROUP_CAMS) * UPKB * sizeof(float), "the accumulator hand-over reuses the panel buffers");
 };
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
     const ParamSets<float> ps, const LMState* __restrict__ st, int C,
@@ -1453,7 +1467,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
   extern __shared__ __align__(16) unsigned char smem[];
   using T = float;
   using Cfg = SchurBf3Cfg;
-  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, KP = Cfg::KP, UPKB = Cfg::UPKB;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, UPKB = Cfg::UPKB;
   if (st->status >= 0) return;
   const bool stamp_wg = dbg && blockIdx.x == 0;
   if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();
@@ -1523,8 +1537,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
     request_index(0);
     request(0);
     if (stamp_wg && threadIdx.x == 0) dbg[49] = clock64();
-    // byte offset of this lane's 8-byte slot inside a plane row block: rows c*11 + e, columns 4q .. 4q+3
-    const int lane_slot = (c * NCP) * KP * 2 + q * 8;
+    // byte offset of this lane's 8-byte slot inside a plane: half (q >> 2) & 1, row 16 e + c, slot sigma(q) ^ (c >> 1)
+    const int lane_slot = ((q >> 2) & 1) * Cfg::HALF_BYTES + c * 64 + ((((q & 3) | ((q >> 3) << 2)) ^ (c >> 1)) << 3);
     for (int it = 0; it <= nchunk; ++it) {
       if (it < nchunk) {
         unsigned char* pbuf = smem + (it & 1) * Cfg::BUF_BYTES;
@@ -1588,20 +1602,30 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
 #pragma unroll
             for (int d = 0; d < 3; ++d) y[d] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
             Uacc[UPK + e] = __builtin_fmaf(y[2], f[8], __builtin_fmaf(y[1], f[7], __builtin_fmaf(y[0], f[6], Uacc[UPK + e])));
-            unsigned hb[3], mb[3], lb[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-              const unsigned yb = __builtin_bit_cast(unsigned, y[d]);
-              hb[d] = yb & 0xffff0000u;
-              const float r1 = y[d] - __builtin_bit_cast(float, hb[d]);          // exact: the low 16 mantissa bits
-              mb[d] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-              const float r2 = r1 - __builtin_bit_cast(float, mb[d]);            // exact: at most 8 significant bits left
-              lb[d] = __builtin_bit_cast(unsigned, r2);
-            }
-            unsigned char* dst = pbuf + lane_slot + e * (KP * 2);
-            *reinterpret_cast<uint2*>(dst) = make_uint2((hb[0] >> 16) | hb[1], hb[2] >> 16);
-            *reinterpret_cast<uint2*>(dst + Cfg::PLANE * 2) = make_uint2((mb[0] >> 16) | mb[1], mb[2] >> 16);
-            *reinterpret_cast<uint2*>(dst + 2 * Cfg::PLANE * 2) = make_uint2((lb[0] >> 16) | (lb[1] & 0xffff0000u), lb[2] >> 16);
+            // three-way split by round-to-nearest (v_cvt_pk_bf16_f32 converts and packs two values in one instruction): the
+            // remainders y - h and (y - h) - m are exact in f32 and the last one has at most 8 significant bits
+            // (inline asm: written as __bf16 conversions the compiler converts the low halves a second time and masks the pad)
+            auto pk = [](float lo, float hi) -> unsigned {
+              unsigned v;
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v) : "v"(lo), "v"(hi));
+              return v;
+            };
+            auto pk1 = [](float lo) -> unsigned {           // upper half = bf16(0) = the slot's zero pad
+              unsigned v;
+              asm("v_cvt_pk_bf16_f32 %0, %1, 0" : "=v"(v) : "v"(lo));
+              return v;
+            };
+            auto lo_f = [](unsigned pkd) -> float { return __builtin_bit_cast(float, pkd << 16); };
+            auto hi_f = [](unsigned pkd) -> float { return __builtin_bit_cast(float, pkd & 0xffff0000u); };
+            const unsigned h01 = pk(y[0], y[1]), h2 = pk1(y[2]);
+            const float r0 = y[0] - lo_f(h01), r1 = y[1] - hi_f(h01), r2 = y[2] - lo_f(h2);
+            const unsigned m01 = pk(r0, r1), m2 = pk1(r2);
+            const float s0 = r0 - lo_f(m01), s1 = r1 - hi_f(m01), s2 = r2 - lo_f(m2);
+            const unsigned l01 = pk(s0, s1), l2 = pk1(s2);
+            unsigned char* dst = pbuf + lane_slot + e * (2 * Cfg::HALF_BYTES);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h2);
+            *reinterpret_cast<uint2*>(dst + Cfg::PLANE * 2) = make_uint2(m01, m2);
+            *reinterpret_cast<uint2*>(dst + 2 * Cfg::PLANE * 2) = make_uint2(l01, l2);
           });
         }
         static_for<0, NCP>([&](auto ac) {
@@ -1631,11 +1655,15 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
 #pragma unroll
     for (int s = 0; s < TPW; ++s) acc[s] = typename Mfma<T>::acc_t{0, 0, 0, 0};
     const int ct = threadIdx.x - NPROD;
-    // fragment of row tile b, k-step s: 8 consecutive k of row 16 b + (lane & 15), starting at 32 s + 8 (lane >> 4)
-    const int frag_off = ((lane & 15) * KP + 8 * (lane >> 4)) * 2;
+    // fragment of row tile b, k-step s: slot (g | 4 s) ^ (i >> 1) of row 16 b + i in both half-planes (i = lane & 15, g = lane >> 4)
+    int frag_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) frag_off[s] = (lane & 15) * 64 + ((((lane >> 4) | (4 * s)) ^ ((lane & 15) >> 1)) << 3);
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     for (int it = 0; it <= nchunk; ++it) {
       if (it >= 1) {
-        const unsigned char* pbuf = smem + ((it - 1) & 1) * Cfg::BUF_BYTES + frag_off;
+        const unsigned char* pbuf = smem + ((it - 1) & 1) * Cfg::BUF_BYTES;
         static_for<0, Cfg::NV>([&](auto vc) {
           constexpr int V = decltype(vc)::value;
           if (cw == V) {
@@ -1643,14 +1671,22 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
             constexpr int RMIN = schur_tile_R(true, LO);
 #pragma unroll
             for (int s = 0; s < Cfg::K / 32; ++s) {
-              bf16x8_t fh[GROUP_TILES], fo[GROUP_TILES];
+              // all three planes of this k-step are requested before the first MFMA (the scheduling barrier keeps the
+              // compiler from sinking the reads next to their uses, which exposed one LDS round trip per few MFMAs)
+              bf16x8_t fh[GROUP_TILES], fm[GROUP_TILES], fl[GROUP_TILES];
               auto load = [&](bf16x8_t (&dst)[GROUP_TILES], int plane) {
 #pragma unroll
-                for (int b = RMIN; b < GROUP_TILES; ++b)
-                  dst[b] = *reinterpret_cast<const bf16x8_t*>(pbuf + plane * (Cfg::PLANE * 2) + (16 * b * KP + 32 * s) * 2);
+                for (int b = RMIN; b < GROUP_TILES; ++b) {
+                  const unsigned char* rowp = pbuf + plane * (Cfg::PLANE * 2) + b * (2 * Cfg::HALF_BYTES) + frag_off[s];
+                  const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(rowp);
+                  const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(rowp + Cfg::HALF_BYTES);
+                  dst[b] = __builtin_bit_cast(bf16x8_t, u32x4_t{lo[0], lo[1], hi[0], hi[1]});
+                }
               };
               load(fh, 0);
-              load(fo, 1);
+              load(fm, 1);
+              load(fl, 2);
+              __builtin_amdgcn_sched_barrier(0);
               // h h'
               static_for<LO, HI>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
@@ -1661,18 +1697,18 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
               static_for<LO, HI>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fo[Tc], acc[t - LO], 0, 0, 0);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo[R], fh[Tc], acc[t - LO], 0, 0, 0);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo[R], fo[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fm[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[R], fh[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[R], fm[Tc], acc[t - LO], 0, 0, 0);
               });
-              load(fo, 2);
               // h l' + l h'
               static_for<LO, HI>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fo[Tc], acc[t - LO], 0, 0, 0);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo[R], fh[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fl[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[R], fh[Tc], acc[t - LO], 0, 0, 0);
               });
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
         });
@@ -1691,17 +1727,12 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
         static_for<T0, T1>([&](auto tc) {
           constexpr int t = decltype(tc)::value;
           constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
-          if constexpr (Tc - R <= 1) {
+          // parameter-major rows: tile (R, Tc) holds parameters (R, Tc) of every camera pair, the camera's own block U sits
+          // on the tile's diagonal (row camera == column camera): at most one of a lane's four registers
+          const int cj_ = lane & 15, rgm = cj_ - 4 * (lane >> 4);
+          const T u = (rgm >= 0 && rgm < 4 && cj_ < C) ? s_Ured[cj_ * UPKB + (R * NCP - (R * (R - 1)) / 2 + (Tc - R))] : (T)0;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              const int i = 16 * R + Mfma<T>::row_of(lane, rg), j = 16 * Tc + (lane & 15);
-              const int ci_ = i / NCP, cj_ = j / NCP;
-              if (ci_ == cj_ && ci_ < C) {
-                const int a = min(i - ci_ * NCP, j - cj_ * NCP), b = max(i - ci_ * NCP, j - cj_ * NCP);
-                acc[t - T0][rg] -= s_Ured[ci_ * UPKB + (a * NCP - (a * (a - 1)) / 2 + (b - a))];
-              }
-            }
-          }
+          for (int rg = 0; rg < 4; ++rg) acc[t - T0][rg] -= (rg == rgm) ? u : (T)0;
         });
       }
     });
