@@ -47,6 +47,7 @@ __device__ inline double rsqrt_nr(double x) {
 // of the identity; both kinds go through the same right-looking column steps (x_k = a_k / L_kk ; a_c -= x_k L[c][k]),
 // whose broadcasts of column k go through v_readlane (SGPRs) instead of LDS round trips.  The identity rows end up as
 // the rows of Linv^T, which replace the tile.  Returns false (wave-uniform) when the block is not positive definite.
+template <bool NEWTON = true>
 __device__ __forceinline__ bool chol16_wave(double* __restrict__ blk) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15;
@@ -54,26 +55,30 @@ __device__ __forceinline__ bool chol16_wave(double* __restrict__ blk) {
   double a[CB];
 #pragma unroll
   for (int j = 0; j < CB; ++j) { const double v = blk[i * CLD + j]; a[j] = ident ? ((j == i) ? 1.0 : 0.0) : v; }
+  double dg = blk[i * CLD + i];            // the row's own diagonal entry (lanes 0..15), downdated with the row's own l_ik
   __builtin_amdgcn_wave_barrier();
-  bool ok = true;
-  // The serial chain of the whole factorisation runs through here: pivot k+1 needs a[k+1] after column step k.  The source
-  // order puts that one critical update first and starts the next pivot's reciprocal square root right behind it, so that its
-  // latency (v_rsq_f64 + one Newton step) is covered by the 14 - k updates of the other columns, which nobody waits for.
-  double akk = readlane_f64(a[0], 0);
-  if (!(akk > 0.0) || !isfinite(akk)) ok = false;
-  double piv = rsqrt_nr(ok ? akk : 1.0);
+  // The serial chain of the whole factorisation runs through here.  Pivot k+1 is row k+1's diagonal entry after column step
+  // k, and that downdate needs nothing from another lane (d -= l_ik^2 with the lane's own l_ik), so one link of the chain
+  //     l_ik = a_ik * piv_k  ->  d -= l_ik^2  ->  v_readlane x2 (lane k+1)  ->  v_rsq_f64 (+ Newton)  -> piv_k+1
+  // has a single cross-lane broadcast in it; the positivity test accumulates beside the chain (a non-positive pivot turns
+  // the tile into NaNs, which the failure flag discards), and the broadcasts that update the other columns are nobody's
+  // critical path.
+  auto pivot = [](double x) { return NEWTON ? rsqrt_nr(x) : __builtin_amdgcn_rsq(x); };
+  double akk = readlane_f64(dg, 0);
+  bool ok = (akk > 0.0) && isfinite(akk);
+  double piv = pivot(akk);
 #pragma unroll
   for (int k = 0; k < CB; ++k) {
     const double lik = a[k] * piv;
     a[k] = lik;
     if (k + 1 < CB) {
-      a[k + 1] -= lik * readlane_f64(lik, k + 1);
-      akk = readlane_f64(a[k + 1], k + 1);
-      if (!(akk > 0.0) || !isfinite(akk)) ok = false;
-      piv = rsqrt_nr(ok ? akk : 1.0);
+      dg = __builtin_fma(-lik, lik, dg);
+      akk = readlane_f64(dg, k + 1);
+      ok = ok && (akk > 0.0) && isfinite(akk);
+      piv = pivot(akk);
     }
 #pragma unroll
-    for (int j = k + 2; j < CB; ++j) a[j] -= lik * readlane_f64(lik, j);
+    for (int j = k + 1; j < CB; ++j) a[j] -= lik * readlane_f64(lik, j);
   }
   if (lane >= 16 && lane < 32) {
 #pragma unroll
@@ -120,6 +125,11 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     const int32_t* __restrict__ first /* [n_sys] system row -> one camera parameter mapped to it, or NULL */,
     long long* __restrict__ dbg /* optional cycle stamps (diagnostic runs only) */) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // fp32 engine: the pivot 1/sqrt(a_kk) is the hardware estimate (5e-8 relative) without the Newton step.  L_kk = a_kk piv
+  // and the column scaled by the same piv factor a matrix whose row/column k differ from A's by 1e-7 relative -- the size
+  // of the rounding error every entry of S already carries there -- and four dependent f64 operations leave each of the
+  // 176 links of the pivot chain.
+  constexpr bool PIV_NEWTON = !std::is_same<T, float>::value;
   if (st->status >= 0) return;
   const int cur_ = ps_cur(ps, st);
   const double* __restrict__ cams = ps.cams[cur_];
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     }
   }
   if (wid == 0) {
-    if (!chol16_wave(Lb + cb_off(0, 0))) { if (lane == 0) s_fail = 1; }
+    if (!chol16_wave<PIV_NEWTON>(Lb + cb_off(0, 0))) { if (lane == 0) s_fail = 1; }
   }
   __syncthreads();
   CHOL_STAMP();
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     // ---- C: look-ahead factorisation of the next diagonal tile (wave 0) | rhs tail + trailing update (waves 1..7)
     if (wid == 0) {
       if (jb + 1 < nb) {
-        if (!chol16_wave(Lb + cb_off(jb + 1, jb + 1))) { if (lane == 0) s_fail = 1; }
+        if (!chol16_wave<PIV_NEWTON>(Lb + cb_off(jb + 1, jb + 1))) { if (lane == 0) s_fail = 1; }
       }
     } else {
       if (wid == 1) {
