@@ -99,7 +99,8 @@ struct Arena {
 struct HostRes {
   hipStream_t stream = nullptr;
   hipEvent_t ev[2 + 12] = {};
-  void* pinned = nullptr;            // 1 KB of pinned host memory (LM state mirror)
+  void* pinned = nullptr;            // PINNED_BYTES of pinned host memory: 1 KB LM state mirror + a landing area for small device-to-host copies
+  static constexpr size_t PINNED_BYTES = 64 * 1024, PINNED_STATE_BYTES = 1024;
   int device = 0;
 };
 struct HostResPool {

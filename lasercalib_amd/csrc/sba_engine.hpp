@@ -105,6 +105,11 @@ struct Engine : EngineBase {
 
   HostRes hres;
   bool have_hres = false;
+  // small device-to-host results land in pinned memory (a copy into pageable memory is staged and blocks the caller per copy)
+  double* h_land = nullptr;
+  static constexpr size_t LAND_DOUBLES = (HostRes::PINNED_BYTES - HostRes::PINNED_STATE_BYTES) / sizeof(double);
+  bool poll_clean = false;            // nothing has been enqueued since the last lm_poll: its state and log are current
+  int n_decides = 0;                  // accept/reject kernels enqueued since lm_begin (upper bound of the log rows on the device)
   ~Engine() override {
     if (comm) (void)Rccl::get().comm_destroy(comm);
     if (h_comm) (void)hipHostFree(h_comm);
@@ -123,13 +128,14 @@ struct Engine : EngineBase {
     if (!HostResPool::get().take(device, &hres)) {
       hres.device = device;
       HIPCHK(hipStreamCreateWithFlags(&hres.stream, hipStreamNonBlocking));
-      HIPCHK(hipHostMalloc(&hres.pinned, 1024, hipHostMallocDefault));
+      HIPCHK(hipHostMalloc(&hres.pinned, HostRes::PINNED_BYTES, hipHostMallocDefault));
       for (auto& e : hres.ev) HIPCHK(hipEventCreate(&e));
     }
     have_hres = true;
     if (d.use_stream) { stream = reinterpret_cast<hipStream_t>(d.stream); own_stream = false; }
     else { stream = hres.stream; own_stream = true; }
     h_state = static_cast<LMState*>(hres.pinned);
+    h_land = reinterpret_cast<double*>(static_cast<char*>(hres.pinned) + HostRes::PINNED_STATE_BYTES);
     ev0 = hres.ev[0]; ev1 = hres.ev[1];
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) pev[k][j] = hres.ev[2 + 2 * k + j];
     d_state.alloc(1);
@@ -595,14 +601,15 @@ struct Engine : EngineBase {
     if (r_out && r_pm.n != (size_t)M) r_pm.alloc(M);
     launch_residual(r_out ? r_pm.p : nullptr);
     const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
-    std::vector<double> part(g);
-    if (g) HIPCHK(hipMemcpyAsync(part.data(), cost_part.p, sizeof(double) * g, hipMemcpyDeviceToHost, stream));
+    std::vector<double> part_v((size_t)g > LAND_DOUBLES ? g : 0);
+    double* part = part_v.empty() ? h_land : part_v.data();
+    if (g) HIPCHK(hipMemcpyAsync(part, cost_part.p, sizeof(double) * g, hipMemcpyDeviceToHost, stream));
     std::vector<T2> r(r_out ? M : 0);
     if (r_out && M) HIPCHK(hipMemcpyAsync(r.data(), r_pm.p, sizeof(T2) * M, hipMemcpyDeviceToHost, stream));
     sync();
     HIPCHK(hipGetLastError());
     double c = 0;
-    for (double v : part) c += v;
+    for (int i = 0; i < g; ++i) c += part[i];
     if (cost_out) *cost_out = c;
     if (r_out)
       par_for(M, [&](int64_t lo, int64_t hi, int) {
@@ -827,10 +834,14 @@ struct Engine : EngineBase {
       initial_cost = c0;
       h_state->cost = c0;
       HIPCHK(hipMemcpyAsync(d_state.p, h_state, sizeof(LMState), hipMemcpyHostToDevice, stream));
+      sync();                      // `ident` above is a stack array
     }
-    sync();
+    // no host synchronisation here: everything above is ordered on the stream in front of the first iteration, and the pinned
+    // state mirror it was copied from is next written by lm_poll's device-to-host copy on the same stream
     log.clear();
     log_read = 0;
+    n_decides = 0;
+    poll_clean = false;
     lm_active = true;
     if (!std::isfinite(c0)) { err = "Residuals are not finite in the initial point."; return SBA_ERR_NONFINITE; }
     return SBA_OK;
@@ -838,6 +849,7 @@ struct Engine : EngineBase {
 
   int lm_linearize() override {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    poll_clean = false;
     if (sq_mode()) { launch_sq_linearize(d_state.p); return SBA_OK; }
     if (fused()) return SBA_OK;          // k_schur_fused linearises
     if (!lin_pts()) {                    // (f64 one-group rigs: k_schur_sym<LIN> linearises the points)
@@ -852,6 +864,7 @@ struct Engine : EngineBase {
   int lm_form_reduced(double* E) override { return form_reduced(E, nullptr); }
   int form_reduced(double* E, double* Pk) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    poll_clean = false;
     if (sq_mode()) {
       if (opts.mode == SBA_MODE_CAMS_ONLY_SQ)
         hipLaunchKernelGGL(k_sq_pack_cams, dim3(64), dim3(256), 0, stream, sq_16.p, C, d_state.p, E);
@@ -900,6 +913,7 @@ struct Engine : EngineBase {
   // scal == nullptr: single rank, the partials are folded inside k_decide and no scalar exchange is needed
   int lm_solve_trial(double* E, double* scal) override {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    poll_clean = false;
     if (opts.mode == SBA_MODE_TRANSFORM_SQ) {
       hipLaunchKernelGGL(k_sq_solve12, dim3(1), dim3(64), 0, stream, sq_16.p, d_state.p, tsets());
       launch_sq_trial();
@@ -984,6 +998,8 @@ struct Engine : EngineBase {
   // enqueue the accept / reject / terminate kernel; nothing is read back
   int lm_decide_async(const double* scal_all, int n_ranks) override {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    poll_clean = false;
+    ++n_decides;
     hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(1024), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
                        gmax_part.p, sq_mode() ? nblk_sq : n_trial_parts(), sq_mode() ? nblk_sq : n_lin_parts(), reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
     pslot_advance();
@@ -994,6 +1010,13 @@ struct Engine : EngineBase {
   int lm_poll(int32_t* status_out, int32_t* iterations_out) override {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     HIPCHK(hipMemcpyAsync(h_state, d_state.p, sizeof(LMState), hipMemcpyDeviceToHost, stream));
+    // the log rows written since the last poll travel with the state: at most one row per accept/reject kernel enqueued so far,
+    // into the pinned landing area when they fit (the usual case: a batch of iterations), otherwise by a second copy below
+    constexpr size_t ROW_DOUBLES = (sizeof(sba_lm_iter_log) + 7) / 8;
+    const int maybe = std::min(n_decides, (int)LOG_CAP) - log_read;
+    const bool rows_landed = maybe > 0 && (size_t)maybe * ROW_DOUBLES <= LAND_DOUBLES;
+    if (rows_landed)
+      HIPCHK(hipMemcpyAsync(h_land, d_log.p + log_read, sizeof(sba_lm_iter_log) * maybe, hipMemcpyDeviceToHost, stream));
     sync();
     HIPCHK(hipGetLastError());
     prof_collect();
@@ -1002,9 +1025,13 @@ struct Engine : EngineBase {
     const int have = std::min(s.iter, LOG_CAP);
     if (have > log_read) {
       log.resize(have);
-      HIPCHK(hipMemcpy(log.data() + log_read, d_log.p + log_read, sizeof(sba_lm_iter_log) * (have - log_read), hipMemcpyDeviceToHost));
+      if (rows_landed && have - log_read <= maybe)
+        std::memcpy(log.data() + log_read, h_land, sizeof(sba_lm_iter_log) * (have - log_read));
+      else
+        HIPCHK(hipMemcpy(log.data() + log_read, d_log.p + log_read, sizeof(sba_lm_iter_log) * (have - log_read), hipMemcpyDeviceToHost));
       log_read = have;
     }
+    poll_clean = true;
     if (status_out) *status_out = s.status;
     if (iterations_out) *iterations_out = s.iter;
     return SBA_OK;
@@ -1025,7 +1052,7 @@ struct Engine : EngineBase {
   int lm_finish(double* cams_out, double* pts_out, sba_lm_report* rep) override {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     int32_t st = -1, it = 0;
-    int rc = lm_poll(&st, &it);          // refreshes `cur` and the log
+    int rc = poll_clean ? SBA_OK : lm_poll(&st, &it);          // refreshes `cur` and the log (unless the caller just polled)
     if (rc) return rc;
     push_ptrs();                         // table consistent with `cur` for the unconditional launches below
     if (sq_mode()) {
@@ -1059,22 +1086,27 @@ struct Engine : EngineBase {
     // gradient norm at the returned point (scipy reports optimality there, trf.py:546-551)
     launch_linearize_points(nullptr);
     double gmax = 0;
-    std::vector<double> gm(nblk), cp(nblk);
+    // the small results land in pinned memory: [gmax partials | cost partials | camera gradient | cameras]
+    const size_t need = 2 * (size_t)nblk + 2 * (size_t)n;
+    std::vector<double> land_v(need > LAND_DOUBLES ? need : 0);
+    double* land = land_v.empty() ? h_land : land_v.data();
+    double *gm = land, *cp = land + nblk, *gch = land + 2 * (size_t)nblk, *cams_l = gch + n;
     if (nblk) {
-      HIPCHK(hipMemcpyAsync(gm.data(), gmax_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipMemcpyAsync(cp.data(), cost_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(gm, gmax_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(cp, cost_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
     }
-    std::vector<double> gch(n, 0.0);
     if (h_state->free_cams) {
       launch_linearize_cams(nullptr);
-      HIPCHK(hipMemcpyAsync(gch.data(), gc.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(gch, gc.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
     } else {
       gc.zero(stream);
+      for (int i = 0; i < n; ++i) gch[i] = 0.0;
     }
-    if (cams_out) HIPCHK(hipMemcpyAsync(cams_out, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    if (cams_out) HIPCHK(hipMemcpyAsync(cams_l, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
     if (pts_out) HIPCHK(hipMemcpyAsync(pts_out, pts[cur].p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost, stream));
     sync();
     HIPCHK(hipGetLastError());
+    if (cams_out) std::memcpy(cams_out, cams_l, sizeof(double) * n);
     double cost = 0;
     for (int i = 0; i < nblk; ++i) { gmax = std::max(gmax, gm[i]); cost += cp[i]; }
     if (comm) {       // whole-job figures: cost and camera gradient are sums over the ranks, the point-gradient maximum a max
@@ -1091,7 +1123,7 @@ struct Engine : EngineBase {
       for (int i = 0; i < n; ++i) gs[h_tie[i]] += gch[i];
       for (double v : gs) gmax = std::max(gmax, std::fabs(v));
     } else {
-      for (double v : gch) gmax = std::max(gmax, std::fabs(v));
+      for (int i = 0; i < n; ++i) gmax = std::max(gmax, std::fabs(gch[i]));
     }
     if (rep) {
       const LMState& s = *h_state;
@@ -1106,8 +1138,11 @@ struct Engine : EngineBase {
   int solve(const sba_lm_opts* o, double* cams_out, double* pts_out, sba_lm_report* rep, sba_lm_iter_log* lg, int cap,
             int32_t* rows) override {
     const auto t0 = std::chrono::steady_clock::now();
+    static const bool solve_debug = getenv("SBA_SOLVE_DEBUG") != nullptr;      // host-side phase times of one solve on stderr
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6; };
     int rc = lm_begin(o);
     if (rc) return rc;
+    const double t_begin = since();
     HIPCHK(hipEventRecord(ev0, stream));
     int32_t status = -1, iters = 0;
     while (status < 0) {
@@ -1140,12 +1175,16 @@ struct Engine : EngineBase {
       rc = lm_poll(&status, &iters);
       if (rc) return rc;
     }
+    const double t_loop = since();
     HIPCHK(hipEventRecord(ev1, stream));
     HIPCHK(hipEventSynchronize(ev1));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
     rc = lm_finish(cams_out, pts_out, rep);
     if (rc) return rc;
+    if (solve_debug)
+      fprintf(stderr, "[solve] lm_begin %.0f us | loop (enqueue + polls) %.0f us (device %.0f us) | lm_finish %.0f us | %d iterations\n",
+              t_begin, t_loop - t_begin, ms * 1e3, since() - t_loop, (int)iters);
     if (rep) {
       rep->status = status;
       rep->seconds_device = ms * 1e-3;
