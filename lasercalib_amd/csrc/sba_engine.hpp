@@ -52,7 +52,18 @@ struct Engine : EngineBase {
   DevBuf<T> slabs, pfac;
   DevBuf<T2> r_pm;
   DevBuf<T> Jc_pm, Jp_pm;
-  DevBuf<LMState> d_state;
+  // The state record lives in a two-entry buffer: k_schur_fused_bf3 can carry the accept/reject decision of the previous trial
+  // step in its prologue, reading one entry and publishing the updated record to the other (see FusedDecide).  d_state.p is the
+  // entry every launch enqueued NOW has to use.
+  DevBuf<LMState> d_state_buf;
+  struct { LMState* p = nullptr; } d_state;
+  int st_slot = 0;
+  bool pending_decide = false;        // lm_decide_async was called and its decision has not been enqueued yet
+  const double* pend_scal = nullptr;
+  int pend_ranks = 1;
+  bool defer_decide = true;           // SBA_DECIDE_KERNEL=1 keeps the separate k_decide launch (A/B measurements)
+  DevBuf<double> gmax_alt;            // second array of gradient maxima (the fused kernel reads one and writes the other)
+  double* gmax_cur = nullptr;         // the array the last linearisation wrote
   DevBuf<sba_lm_iter_log> d_log;
   int log_read = 0;
   int cur_at_begin = 0;
@@ -138,7 +149,9 @@ struct Engine : EngineBase {
     h_land = reinterpret_cast<double*>(static_cast<char*>(hres.pinned) + HostRes::PINNED_STATE_BYTES);
     ev0 = hres.ev[0]; ev1 = hres.ev[1];
     for (int k = 0; k < KP_N; ++k) for (int j = 0; j < 2; ++j) pev[k][j] = hres.ev[2 + 2 * k + j];
-    d_state.alloc(1);
+    d_state_buf.alloc(2);
+    d_state.p = d_state_buf.p;
+    if (getenv("SBA_DECIDE_KERNEL")) defer_decide = false;
 #if SBA_NCP == 11
     // SBA_FUSED_MFMA=f32 keeps the f32-input MFMA kernel (A/B measurements, equivalence test); default: bf16 x 3 split
     if (const char* e = getenv("SBA_FUSED_MFMA")) fused_bf3 = (std::string(e) != "f32");
@@ -411,7 +424,7 @@ struct Engine : EngineBase {
     lin_pts_ok = (dense_one_group || masked_fused) && SCHUR_LIN_OK<T> && !getenv("SBA_NO_FUSED");
     if (fused_masked || (lin_pts_ok && !dense_one_group)) vis_mask.upload(vmask, stream);
     if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * GROUP_ROWS);
-    cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1));
+    cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1)); gmax_alt.alloc(std::max(std::max(nblk, ksplit), 1));
     trial_part.alloc((size_t)4 * std::max(nblk, 1));
     up_lap("allocations + H2D enqueue");
     sync();   // the staging vectors go out of scope now
@@ -488,12 +501,27 @@ struct Engine : EngineBase {
 #if SBA_NCP == 11
     if constexpr (sizeof(T) == 4) {
       if (fused()) {
-        if (fused_bf3)
+        if (fused_bf3) {
+          FusedDecide fd{};
+          fd.st_in = fd.st_out = d_state.p;
+          double* gm_out = (gmax_cur == gmax_part.p) ? gmax_alt.p : gmax_part.p;      // never the array a decision may still read
+          if (pending_decide) {
+            st_slot ^= 1;
+            fd.st_out = d_state_buf.p + st_slot;
+            fd.do_decide = 1;
+            fd.scal_all = pend_scal; fd.n_ranks = pend_ranks;
+            fd.trial_part = trial_part.p; fd.gmax_in = gmax_cur;
+            fd.n_trial = n_trial_parts(); fd.n_gmax = n_lin_parts();
+            fd.log = reinterpret_cast<LMLogRow*>(d_log.p); fd.log_cap = LOG_CAP;
+          }
           hipLaunchKernelGGL(k_schur_fused_bf3, dim3(ksplit), dim3(SCHUR_THREADS), SchurBf3Cfg::LDS_BYTES, stream,
-                             ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
+                             ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
                              N, ksplit, D2p.p, gp.p, pfac.p,
-                             slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p, schur_debug ? schur_dbg.p : nullptr);
-        else
+                             slabs.p, bpart.p, gdpart.p, cost_part.p, gm_out, schur_debug ? schur_dbg.p : nullptr);
+          d_state.p = fd.st_out;
+          pending_decide = false;
+          gmax_cur = gm_out;
+        } else
           hipLaunchKernelGGL(k_schur_fused, dim3(ksplit), dim3(SCHUR_THREADS), SchurFusedCfg<float>::LDS_BYTES, stream,
                              ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
                              N, ksplit, D2p.p, gp.p, pfac.p,
@@ -506,6 +534,9 @@ struct Engine : EngineBase {
           for (int i = 0; i < 14; ++i) fprintf(stderr, "  it %2d: P %7lld  C %7lld\n", i, st[2 * i] - st[0], st[2 * i + 1] - st[0]);
           fprintf(stderr, "  phases (cycles): prologue %lld | main loop %lld | fold U %lld | slab stores %lld | tail %lld | whole kernel %lld\n",
                   st[49] - st[48], st[50] - st[49], st[51] - st[50], st[52] - st[51], st[53] - st[52], st[53] - st[48]);
+          if (fused_bf3)
+            fprintf(stderr, "  prologue (cycles): loads requested + LDS zeroed %lld | first barrier passed (record arrived) %lld | camera table in LDS %lld | producers set up %lld\n",
+                    st[54] - st[48], st[55] - st[48], st[56] - st[48], st[49] - st[48]);
           schur_debug = false;
         }
         return;
@@ -769,6 +800,9 @@ struct Engine : EngineBase {
     if (!uploaded) { err = "sba_upload has not been called"; return SBA_ERR_STATE; }
     HIPCHK(hipSetDevice(device));
     opts = *o;
+    st_slot = 0;
+    d_state.p = d_state_buf.p;
+    pending_decide = false;
     prof_on = opts.reserved[0] != 0;
     for (int k = 0; k < KP_N; ++k) { prof_us[k] = 0; prof_cnt[k] = 0; }
     pslot = 0;
@@ -842,6 +876,8 @@ struct Engine : EngineBase {
     log_read = 0;
     n_decides = 0;
     poll_clean = false;
+    pending_decide = false;
+    gmax_cur = gmax_part.p;
     lm_active = true;
     if (!std::isfinite(c0)) { err = "Residuals are not finite in the initial point."; return SBA_ERR_NONFINITE; }
     return SBA_OK;
@@ -850,6 +886,7 @@ struct Engine : EngineBase {
   int lm_linearize() override {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     poll_clean = false;
+    if (!bf3_path()) flush_decide();
     if (sq_mode()) { launch_sq_linearize(d_state.p); return SBA_OK; }
     if (fused()) return SBA_OK;          // k_schur_fused linearises
     if (!lin_pts()) {                    // (f64 one-group rigs: k_schur_sym<LIN> linearises the points)
@@ -865,6 +902,7 @@ struct Engine : EngineBase {
   int form_reduced(double* E, double* Pk) {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     poll_clean = false;
+    if (!bf3_path()) flush_decide();
     if (sq_mode()) {
       if (opts.mode == SBA_MODE_CAMS_ONLY_SQ)
         hipLaunchKernelGGL(k_sq_pack_cams, dim3(64), dim3(256), 0, stream, sq_16.p, C, d_state.p, E);
@@ -991,7 +1029,7 @@ struct Engine : EngineBase {
     launch_backsub_trial();
     prof_end(KP_BACKSUB);
     if (scal)
-      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_part.p, n_trial_parts(), n_lin_parts(), d_state.p, scal);
+      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_rd(), n_trial_parts(), n_lin_parts(), d_state.p, scal);
     return SBA_OK;
   }
 
@@ -1000,15 +1038,39 @@ struct Engine : EngineBase {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
     poll_clean = false;
     ++n_decides;
-    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(1024), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
-                       gmax_part.p, sq_mode() ? nblk_sq : n_trial_parts(), sq_mode() ? nblk_sq : n_lin_parts(), reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
+    if (defer_decide && bf3_path()) {
+      // the next k_schur_fused_bf3 takes the decision in its prologue; whatever else needs the decided record first
+      // (lm_poll, another linearisation path) enqueues the kernel below through flush_decide()
+      pending_decide = true; pend_scal = scal_all; pend_ranks = n_ranks;
+      pslot_advance();
+      return SBA_OK;
+    }
+    launch_decide(scal_all, n_ranks);
     pslot_advance();
     return SBA_OK;
+  }
+  bool bf3_path() const {
+#if SBA_NCP == 11
+    return sizeof(T) == 4 && fused() && fused_bf3 && !sq_mode();
+#else
+    return false;
+#endif
+  }
+  const double* gmax_rd() const { return (bf3_path() && gmax_cur) ? gmax_cur : gmax_part.p; }
+  void launch_decide(const double* scal_all, int n_ranks) {
+    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(1024), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
+                       gmax_rd(), sq_mode() ? nblk_sq : n_trial_parts(), sq_mode() ? nblk_sq : n_lin_parts(), reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
+  }
+  void flush_decide() {
+    if (!pending_decide) return;
+    launch_decide(pend_scal, pend_ranks);
+    pending_decide = false;
   }
 
   // read the state back (one sync); returns the scipy status or -1 while the solve is still running
   int lm_poll(int32_t* status_out, int32_t* iterations_out) override {
     if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    flush_decide();
     HIPCHK(hipMemcpyAsync(h_state, d_state.p, sizeof(LMState), hipMemcpyDeviceToHost, stream));
     // the log rows written since the last poll travel with the state: at most one row per accept/reject kernel enqueued so far,
     // into the pinned landing area when they fit (the usual case: a batch of iterations), otherwise by a second copy below

@@ -96,6 +96,98 @@ __device__ inline double block_sum(double v, double* scratch) {
     for (int i = 0; i < nw; ++i) s += scratch[i];
   return s;
 }
+
+// ------------------------------------------------------------------ accept / reject / terminate (device function)
+// One iteration-log row per trial step, same columns scipy prints with verbose=2 (layout = sba_lm_iter_log).
+struct LMLogRow { int iteration; int accepted; long long nfev; double cost, cost_reduction, step_norm, optimality, lambda, rho; };
+static_assert(sizeof(LMState) % 4 == 0, "LMState is copied word by word");
+
+// per-thread partial sums of the trial scalars (single rank: folded here from the per-workgroup partials of the trial and
+// linearisation kernels; multi-rank: the gathered scalars are read by thread 0 in decide_core)
+struct DecidePartials { double a = 0, b = 0, c = 0, d = 0, g = 0; };
+__device__ inline void decide_gather(DecidePartials& p, const double* __restrict__ scal_all, const double* __restrict__ trial_part,
+                                     const double* __restrict__ gmax_part, int nblk, int n_gmax) {
+  if (scal_all != nullptr) return;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+    const double t0 = trial_part[i], t1 = trial_part[nblk + i], t2 = trial_part[2 * nblk + i], t3 = trial_part[3 * nblk + i];
+    p.a += t0; p.b += t1; p.c += t2; p.d += t3;
+  }
+  for (int i = threadIdx.x; i < n_gmax; i += blockDim.x) p.g = fmax(p.g, gmax_part[i]);
+}
+
+// The accept/reject/terminate decision of one trial step on a copy `st` of the state record in LDS.  Called by every thread
+// of the workgroup (it contains one barrier); thread 0 updates the record and fills *row; the caller adds a barrier before
+// other threads read either.  Returns (thread 0) whether the row belongs into the log.  Fixed summation order: every
+// workgroup that runs this on the same inputs reaches the same decision bit for bit.
+__device__ inline bool decide_core(LMState* st, const DecidePartials& p, const double* __restrict__ scal_all, int n_ranks,
+                                   LMLogRow* row, int log_cap) {
+  double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
+  if (scal_all == nullptr) {
+    // one LDS exchange for all five reductions
+    __shared__ double s_red[5][16];
+    const double a = wave_sum(p.a), b = wave_sum(p.b), c = wave_sum(p.c), d = wave_sum(p.d), g = wave_max(p.g);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) { s_red[0][wid] = a; s_red[1][wid] = b; s_red[2][wid] = c; s_red[3][wid] = d; s_red[4][wid] = g; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int i = 0; i < nw; ++i) { cost_new += s_red[0][i]; pred += s_red[1][i]; dx2 += s_red[2][i]; x2 += s_red[3][i]; gmax = fmax(gmax, s_red[4][i]); }
+    failv = (double)st->chol_fail;
+  }
+  if (threadIdx.x != 0) return false;
+  if (scal_all != nullptr) {
+    for (int r = 0; r < n_ranks; ++r) {
+      const double* s = scal_all + (size_t)r * NSCAL;
+      cost_new += s[0]; pred += s[1]; dx2 += s[2]; x2 += s[3];
+      gmax = fmax(gmax, s[4]); failv = fmax(failv, s[5]);
+    }
+  }
+  pred += st->pred_c; dx2 += st->dx2_c; x2 += st->x2_c; gmax = fmax(gmax, st->gmax_c);
+  st->gnorm = gmax;
+  st->step_norm = sqrt(dx2);
+  st->x_norm = sqrt(x2);
+  st->cost_new = cost_new;
+  st->pred = pred;
+  st->iter += 1;
+  int status = -1;
+  int accepted = 0;
+  double actual = 0, rho = 0;
+  if (gmax < st->gtol) {                      // scipy trf.py:452 tests this before taking a step
+    status = 1;
+  } else {
+    st->nfev += 1;
+    const bool ok = !(failv > 0) && isfinite(cost_new) && pred > 0;
+    actual = ok ? st->cost - cost_new : -1.0;
+    rho = ok ? actual / pred : -1.0;
+    if (ok) {                                  // scipy common.py:705-717
+      const bool f_ok = actual < st->ftol * st->cost && rho > 0.25;
+      const bool x_ok = sqrt(dx2) < st->xtol * (st->xtol + sqrt(x2));
+      status = (f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : -1;
+    }
+    if (actual > 0) {
+      const double t = 2.0 * rho - 1.0;
+      const double l = st->lam * fmax(1.0 / 3.0, 1.0 - t * t * t);
+      st->lam = fmin(fmax(l, st->lam_min), st->lam_max);
+      st->nu = 2.0;
+      accepted = 1;
+      st->n_accepted += 1;
+      st->cost = cost_new;        // refreshed again from the exchange buffer after the next linearization
+      st->njev += 1;              // the accepted point gets a new Jacobian (scipy counts it the same way)
+      st->fresh = 1;
+      st->cur ^= 1;               // the trial point becomes the current one
+    } else {
+      st->lam = fmin(st->lam * st->nu, st->lam_max);
+      st->nu *= 2.0;
+    }
+    if (status < 0 && st->nfev >= st->max_nfev) status = 0;
+  }
+  if (status < 0 && st->max_iter > 0 && st->iter >= st->max_iter) status = 0;
+  st->accepted = accepted; st->actual = actual; st->rho = rho;
+  st->need_lin = (accepted || st->always_relin) ? 1 : 0;
+  st->status = status;
+  row->iteration = st->iter; row->accepted = accepted; row->nfev = st->nfev; row->cost = st->cost;
+  row->cost_reduction = actual; row->step_norm = st->step_norm; row->optimality = gmax; row->lambda = st->lam; row->rho = rho;
+  return st->iter <= log_cap;
+}
 __device__ inline double block_max(double v, double* scratch) {
   v = wave_max(v);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1458,8 +1550,26 @@ struct SchurBf3Cfg {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
+// The accept/reject decision of the PREVIOUS trial step can ride in this kernel's prologue (do_decide): every workgroup reads
+// the untouched record st_in and the trial partials, runs decide_core on its own LDS copy -- same inputs, same summation
+// order, same decision everywhere -- and workgroup 0 publishes the updated record to st_out (the other slot of a two-entry
+// buffer: nothing a late workgroup still has to read is overwritten; for the same reason the gradient maxima this kernel
+// writes go to a different array than the one the decision reads) and appends the log row.  That takes the k_decide launch
+// (6.6 us of mostly launch and memory latency) out of the iteration for one more dependent read in front of the camera load.
+struct FusedDecide {
+  const LMState* st_in;          // record before the decision (never written by this kernel)
+  LMState* st_out;               // where workgroup 0 publishes it afterwards (== st_in when do_decide == 0: nothing is written)
+  int do_decide;
+  const double* scal_all;        // multi-rank: gathered scalars [n_ranks][NSCAL], else NULL
+  int n_ranks;
+  const double* trial_part;      // [4][n_trial] partials of the trial kernel
+  const double* gmax_in;         // [n_gmax] gradient maxima of the previous linearisation
+  int n_trial, n_gmax;
+  LMLogRow* log;
+  int log_cap;
+};
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
-    const ParamSets<float> ps, const LMState* __restrict__ st, int C,
+    const ParamSets<float> ps, const FusedDecide fd, int C,
     const float2* __restrict__ uv, const float* __restrict__ w, const int32_t* __restrict__ pt_start,
     const uint16_t* __restrict__ vis, int N, int ksplit, double* __restrict__ D2p, double* __restrict__ gp,
     float* __restrict__ pf, float* __restrict__ slabs, double* __restrict__ bpart, double* __restrict__ gdpart,
@@ -1468,27 +1578,74 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
   using T = float;
   using Cfg = SchurBf3Cfg;
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, UPKB = Cfg::UPKB;
-  if (st->status >= 0) return;
   const bool stamp_wg = dbg && blockIdx.x == 0;
   if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();
-  const int cur_ = ps_cur(ps, st);
-  const T* __restrict__ campre = ps.campre[cur_];
-  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  __shared__ LMState s_st;
+  __shared__ LMLogRow s_row;
+  __shared__ int s_have_row;
+  __shared__ double s_scr[2][NPROD / 64];
   T* s_cam = reinterpret_cast<T*>(smem + 2 * Cfg::BUF_BYTES);            // [16][CAMPRE]
   T* s_U = reinterpret_cast<T*>(smem);                                   // [256][UPKB] once the panels are done with
   T* s_Ured = s_U + NPROD * UPKB;                                        // [C][UPKB]
-  __shared__ double s_scr[2][NPROD / 64];
-  {   // zero both buffers once: the pad column (d = 3) of every point is never written again
-    uint4* z4 = reinterpret_cast<uint4*>(smem);
-    for (int i = threadIdx.x; i < 2 * Cfg::BUF_BYTES / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
-  }
-  for (int i = threadIdx.x; i < C * CAMPRE; i += THREADS) s_cam[i] = campre[i];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool producer = threadIdx.x < NPROD;
   int per = (N + ksplit - 1) / ksplit;
   per = ((per + PTS - 1) / PTS) * PTS;
   const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
   const int nchunk = (pend - pbeg + PTS - 1) / PTS;
+  // ---- prologue: ONE round trip to memory.  Which parameter set is current is only known after the record has arrived (and,
+  // with do_decide, after the decision), so everything that depends on it is requested for BOTH sets right away -- the camera
+  // table and the first chunk's point coordinates -- next to the record, the decision's partial sums and the first chunk's
+  // observation data; the selection happens in registers.  (Chained, record -> camera table -> first chunk, the prologue was
+  // three round trips, 6-8k cycles of a 100k-cycle kernel.)
+  static_assert(GROUP_CAMS * CAMPRE <= THREADS, "one camera-table entry per thread");
+  const int q0 = threadIdx.x >> 4, c0 = threadIdx.x & 15;
+  const int p_first = pbeg + q0;
+  const bool first_pt = producer && nchunk > 0 && p_first < pend;
+  T pre_cam[2] = {0, 0}, pre_X[2][3] = {{0, 0, 0}, {0, 0, 0}}, pre_w = 1;
+  double pre_D[3] = {0, 0, 0};
+  unsigned pre_mask = 0xffffu; int pre_start = 0;
+  float2 pre_uv = make_float2(0.f, 0.f);
+  DecidePartials dp;
+  {
+    constexpr int NWORD = sizeof(LMState) / 4;
+    if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(fd.st_in)[threadIdx.x];
+    if (fd.do_decide) decide_gather(dp, fd.scal_all, fd.trial_part, fd.gmax_in, fd.n_trial, fd.n_gmax);
+    if ((int)threadIdx.x < C * CAMPRE) { pre_cam[0] = ps.campre[0][threadIdx.x]; pre_cam[1] = ps.campre[1][threadIdx.x]; }
+    if (first_pt) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        pre_X[0][k] = ps.ptsT[0][3 * (size_t)p_first + k]; pre_X[1][k] = ps.ptsT[1][3 * (size_t)p_first + k];
+        pre_D[k] = D2p[3 * (size_t)p_first + k];
+      }
+      if (vis) { pre_mask = vis[p_first]; pre_start = pt_start[p_first]; }
+      else if (c0 < C) { pre_uv = uv[(size_t)p_first * C + c0]; pre_w = w ? w[(size_t)p_first * C + c0] : (T)1; }
+    }
+    {   // zero both panel buffers meanwhile: the rows of cameras >= C are never written
+      uint4* z4 = reinterpret_cast<uint4*>(smem);
+      for (int i = threadIdx.x; i < 2 * Cfg::BUF_BYTES / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (stamp_wg && threadIdx.x == 0) dbg[54] = clock64();
+    __syncthreads();
+    if (stamp_wg && threadIdx.x == 0) dbg[55] = clock64();
+    if (fd.do_decide) {
+      const bool running = s_st.status < 0;                 // uniform; a finished solve only has its record carried over
+      bool have_row = false;
+      if (running) have_row = decide_core(&s_st, dp, fd.scal_all, fd.n_ranks, &s_row, fd.log_cap);
+      if (threadIdx.x == 0) s_have_row = have_row ? 1 : 0;
+      __syncthreads();
+      if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(fd.st_out)[threadIdx.x] = reinterpret_cast<const int*>(&s_st)[threadIdx.x];
+        if (threadIdx.x == 0 && s_have_row && fd.log) fd.log[s_st.iter - 1] = s_row;
+      }
+    }
+  }
+  if (s_st.status >= 0) return;
+  const LMState* st = &s_st;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  if ((int)threadIdx.x < C * CAMPRE) s_cam[threadIdx.x] = cur_ ? pre_cam[1] : pre_cam[0];
+  if (stamp_wg && threadIdx.x == 0) dbg[56] = clock64();
   const T lam = (T)st->lam;
   auto fold_u = [&]() {
     for (int o = threadIdx.x; o < C * UPKB; o += THREADS) {
@@ -1534,8 +1691,23 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
       }
       request_index(chunk + 1);
     };
-    request_index(0);
-    request(0);
+    {   // chunk 0 was requested in the prologue
+      i_pt = first_pt; i_mask = pre_mask; i_start = pre_start;
+      n_pt = i_pt;
+      n_valid = i_pt && cam_ok && ((i_mask >> c) & 1u);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { n_X[k] = cur_ ? pre_X[1][k] : pre_X[0][k]; n_D[k] = pre_D[k]; }
+      if (n_valid) {
+        if (vis) {
+          const size_t o = (size_t)i_start + __builtin_popcount(i_mask & ((1u << c) - 1u));
+          n_uv = uv[o];
+          n_w = w ? w[o] : (T)1;
+        } else {
+          n_uv = pre_uv; n_w = pre_w;
+        }
+      }
+      request_index(1);
+    }
     if (stamp_wg && threadIdx.x == 0) dbg[49] = clock64();
     // byte offset of this lane's 8-byte slot inside a plane: half (q >> 2) & 1, row 16 e + c, slot sigma(q) ^ (c >> 1)
     const int lane_slot = ((q >> 2) & 1) * Cfg::HALF_BYTES + c * 64 + ((((q & 3) | ((q >> 3) << 2)) ^ (c >> 1)) << 3);

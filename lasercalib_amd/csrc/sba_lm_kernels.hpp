@@ -624,9 +624,9 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
 }
 
 // ------------------------------------------------------------------ accept / reject / terminate
-// One iteration-log row per trial step, same columns scipy prints with verbose=2 (layout = sba_lm_iter_log).
-struct LMLogRow { int iteration; int accepted; long long nfev; double cost, cost_reduction, step_norm, optimality, lambda, rho; };
-
+// The decision itself is decide_core (sba_kernels.hpp); this kernel runs it on the record in place.  k_schur_fused_bf3 runs
+// the same function in its prologue instead (every workgroup redundantly, one of them publishing the result), which takes
+// this launch out of the iteration.
 // scal_all: n_ranks x 8 scalars (already gathered), or -- single rank -- nullptr, in which case the block folds the
 // per-block partials itself (what k_trial_scalars does for the multi-rank path) and no separate launch is needed.
 template <typename T>
@@ -639,102 +639,27 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* st,
   // link costs a memory round trip.  The record is staged in LDS by the whole block (its load overlaps the partial
   // sums), thread 0 works on that copy, writes it back with fire-and-forget stores and publishes `status` last.
   __shared__ LMState s_st;
-  static_assert(sizeof(LMState) % 4 == 0, "LMState is copied word by word");
+  __shared__ LMLogRow s_row;
   constexpr int NWORD = sizeof(LMState) / 4;
-  // the loads of the partials are issued together with the copy of the record (one fabric round trip, not two); they are
-  // harmless when the solve has already terminated
-  double a = 0, b = 0, c = 0, d = 0, g = 0;
-  if (scal_all == nullptr) {
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
-      const double t0 = trial_part[i], t1 = trial_part[nblk + i], t2 = trial_part[2 * nblk + i], t3 = trial_part[3 * nblk + i];
-      a += t0; b += t1; c += t2; d += t3;
-    }
-    for (int i = threadIdx.x; i < n_gmax; i += blockDim.x) g = fmax(g, gmax_part[i]);
-  }
+  DecidePartials dp;
+  decide_gather(dp, scal_all, trial_part, gmax_part, nblk, n_gmax);
   if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
   __syncthreads();
   if (s_st.status >= 0) return;
-  LMState* const gst = st;
-  st = &s_st;
-  double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
-  if (scal_all == nullptr) {
-    // one LDS exchange for all five reductions (five block_sum calls were ten barriers)
-    __shared__ double s_red[5][16];
-    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d); g = wave_max(g);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (lane == 0) { s_red[0][wid] = a; s_red[1][wid] = b; s_red[2][wid] = c; s_red[3][wid] = d; s_red[4][wid] = g; }
-    __syncthreads();
-    if (threadIdx.x == 0)
-      for (int i = 0; i < nw; ++i) { cost_new += s_red[0][i]; pred += s_red[1][i]; dx2 += s_red[2][i]; x2 += s_red[3][i]; gmax = fmax(gmax, s_red[4][i]); }
-    failv = (double)st->chol_fail;
-  }
+  const bool have_row = decide_core(&s_st, dp, scal_all, n_ranks, &s_row, log_cap);      // result valid in thread 0
   if (threadIdx.x != 0) return;
-  if (scal_all != nullptr) {
-    for (int r = 0; r < n_ranks; ++r) {
-      const double* s = scal_all + (size_t)r * NSCAL;
-      cost_new += s[0]; pred += s[1]; dx2 += s[2]; x2 += s[3];
-      gmax = fmax(gmax, s[4]); failv = fmax(failv, s[5]);
-    }
-  }
-  pred += st->pred_c; dx2 += st->dx2_c; x2 += st->x2_c; gmax = fmax(gmax, st->gmax_c);
-  st->gnorm = gmax;
-  st->step_norm = sqrt(dx2);
-  st->x_norm = sqrt(x2);
-  st->cost_new = cost_new;
-  st->pred = pred;
-  st->iter += 1;
-  int status = -1;
-  int accepted = 0;
-  double actual = 0, rho = 0;
-  if (gmax < st->gtol) {                      // scipy trf.py:452 tests this before taking a step
-    status = 1;
-  } else {
-    st->nfev += 1;
-    const bool ok = !(failv > 0) && isfinite(cost_new) && pred > 0;
-    actual = ok ? st->cost - cost_new : -1.0;
-    rho = ok ? actual / pred : -1.0;
-    if (ok) {                                  // scipy common.py:705-717
-      const bool f_ok = actual < st->ftol * st->cost && rho > 0.25;
-      const bool x_ok = sqrt(dx2) < st->xtol * (st->xtol + sqrt(x2));
-      status = (f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : -1;
-    }
-    if (actual > 0) {
-      const double t = 2.0 * rho - 1.0;
-      const double l = st->lam * fmax(1.0 / 3.0, 1.0 - t * t * t);
-      st->lam = fmin(fmax(l, st->lam_min), st->lam_max);
-      st->nu = 2.0;
-      accepted = 1;
-      st->n_accepted += 1;
-      st->cost = cost_new;        // refreshed again from the exchange buffer after the next linearization
-      st->njev += 1;              // the accepted point gets a new Jacobian (scipy counts it the same way)
-      st->fresh = 1;
-      st->cur ^= 1;               // the trial point becomes the current one
-    } else {
-      st->lam = fmin(st->lam * st->nu, st->lam_max);
-      st->nu *= 2.0;
-    }
-    if (status < 0 && st->nfev >= st->max_nfev) status = 0;
-  }
-  if (status < 0 && st->max_iter > 0 && st->iter >= st->max_iter) status = 0;
-  st->accepted = accepted; st->actual = actual; st->rho = rho;
-  st->need_lin = (accepted || st->always_relin) ? 1 : 0;
-  if (log && st->iter <= log_cap) {
-    LMLogRow row;
-    row.iteration = st->iter; row.accepted = accepted; row.nfev = st->nfev; row.cost = st->cost;
-    row.cost_reduction = actual; row.step_norm = st->step_norm; row.optimality = gmax; row.lambda = st->lam; row.rho = rho;
-    log[st->iter - 1] = row;
-  }
+  if (have_row && log) log[s_st.iter - 1] = s_row;
   {
     constexpr int SW = offsetof(LMState, status) / 4;
     const int* src = reinterpret_cast<const int*>(&s_st);
-    int* dst = reinterpret_cast<int*>(gst);
+    int* dst = reinterpret_cast<int*>(st);
 #pragma unroll
     for (int wd = 0; wd < NWORD; ++wd)
       if (wd != SW) dst[wd] = src[wd];
   }
   // no fence: every reader of the record (the next kernels of the stream, the host's copy in lm_poll) is ordered after
   // this kernel by the stream itself
-  gst->status = status;
+  st->status = s_st.status;
 }
 
 }  // namespace SBA_NS

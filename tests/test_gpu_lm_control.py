@@ -125,3 +125,33 @@ def test_far_start_with_outliers_ends_in_a_stationary_point():
     again, _, _ = orc.bundle_adjust(cams, pts, uv, p["ci"], p["pi"], ftol=1e-6, max_nfev=50)
     assert again.cost >= rep.cost * (1 - 1e-5)
     assert abs(rep.cost - ref.cost) <= 5e-3 * ref.cost
+
+
+@pytest.mark.parametrize("kw", [
+    dict(ftol=1e-4),                                                                   # terminates by ftol inside a batch
+    dict(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=7, always_relinearize=True),           # stops on the iteration budget
+    dict(ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=5, lambda0=1e-12),              # rejected steps in the mix
+])
+def test_decision_in_the_fused_prologue_equals_the_separate_kernel(kw, monkeypatch):
+    """fp32, <= 16 cameras: k_schur_fused_bf3 takes the accept/reject decision of the previous trial in its prologue (every
+    workgroup redundantly, workgroup 0 publishing the record; csrc/sba_kernels.hpp FusedDecide).  SBA_DECIDE_KERNEL=1 keeps
+    the separate k_decide launch: same decision function on the same inputs -> identical logs and identical parameters."""
+    rig = make_rig(12, 3000, seed=11, visibility=0.85)
+    args = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+
+    def run():
+        with _native.Problem(*args, dtype="f32") as prob:
+            return prob.solve_lm(prob.make_opts(**kw))
+
+    cams_a, pts_a, rep_a, log_a = run()
+    monkeypatch.setenv("SBA_DECIDE_KERNEL", "1")
+    cams_b, pts_b, rep_b, log_b = run()
+    assert rep_a.status == rep_b.status and rep_a.iterations == rep_b.iterations and rep_a.nfev == rep_b.nfev
+    assert rep_a.iterations >= 2
+    assert len(log_a) == len(log_b) == rep_a.iterations
+    for ra, rb in zip(log_a, log_b):
+        for f in ("iteration", "accepted", "nfev", "cost", "cost_reduction", "step_norm", "optimality", "lambda_", "rho"):
+            if hasattr(ra, f):
+                assert getattr(ra, f) == getattr(rb, f), f
+    assert rep_a.cost == rep_b.cost and rep_a.optimality == rep_b.optimality
+    assert np.array_equal(cams_a, cams_b) and np.array_equal(pts_a, pts_b)
