@@ -116,6 +116,31 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ Dt, const 
   __builtin_amdgcn_wave_barrier();
 }
 
+// Wave 0's share of phase B in one go: P = A21 Linv^T for the block right below the diagonal, then D -= P P^T for the next
+// diagonal tile.  The panel product is formed TRANSPOSED (operands swapped: P^T = Linv A21^T), because the accumulator
+// layout of P^T -- lane holds P[lane & 15][(lane >> 4) + 4 reg] -- is exactly the A/B operand layout the downdate needs:
+// the four accumulator registers go straight back into the MFMAs and the serial chain loses an LDS write/read round trip.
+// P itself is still written to LDS for the other waves' trailing updates (not on the chain).
+__device__ __forceinline__ void chol_panel_update_diag(double* __restrict__ Pblk, const double* __restrict__ LinvT, double* __restrict__ Dt) {
+  const int lane = threadIdx.x & 63;
+  const double* Pa = Pblk + (lane & 15) * CLD + (lane >> 4);          // A21[row lane&15][k = 4ks + lane>>4]  (B operand of the swapped product)
+  const double* Pl = LinvT + (lane >> 4) * CLD + (lane & 15);         // LinvT[k = 4ks + lane>>4][lane&15] = Linv[lane&15][k]  (A operand)
+  Mfma<double>::acc_t d;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) d[rg] = Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)];
+  Mfma<double>::acc_t pt = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) pt = Mfma<double>::mma(Pl[4 * ks * CLD], Pa[4 * ks], pt);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) d = Mfma<double>::mma(-pt[ks], pt[ks], d);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Pblk[(lane & 15) * CLD + (lane >> 4) + 4 * rg] = pt[rg];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = d[rg];
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <typename T>
 __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     const double* __restrict__ E /* summed exchange buffer [S | rhs | diagU | gc | cost] */, int C,
@@ -284,9 +309,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     //      diagonal tile with it, the last wave forward-solves the rhs block
     if (wid == 0) {
       if (jb + 1 < nb) {
-        double* P = Lb + cb_off(jb + 1, jb);
-        chol_panel_block(P, LinvT);
-        chol_update_tile(Lb + cb_off(jb + 1, jb + 1), P, P);
+        chol_panel_update_diag(Lb + cb_off(jb + 1, jb), LinvT, Lb + cb_off(jb + 1, jb + 1));
       }
     } else {
       for (int r = jb + 2 + (wid - 1); r < nb; r += NW - 1) chol_panel_block(Lb + cb_off(r, jb), LinvT);

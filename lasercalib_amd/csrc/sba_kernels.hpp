@@ -276,6 +276,35 @@ __global__ void k_project_rows(const double* __restrict__ pts, const double* __r
 // ------------------------------------------------------------------ device-side layout of a dense observation list (sba_upload)
 // The caller's raw arrays (float64 pixels / weights, int64 indices; scripts/get_points3d.py:73-86 order) -> device layout.
 // Observation i must be (point i / C, camera i % C); any deviation raises the flag and the host path takes over.
+// Several camera groups: where a point's observations of one group sit in the point-major list.  For every (group g, point p)
+// gmask[g*N + p] has bit c set when camera 16 g + c sees p and gstart[g*N + p] is the index of the first such observation, so
+// that a Schur producer lane (point, camera) finds its observation at gstart + popcount(mask below c) instead of scanning the
+// point's whole observation list for members of its group.  Requires strictly ascending cameras inside every point (no
+// duplicate (point, camera) pair); *bad is set otherwise and the kernels keep scanning.
+__global__ void k_group_index(const int32_t* __restrict__ ci, const int32_t* __restrict__ pt_start, int N, int ngroups,
+                              uint16_t* __restrict__ gmask, int32_t* __restrict__ gstart, int* __restrict__ bad) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const int a = pt_start[p], b = pt_start[p + 1];
+  int g = 0, prev = -1;
+  unsigned m = 0;
+  int first = a;
+  bool ok = true;
+  auto flush = [&](int upto) {          // close groups g .. upto-1
+    for (; g < upto; ++g) { gmask[(size_t)g * N + p] = (uint16_t)m; gstart[(size_t)g * N + p] = first; m = 0; }
+  };
+  for (int o = a; o < b; ++o) {
+    const int c = ci[o];
+    if (c <= prev) ok = false;
+    prev = c;
+    const int cg = c / GROUP_CAMS;
+    if (cg > g) { flush(cg); first = o; }
+    if (cg == g) m |= 1u << (c - cg * GROUP_CAMS);
+  }
+  flush(ngroups);
+  if (!ok) *bad = 1;
+}
+
 template <typename T>
 __global__ void k_upload_dense(const double2* __restrict__ uv, const long long* __restrict__ ci, const long long* __restrict__ pi,
                                const double* __restrict__ w, int C, int N, long long M,
@@ -854,7 +883,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ pt_start, int N,
     const T* __restrict__ pf, const int32_t* __restrict__ pair_ga, const int32_t* __restrict__ pair_gb,
     int pair0, int ksplit, int dense, T* __restrict__ slabs, double* __restrict__ bpart,
-    long long* __restrict__ dbg /* optional cycle stamps of workgroup (0,0): [it][producer done, consumer done, barrier out] */) {
+    long long* __restrict__ dbg /* optional cycle stamps of workgroup (0,0): [it][producer done, consumer done, barrier out] */,
+    const uint16_t* __restrict__ gmask = nullptr, const int32_t* __restrict__ gstart = nullptr /* k_group_index tables, or NULL: scan */) {
   extern __shared__ __align__(16) unsigned char smem[];
   using Cfg = SchurCfg<T, DIAG>;
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, NCW = Cfg::NCW, TPW = Cfg::TPW;
@@ -945,6 +975,31 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
           // <= 16 points x 16 cameras = 256 observations = one per producer lane; operands of the NEXT chunk were
           // requested one iteration ago (software pipeline: indices two chunks ahead, point data one chunk ahead)
           if (cur_valid) emit(cur_c, cur_p - p0, cur_uv.x, cur_uv.y, cur_w, cur_X[0], cur_X[1], cur_X[2], cur_f);
+        } else if (gmask) {
+          // several camera groups, indexed: lane = (point, camera of the group) finds its observation directly -- every lane
+          // of a wave has work when the group sees the point (scanning the point's whole list kept 16 of 64 cameras' lanes
+          // busy); an off-diagonal pair takes its second group in a second pass (or in the upper lane rows when PTS = 8)
+          constexpr int ROWS = NPROD / 16;
+          constexpr int PASSES = (PTS * Cfg::NPANEL + ROWS - 1) / ROWS;
+          const int r = threadIdx.x >> 4, cl = threadIdx.x & 15;
+#pragma unroll
+          for (int pass = 0; pass < PASSES; ++pass) {
+            const int idx = pass * ROWS + r;
+            const int q = idx % PTS, h = idx / PTS;
+            const int pp = p0 + q;
+            if (h < Cfg::NPANEL && pp < p1) {
+              const int g = h ? gb : ga;
+              const unsigned m = gmask[(size_t)g * N + pp];
+              if ((m >> cl) & 1u) {
+                const size_t o = (size_t)gstart[(size_t)g * N + pp] + __builtin_popcount(m & ((1u << cl) - 1u));
+                T f[PF];
+#pragma unroll
+                for (int k = 0; k < PF; ++k) f[k] = pf[(size_t)pp * PF + k];
+                const auto mm = uv[o];
+                emit(g * GROUP_CAMS + cl, q, mm.x, mm.y, w ? w[o] : (T)1, ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f);
+              }
+            }
+          }
         } else {
           const int o_lo = pt_start[p0], o_hi = pt_start[p1];
           for (int o = o_lo + threadIdx.x; o < o_hi; o += NPROD) {

@@ -14,10 +14,10 @@ __device__ inline double readlane_f64(double v, int src) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
-template <int VAR>
+template <int VAR, int SB>
 __global__ __launch_bounds__(64) void k(const double* A, double* out, long long* cyc, int reps) {
   __shared__ double blk[CB * CLD];
-  __shared__ __align__(16) double s_l[2][CB];
+  __shared__ __align__(16) double s_l[2][64];
   const int lane = threadIdx.x & 63, i = lane & 15;
   const bool ident = lane >= 16;
   long long total = 0;
@@ -32,20 +32,71 @@ __global__ __launch_bounds__(64) void k(const double* A, double* out, long long*
     __builtin_amdgcn_wave_barrier();
     double akk = readlane_f64(dg, 0);
     double piv = __builtin_amdgcn_rsq(akk);
+    double lprev = 0;
+    double lq[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) lq[j] = 0;
 #pragma unroll
     for (int k = 0; k < CB; ++k) {
       const double lik = a[k] * piv;
       a[k] = lik;
+      if (VAR == 5) {
+        // the order the hazards want: the broadcast of l_(k+1)k fills the wait state between the diagonal downdate and its
+        // v_readlane, the column-(k+1) update fills the two wait states between that v_readlane and the rsq
+        if (k + 1 < CB) {
+          __builtin_amdgcn_sched_barrier(0);
+          dg = __builtin_fma(-lik, lik, dg);
+          __builtin_amdgcn_sched_barrier(0);
+          const double bl = readlane_f64(lik, k + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          akk = readlane_f64(dg, k + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          a[k + 1] = __builtin_fma(-lik, bl, a[k + 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          piv = __builtin_amdgcn_rsq(akk);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = k + 2; j < CB; ++j) a[j] -= lik * readlane_f64(lik, j);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       if (k + 1 < CB) {
         dg = __builtin_fma(-lik, lik, dg);
         akk = readlane_f64(dg, k + 1);
         piv = __builtin_amdgcn_rsq(akk);
       }
-      if (VAR == 0) {
+      if (VAR == 4) {
+        // software-pipelined LDS broadcast: the column published in step k-1 was read back during that step (lq), its
+        // updates run in the shadow of this step's rsq; column k+1 takes this step's contribution by v_readlane
+        if (k + 1 < CB) a[k + 1] -= lik * readlane_f64(lik, k + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k >= 1) {
+#pragma unroll
+          for (int j = k + 1; j < CB; ++j) a[j] -= lprev * lq[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        s_l[k & 1][lane] = lik;                    // every lane stores (no branch: one basic block keeps LLVM from sinking the updates)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = k + 2; j < CB; ++j) lq[j] = s_l[k & 1][j];
+        lprev = lik;
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (VAR == 0) {
 #pragma unroll
         for (int j = k + 1; j < CB; ++j) a[j] -= lik * readlane_f64(lik, j);
       } else if (VAR == 1) {
         if (k + 1 < CB) a[k + 1] -= lik * readlane_f64(lik, k + 1);
+      } else if (VAR == 3) {
+        // column k+1 by v_readlane now; the other columns take step k-1's contribution, read back from LDS one step late
+        if (k + 1 < CB) a[k + 1] -= lik * readlane_f64(lik, k + 1);
+        if (lane < 16) s_l[k & 1][lane] = lik;
+        __builtin_amdgcn_wave_barrier();
+        if (k >= 1) {
+#pragma unroll
+          for (int j = k + 1; j < CB; ++j) a[j] -= lprev * s_l[(k - 1) & 1][j];
+        }
+        lprev = lik;
       } else if (VAR == 2) {
         if (k + 1 < CB) a[k + 1] -= lik * readlane_f64(lik, k + 1);
         if (k + 2 < CB) {
@@ -55,6 +106,7 @@ __global__ __launch_bounds__(64) void k(const double* A, double* out, long long*
           for (int j = k + 2; j < CB; ++j) a[j] -= lik * s_l[k & 1][j];
         }
       }
+      if (SB) __builtin_amdgcn_sched_barrier(0);
     }
     if (lane >= 16 && lane < 32) {
 #pragma unroll
@@ -73,9 +125,15 @@ int main() {
   (void)hipMalloc(&dA, 2048); (void)hipMalloc(&dO, 2048); (void)hipMalloc(&dC, 8);
   (void)hipMemcpy(dA, A.data(), 2048, hipMemcpyHostToDevice);
   auto run = [&](int var) {
-    if (var == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
-    if (var == 1) hipLaunchKernelGGL(k<1>, dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
-    if (var == 2) hipLaunchKernelGGL(k<2>, dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
+    if (var == 0) hipLaunchKernelGGL((k<0, 0>), dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
+    if (var == 1) hipLaunchKernelGGL((k<1, 0>), dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
+    if (var == 2) hipLaunchKernelGGL((k<2, 0>), dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
+    if (var == 3) hipLaunchKernelGGL((k<3, 0>), dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
+    if (var == 4) hipLaunchKernelGGL((k<4, 0>), dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
+    if (var == 5) hipLaunchKernelGGL((k<5, 0>), dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
+    if (var == 10) hipLaunchKernelGGL((k<0, 1>), dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
+    if (var == 11) hipLaunchKernelGGL((k<1, 1>), dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
+    if (var == 13) hipLaunchKernelGGL((k<3, 1>), dim3(1), dim3(64), 0, 0, dA, dO, dC, 20);
     long long c; (void)hipMemcpy(&c, dC, 8, hipMemcpyDeviceToHost);
     (void)hipMemcpy(L.data(), dO, 2048, hipMemcpyDeviceToHost);
     // check: out = Linv^T; (Linv^T)(Linv) should equal A^-1 -> verify A * (LinvT * Linv) = I
@@ -87,6 +145,6 @@ int main() {
     }
     printf("variant %d: %lld cycles per tile (%.0f per pivot), |A Ainv - I| = %.2e\n", var, c, c / 16.0, err);
   };
-  run(0); run(1); run(2);
+  run(0); run(1); run(4); run(5);
   return 0;
 }
