@@ -386,9 +386,12 @@ struct Engine : EngineBase {
       int target = 256;
       if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
       // workgroups per k-split: every pair is dealt to TS workgroups (tile split, grid.z of k_schur)
-      // the diagonal and the off-diagonal pairs are two launches, one after the other: each must fill the chip
-      const int wg_per_ks = std::max(ngroups * SchurSel<T, true>::TS, (npairs - ngroups) * SchurSel<T, false>::TS);
-      int ks = std::max(1, target / wg_per_ks);
+      // the diagonal and the off-diagonal pairs are two launches, one after the other, with the same k-split: it is sized so
+      // that the SMALLER of the two still fills the chip (sized for the larger one, the 4 diagonal pairs of a 64-camera rig ran
+      // on 84 of 256 CUs); the larger launch then simply takes several rounds of shorter workgroups
+      const int wg_diag = ngroups * SchurSel<T, true>::TS, wg_off = (npairs - ngroups) * SchurSel<T, false>::TS;
+      const int wg_per_ks = wg_off > 0 ? std::min(wg_diag, wg_off) : wg_diag;
+      int ks = std::max(1, (target + wg_per_ks - 1) / wg_per_ks);
       const int maxks = std::max(1, (N + SCHUR_PTS - 1) / SCHUR_PTS);
       ksplit = std::min(ks, maxks);
     }
