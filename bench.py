@@ -39,8 +39,8 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # f32-in MFMA = vector rate 157
 # HBM bytes per launch from rocprofv3 PMC passes (profiles/r2_pmc_*: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
 # 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).  Valid for the default workload only
 # (16 cams x 50k points, f32, one GPU); other shapes report null.
-PMC_TRAFFIC_BYTES_16x50k_F32 = {"schur_fused": 30.58e6, "schur": 26.58e6, "resjac": 104.62e6, "linearize_points": 19.92e6,
-                                "linearize_cams": 15.52e6, "backsub": 14.54e6, "residual": 13.12e6}
+PMC_TRAFFIC_BYTES_16x50k_F32 = {"schur_fused": 30.72e6, "schur": 26.58e6, "resjac": 104.62e6, "linearize_points": 19.93e6,
+                                "linearize_cams": 15.53e6, "backsub": 14.56e6, "residual": 13.12e6}
 
 
 def parse():
@@ -246,7 +246,9 @@ def main():
                     "note": ("algorithmic f32 flops of the symmetric Schur product against the f32-input MFMA peak (= f32 vector peak). "
                              "k_schur_fused_bf3 forms every f32 product exactly from six bf16 partial products on the bf16 matrix pipe "
                              "(3-way split of the f32 panel), so the f32 MFMA peak is the yardstick BASELINE/SURVEY name, not a hard ceiling "
-                             "for this kernel; its own limit is the producers' VALU work (DESIGN.md 4.2)") if bf3 else None}
+                             "for this kernel; its own limit is the producers' VALU work (DESIGN.md 4.2).  launch_us is the kernel as it runs "
+                             "in the loop: its prologue also takes the accept/reject decision of the previous LM step (about 3 us; a separate "
+                             "6.6 us k_decide launch before, SBA_DECIDE_KERNEL=1 restores it)") if bf3 else None}
         else:
             by = algorithmic_bytes_per_obs(dominant, s, C, shard["pts"].shape[0], M_local) * M_local
             ach = by / (kt[dominant] * 1e-6) / 1e9

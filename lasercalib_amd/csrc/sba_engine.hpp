@@ -1230,8 +1230,11 @@ struct Engine : EngineBase {
     while (status < 0) {
       // a batch of iterations is enqueued back to back; the kernels turn into no-ops once the device-side state says the
       // solve has terminated, and a rejected step skips its re-linearization on the device, not on the host
-      int batch = prof_on ? 1 : BATCH;
-      if (o->max_iter > 0) batch = prof_on ? 1 : std::min(std::max(1, o->max_iter - iters), 64);
+      // (profiling: one event pair per kernel class, read at every poll.  Two iterations per poll, so that the pairs time the
+      //  SECOND one, whose fused kernel carries the previous step's decision in its prologue like every iteration of a normal batch)
+      const int pbatch = bf3_path() && defer_decide ? 2 : 1;
+      int batch = prof_on ? pbatch : BATCH;
+      if (o->max_iter > 0) batch = std::min(std::max(1, o->max_iter - iters), prof_on ? pbatch : 64);
       for (int b = 0; b < batch; ++b) {
         lm_linearize();
         if (!comm) {

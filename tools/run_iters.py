@@ -2,6 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lasercalib_amd import _native
+if os.environ.get('SBA_LIB_AB'):      # A/B runs: another build of the library
+    _native.LIB_PATH = os.environ['SBA_LIB_AB']
 from lasercalib_amd.synth import make_rig
 C, N, K, dtype = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 rig = make_rig(C, N, seed=0)
