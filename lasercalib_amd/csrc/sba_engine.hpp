@@ -30,7 +30,7 @@ struct Engine : EngineBase {
   bool lin_pts_ok = false;           // f64, one group: the point linearisation runs inside k_schur_sym (LIN)
   bool masked_ok = false;            // one group, no duplicate (point, camera) pairs, not dense: visibility mask available
   DevBuf<uint16_t> vis_mask;
-  DevBuf<uint16_t> grp_mask;         // several camera groups: k_group_index tables [ngroups][N] (f32 Schur producers)
+  DevBuf<uint16_t> grp_mask;         // several camera groups: k_group_index tables [ngroups][N] (Schur producers)
   DevBuf<int32_t> grp_start;
   bool grp_indexed = false;
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
@@ -408,7 +408,7 @@ struct Engine : EngineBase {
     cam_chunk_start.upload(cam_ch, stream);
     pair_ga.upload(pga, stream); pair_gb.upload(pgb, stream);
     grp_indexed = false;
-    if (ngroups > 1 && N > 0 && sizeof(T) == 4 && !getenv("SBA_SCHUR_SCAN")) {
+    if (ngroups > 1 && N > 0 && !getenv("SBA_SCHUR_SCAN")) {
       grp_mask.alloc((size_t)ngroups * N); grp_start.alloc((size_t)ngroups * N);
       if (up_flag.n == 0) up_flag.alloc(1);
       up_flag.zero(stream);
@@ -589,7 +589,9 @@ struct Engine : EngineBase {
     if constexpr (SCHUR_SYM<T>) {
       hipLaunchKernelGGL((k_schur_sym<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
                          stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
-                         pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p, schur_debug ? schur_dbg.p : nullptr);
+                         pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p, schur_debug ? schur_dbg.p : nullptr,
+                         (const uint16_t*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr,
+                         grp_indexed ? grp_mask.p : (const uint16_t*)nullptr, grp_indexed ? grp_start.p : (const int32_t*)nullptr);
       if (schur_debug) {
         std::vector<long long> st(64);
         HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
@@ -603,7 +605,9 @@ struct Engine : EngineBase {
         hipLaunchKernelGGL((k_schur_sym<T, false, PARTIAL>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
                            CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
                            has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N, pfac.p,
-                           pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr);
+                           pair_ga.p, pair_gb.p, ngroups, ksplit, (int)dense, slabs.p, bpart.p, nullptr,
+                           (const uint16_t*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr,
+                           grp_indexed ? grp_mask.p : (const uint16_t*)nullptr, grp_indexed ? grp_start.p : (const int32_t*)nullptr);
       return;
     } else {
     hipLaunchKernelGGL((k_schur<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,

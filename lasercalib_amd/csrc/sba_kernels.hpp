@@ -1072,7 +1072,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
     int pair0, int ksplit, int dense, T* __restrict__ slabs, double* __restrict__ bpart,
     long long* __restrict__ dbg /* optional cycle stamps of workgroup (0,0,0): [it][produce done, after barrier, consume done] */,
     const uint16_t* __restrict__ vis = nullptr /* LIN: per-point visibility mask, NULL = dense */, double* __restrict__ D2p = nullptr,
-    double* __restrict__ gp = nullptr, double* __restrict__ cost_part = nullptr, double* __restrict__ gmax_part = nullptr) {
+    double* __restrict__ gp = nullptr, double* __restrict__ cost_part = nullptr, double* __restrict__ gmax_part = nullptr,
+    const uint16_t* __restrict__ gmask = nullptr, const int32_t* __restrict__ gstart = nullptr /* k_group_index tables, or NULL: scan */) {
   extern __shared__ __align__(16) unsigned char smem[];
   using Cfg = SchurSymCfg<T, DIAG>;
   constexpr int THREADS = Cfg::THREADS, NCW = Cfg::NCW, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K;
@@ -1248,6 +1249,30 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
       cur_valid = n1_valid; cur_c = n1_c; cur_p = n1_p; cur_uv = n1_uv; cur_w = n1_w;
       load_point();
       load_idx(it + 2, n1_valid, n1_c, n1_p, n1_uv, n1_w);
+    } else if (gmask) {
+      // several camera groups, indexed (see k_schur): lane = (point, camera of the group)
+      constexpr int ROWS = THREADS / 16;
+      constexpr int PASSES = (PTS * Cfg::NPANEL + ROWS - 1) / ROWS;
+      const int r = threadIdx.x >> 4, cl = threadIdx.x & 15;
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int idx = pass * ROWS + r;
+        const int q = idx % PTS, h = idx / PTS;
+        const int pp = p0 + q;
+        if (h < Cfg::NPANEL && pp < p1) {
+          const int g = h ? gb : ga;
+          const unsigned m = gmask[(size_t)g * N + pp];
+          if ((m >> cl) & 1u) {
+            const size_t o = (size_t)gstart[(size_t)g * N + pp] + __builtin_popcount(m & ((1u << cl) - 1u));
+            T f[PF];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) f[k] = pf[(size_t)pp * PF + k];
+            const auto mm = uv[o];
+            schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, g * GROUP_CAMS + cl, q, mm.x, mm.y, w ? w[o] : (T)1,
+                                ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f, (T)ps.loss_delta);
+          }
+        }
+      }
     } else {
       const int o_lo = pt_start[p0], o_hi = pt_start[p1];
       for (int o = o_lo + threadIdx.x; o < o_hi; o += THREADS) {
