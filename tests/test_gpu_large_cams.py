@@ -122,3 +122,31 @@ def test_per_gpu_shares_of_configs_4_and_5(C, N, tangential):
     assert np.max(np.abs(ratios - ratios_t)) <= 1e-3
     if tangential:
         assert np.max(np.abs(cams[:, 9:11] - rig["cams_true"][:, 9:11])) <= 1e-4     # 125k points per camera pin p1, p2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("C,N,vis", [(20, 1500, 0.8), (40, 900, 0.6)])
+def test_indexed_group_producers_equal_the_scanning_ones(C, N, vis, dtype, monkeypatch):
+    """Several camera groups: a Schur producer lane (point, camera) finds its observation through the k_group_index tables
+    (csrc/sba_kernels.hpp); SBA_SCHUR_SCAN=1 keeps the scan of the point's observation list.  Both write the same values into
+    the same panel entries, so the solves agree bit for bit.  A list whose cameras DEscend inside every point cannot be
+    indexed (the tables need ascending cameras): it takes the scanning producers by itself and must land on the same optimum."""
+    rig = make_rig(C, N, seed=21, visibility=vis)
+    a = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+
+    def run(args):
+        with _native.Problem(*args, dtype=dtype) as prob:
+            return prob.solve_lm(prob.make_opts(ftol=1e-6))
+
+    cams_i, pts_i, rep_i, log_i = run(a)
+    monkeypatch.setenv("SBA_SCHUR_SCAN", "1")
+    cams_s, pts_s, rep_s, log_s = run(a)
+    monkeypatch.delenv("SBA_SCHUR_SCAN")
+    assert rep_i.iterations == rep_s.iterations >= 2 and rep_i.status == rep_s.status
+    assert rep_i.cost == rep_s.cost and np.array_equal(cams_i, cams_s) and np.array_equal(pts_i, pts_s)
+    # same observations, cameras descending inside each point (stable sort by point keeps that order on the device)
+    order = np.lexsort((-rig["camera_ind"], rig["point_ind"]))
+    b = (rig["cams0"], rig["pts0"], rig["points_2d"][order], rig["camera_ind"][order], rig["point_ind"][order])
+    cams_d, pts_d, rep_d, log_d = run(b)
+    tol = 1e-10 if dtype == "f64" else 1e-5           # another summation order inside the per-point sums, nothing else
+    assert rep_d.status == rep_i.status and abs(rep_d.cost - rep_i.cost) <= tol * rep_i.cost
