@@ -33,6 +33,7 @@ struct Engine : EngineBase {
   DevBuf<uint16_t> grp_mask;         // several camera groups: k_group_index tables [ngroups][N] (Schur producers)
   DevBuf<int32_t> grp_start;
   bool grp_indexed = false;
+  bool no_bf3_pairs = false;         // SBA_NO_BF3_PAIRS=1: f32-input MFMA kernels for every group pair (A/B, equivalence test)
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
   bool fused_bf3 = true;             // ... with the Schur products on the bf16 matrix pipe (k_schur_fused_bf3)
   DevBuf<double> gdpart;
@@ -184,6 +185,7 @@ struct Engine : EngineBase {
 #if SBA_NCP == 11
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_diag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
 #endif
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -408,6 +410,7 @@ struct Engine : EngineBase {
     cam_chunk_start.upload(cam_ch, stream);
     pair_ga.upload(pga, stream); pair_gb.upload(pgb, stream);
     grp_indexed = false;
+    no_bf3_pairs = getenv("SBA_NO_BF3_PAIRS") != nullptr;
     if (ngroups > 1 && N > 0 && !getenv("SBA_SCHUR_SCAN")) {
       grp_mask.alloc((size_t)ngroups * N); grp_start.alloc((size_t)ngroups * N);
       if (up_flag.n == 0) up_flag.alloc(1);
@@ -610,6 +613,13 @@ struct Engine : EngineBase {
                            grp_indexed ? grp_mask.p : (const uint16_t*)nullptr, grp_indexed ? grp_start.p : (const int32_t*)nullptr);
       return;
     } else {
+#if SBA_NCP == 11
+    if (diag_pairs_bf3()) {
+      hipLaunchKernelGGL(k_schur_diag_bf3, dim3(ksplit, ngroups), dim3(SCHUR_THREADS), SchurBf3Cfg::LDS_BYTES, stream,
+                         ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, grp_mask.p, grp_start.p, N, pfac.p, pair_ga.p, 0, ksplit,
+                         slabs.p, bpart.p);
+    } else
+#endif
     hipLaunchKernelGGL((k_schur<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
                        stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
                        pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,
@@ -943,7 +953,7 @@ struct Engine : EngineBase {
       const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 15) / 16 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, npairs, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? gdpart.p : (const double*)nullptr, Pk, (int)(fused() && fused_bf3));
+                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_bf3) ? 1 : (diag_pairs_bf3() ? 2 : 0));
     }
     prof_end(KP_REDUCE);
     return SBA_OK;
@@ -1072,6 +1082,14 @@ struct Engine : EngineBase {
     launch_decide(scal_all, n_ranks);
     pslot_advance();
     return SBA_OK;
+  }
+  // several camera groups, fp32, 11 parameters, indexed producers: the diagonal group pairs run on the bf16 pipe (k_schur_diag_bf3)
+  bool diag_pairs_bf3() const {
+#if SBA_NCP == 11
+    return sizeof(T) == 4 && ngroups > 1 && grp_indexed && !fused() && !no_bf3_pairs;
+#else
+    return false;
+#endif
   }
   bool bf3_path() const {
 #if SBA_NCP == 11

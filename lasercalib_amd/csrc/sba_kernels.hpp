@@ -1974,6 +1974,220 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
     if (stamp_wg) dbg[53] = clock64();
   }
 }
+
+// ------------------------------------------------------------------ diagonal group pair of a multi-group rig on the bf16 pipe
+// The Schur block of ONE camera group with itself (16 cameras, 176 rows) when the rig has several groups: the producers and
+// consumers of k_schur_fused_bf3 without the linearisation around them -- the point factors L^-1, z come from k_point_factor
+// (they involve every camera that sees the point, not just this group), U and g_c from k_linearize_cams, the decision from
+// k_decide.  Lane (q, c) = (point of the 16-point chunk, camera of the group) finds its observation through the k_group_index
+// tables; a lane without one runs the same code with weight 0 and writes zeros.  Same LDS planes, same six bf16 MFMAs per
+// tile and k-step, same parameter-major tile order (k_build_exchange: emajor = 2 undoes it for the diagonal pairs).
+// grid = (ksplit, ngroups).  Replaces k_schur<float, true> there: 4 x fewer matrix cycles, and they overlap with the producers.
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
+    const ParamSets<float> ps, const LMState* __restrict__ st, int C,
+    const float2* __restrict__ uv, const float* __restrict__ w, const uint16_t* __restrict__ gmask, const int32_t* __restrict__ gstart,
+    int N, const float* __restrict__ pf, const int32_t* __restrict__ pair_ga, int pair0, int ksplit,
+    float* __restrict__ slabs, double* __restrict__ bpart) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using T = float;
+  using Cfg = SchurBf3Cfg;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS;
+  if (st->status >= 0) return;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  const int pair = pair0 + blockIdx.y;
+  const int ga = pair_ga[pair];
+  const int camA0 = ga * GROUP_CAMS, nA = min(GROUP_CAMS, C - camA0);
+  const uint16_t* __restrict__ gm = gmask + (size_t)ga * N;
+  const int32_t* __restrict__ gs = gstart + (size_t)ga * N;
+  T* s_cam = reinterpret_cast<T*>(smem + 2 * Cfg::BUF_BYTES);            // [16][CAMPRE]
+  T* s_B = reinterpret_cast<T*>(smem);                                   // [256][NCP] once the panels are done with
+  {   // zero both panel buffers: the rows of cameras >= nA are never written
+    uint4* z4 = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < 2 * Cfg::BUF_BYTES / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
+  }
+  for (int i = threadIdx.x; i < nA * CAMPRE; i += THREADS) s_cam[i] = ps.campre[cur_][(size_t)camA0 * CAMPRE + i];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool producer = threadIdx.x < NPROD;
+  int per = (N + ksplit - 1) / ksplit;
+  per = ((per + PTS - 1) / PTS) * PTS;
+  const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
+  const int nchunk = (pend - pbeg + PTS - 1) / PTS;
+  __syncthreads();
+
+  if (producer) {
+    const int q = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const bool cam_ok = c < nA;
+    const T* cp_safe = s_cam + (cam_ok ? c : 0) * CAMPRE;
+    T bacc[NCP];
+#pragma unroll
+    for (int e = 0; e < NCP; ++e) bacc[e] = (T)0;
+    float2 n_uv = make_float2(0.f, 0.f);
+    T n_w = 1, n_X[3] = {0, 0, 0}, n_f[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) n_f[k] = (T)0;
+    bool n_valid = false;
+    unsigned i_mask = 0; int i_start = 0; bool i_pt = false;
+    auto request_index = [&](int chunk) {
+      const int p = pbeg + chunk * PTS + q;
+      i_pt = chunk < nchunk && p < pend;
+      i_mask = 0; i_start = 0;
+      if (i_pt) { i_mask = gm[p]; i_start = gs[p]; }
+    };
+    auto request = [&](int chunk) {
+      const int p = pbeg + chunk * PTS + q;
+      n_valid = i_pt && cam_ok && ((i_mask >> c) & 1u);
+      if (i_pt) {
+        n_X[0] = ptsT[3 * (size_t)p]; n_X[1] = ptsT[3 * (size_t)p + 1]; n_X[2] = ptsT[3 * (size_t)p + 2];
+        const float4* f4 = reinterpret_cast<const float4*>(pf + (size_t)p * PF);
+        const float4 a = f4[0], b = f4[1], d = f4[2];
+        n_f[0] = a.x; n_f[1] = a.y; n_f[2] = a.z; n_f[3] = a.w; n_f[4] = b.x; n_f[5] = b.y; n_f[6] = b.z; n_f[7] = b.w;
+        n_f[8] = d.x; n_f[9] = d.y; n_f[10] = d.z; n_f[11] = d.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) n_f[k] = (T)0;
+      }
+      if (n_valid) {
+        const size_t o = (size_t)i_start + __builtin_popcount(i_mask & ((1u << c) - 1u));
+        n_uv = uv[o];
+        n_w = w ? w[o] : (T)1;
+      }
+      request_index(chunk + 1);
+    };
+    request_index(0);
+    request(0);
+    const int lane_slot = ((q >> 2) & 1) * Cfg::HALF_BYTES + c * 64 + ((((q & 3) | ((q >> 3) << 2)) ^ (c >> 1)) << 3);
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it < nchunk) {
+        unsigned char* pbuf = smem + (it & 1) * Cfg::BUF_BYTES;
+        const bool valid = n_valid;
+        const float2 m = n_uv;
+        const T ww = n_w, X0 = n_X[0], X1 = n_X[1], X2 = n_X[2];
+        T f[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) f[k] = n_f[k];
+        request(it + 1);
+        T r[2], Jc[2][NCP], Jp[2][3];
+        obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
+        (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+        // Ytilde = Jc^T (Jp L^-T) (all zero for a degenerate or fixed point: its factor row is zero), its three bf16 pieces
+        // into the planes, and the right-hand side  b_c += Ytilde z
+        T Jt[2][3];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          Jt[rr][0] = Jp[rr][0] * f[0];
+          Jt[rr][1] = Jp[rr][0] * f[1] + Jp[rr][1] * f[2];
+          Jt[rr][2] = Jp[rr][0] * f[3] + Jp[rr][1] * f[4] + Jp[rr][2] * f[5];
+        }
+        if (cam_ok) {
+          static_for<0, NCP>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            T y[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) y[d] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
+            bacc[e] = __builtin_fmaf(y[2], f[8], __builtin_fmaf(y[1], f[7], __builtin_fmaf(y[0], f[6], bacc[e])));
+            auto pk = [](float lo, float hi) -> unsigned {
+              unsigned v;
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v) : "v"(lo), "v"(hi));
+              return v;
+            };
+            auto pk1 = [](float lo) -> unsigned {
+              unsigned v;
+              asm("v_cvt_pk_bf16_f32 %0, %1, 0" : "=v"(v) : "v"(lo));
+              return v;
+            };
+            auto lo_f = [](unsigned pkd) -> float { return __builtin_bit_cast(float, pkd << 16); };
+            auto hi_f = [](unsigned pkd) -> float { return __builtin_bit_cast(float, pkd & 0xffff0000u); };
+            const unsigned h01 = pk(y[0], y[1]), h2 = pk1(y[2]);
+            const float r0 = y[0] - lo_f(h01), r1 = y[1] - hi_f(h01), r2 = y[2] - lo_f(h2);
+            const unsigned m01 = pk(r0, r1), m2 = pk1(r2);
+            const float s0 = r0 - lo_f(m01), s1 = r1 - hi_f(m01), s2 = r2 - lo_f(m2);
+            const unsigned l01 = pk(s0, s1), l2 = pk1(s2);
+            unsigned char* dst = pbuf + lane_slot + e * (2 * Cfg::HALF_BYTES);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h2);
+            *reinterpret_cast<uint2*>(dst + Cfg::PLANE * 2) = make_uint2(m01, m2);
+            *reinterpret_cast<uint2*>(dst + 2 * Cfg::PLANE * 2) = make_uint2(l01, l2);
+          });
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();                       // the consumers have read the last panel: the buffers become the hand-over area
+#pragma unroll
+    for (int e = 0; e < NCP; ++e) s_B[threadIdx.x * NCP + e] = bacc[e];
+    __syncthreads();
+    if ((int)threadIdx.x < GROUP_ROWS) {
+      const int cc = threadIdx.x / NCP, e = threadIdx.x - cc * NCP;
+      double sum = 0;
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) sum += (double)s_B[(qq * 16 + cc) * NCP + e];
+      bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + threadIdx.x] = (cc < nA) ? sum : 0.0;
+    }
+  } else {
+    const int cw = wid - NPROD / 64;
+    typename Mfma<T>::acc_t acc[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) acc[s] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+    int frag_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) frag_off[s] = (lane & 15) * 64 + ((((lane >> 4) | (4 * s)) ^ ((lane & 15) >> 1)) << 3);
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it >= 1) {
+        const unsigned char* pbuf = smem + ((it - 1) & 1) * Cfg::BUF_BYTES;
+        static_for<0, Cfg::NV>([&](auto vc) {
+          constexpr int V = decltype(vc)::value;
+          if (cw == V) {
+            constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
+            constexpr int RMIN = schur_tile_R(true, LO);
+#pragma unroll
+            for (int s = 0; s < Cfg::K / 32; ++s) {
+              bf16x8_t fh[GROUP_TILES], fm[GROUP_TILES], fl[GROUP_TILES];
+              auto load = [&](bf16x8_t (&dst)[GROUP_TILES], int plane) {
+#pragma unroll
+                for (int b = RMIN; b < GROUP_TILES; ++b) {
+                  const unsigned char* rowp = pbuf + plane * (Cfg::PLANE * 2) + b * (2 * Cfg::HALF_BYTES) + frag_off[s];
+                  const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(rowp);
+                  const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(rowp + Cfg::HALF_BYTES);
+                  dst[b] = __builtin_bit_cast(bf16x8_t, u32x4_t{lo[0], lo[1], hi[0], hi[1]});
+                }
+              };
+              load(fh, 0);
+              load(fm, 1);
+              load(fl, 2);
+              __builtin_amdgcn_sched_barrier(0);
+              static_for<LO, HI>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fh[Tc], acc[t - LO], 0, 0, 0);
+              });
+              static_for<LO, HI>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fm[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[R], fh[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[R], fm[Tc], acc[t - LO], 0, 0, 0);
+              });
+              static_for<LO, HI>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fl[Tc], acc[t - LO], 0, 0, 0);
+                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[R], fh[Tc], acc[t - LO], 0, 0, 0);
+              });
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        });
+      }
+      __syncthreads();
+    }
+    __syncthreads();                       // matches the producers' barrier in front of the hand-over
+    __syncthreads();                       // (and the one behind it)
+    T* slab = slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
+    schur_store_v<Cfg>(cw, slab, lane, acc);
+  }
+}
 #endif  // SBA_NCP == 11 (fused linearise + Schur kernel)
 
 }  // namespace SBA_NS

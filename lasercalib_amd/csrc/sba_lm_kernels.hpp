@@ -33,7 +33,8 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
                                           slabs hold Schur partials - U and bpart holds b - g_c); NULL = classic U / gc */,
     double* __restrict__ Pk = nullptr /* multi-rank: the same system once more, upper triangle packed row by row
                                          [S n(n+1)/2 | rhs | diagU | gc | cost] -- what travels through the all-reduce */,
-    int emajor = 0 /* k_schur_fused_bf3: tile (R, Tc) holds parameters (R, Tc) of the camera pairs (row 16 e + c) */) {
+    int emajor_mode = 0 /* parameter-major tiles (tile (R, Tc) holds parameters (R, Tc) of the camera pairs, row 16 e + c):
+                           1 = every pair (k_schur_fused_bf3), 2 = the diagonal pairs (k_schur_diag_bf3) */) {
   using M_ = Mfma<T>;
   // tiles: 64 entries x 16 k-split groups per block (256-byte segments per group load; 16 entries x 64 groups was
   // measured slower: 64-byte segments, four times the blocks).  Rows: 16 rows x 64 groups, see below.
@@ -59,8 +60,9 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     schur_tile_rc(diag, t, R, Tc);
     const int e = part * EPB + l16;                   // entry of the tile's register dump: lane = e>>2, reg = e&3
     const int rg = e & 3, lane = e >> 2;            // slab layout [tile][lane][reg]
-    const int i = emajor ? M_::row_of(lane, rg) * NCP + R : ga * GROUP_ROWS + 16 * R + M_::row_of(lane, rg);
-    const int j = emajor ? (lane & 15) * NCP + Tc : gb * GROUP_ROWS + 16 * Tc + (lane & 15);
+    const bool emajor = emajor_mode == 1 || (emajor_mode == 2 && diag);
+    const int i = emajor ? (ga * GROUP_CAMS + M_::row_of(lane, rg)) * NCP + R : ga * GROUP_ROWS + 16 * R + M_::row_of(lane, rg);
+    const int j = emajor ? (gb * GROUP_CAMS + (lane & 15)) * NCP + Tc : gb * GROUP_ROWS + 16 * Tc + (lane & 15);
     const size_t stride = (size_t)NT * 256;
     const T* src = slabs + (size_t)pair * ksplit * stride + (size_t)t * 256 + e;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;

@@ -138,15 +138,44 @@ def test_indexed_group_producers_equal_the_scanning_ones(C, N, vis, dtype, monke
         with _native.Problem(*args, dtype=dtype) as prob:
             return prob.solve_lm(prob.make_opts(ftol=1e-6))
 
+    monkeypatch.setenv("SBA_NO_BF3_PAIRS", "1")       # same consumer kernels on both sides (fp32 diagonal pairs: f32-input MFMAs)
     cams_i, pts_i, rep_i, log_i = run(a)
     monkeypatch.setenv("SBA_SCHUR_SCAN", "1")
     cams_s, pts_s, rep_s, log_s = run(a)
     monkeypatch.delenv("SBA_SCHUR_SCAN")
     assert rep_i.iterations == rep_s.iterations >= 2 and rep_i.status == rep_s.status
     assert rep_i.cost == rep_s.cost and np.array_equal(cams_i, cams_s) and np.array_equal(pts_i, pts_s)
+    monkeypatch.delenv("SBA_NO_BF3_PAIRS")
     # same observations, cameras descending inside each point (stable sort by point keeps that order on the device)
     order = np.lexsort((-rig["camera_ind"], rig["point_ind"]))
     b = (rig["cams0"], rig["pts0"], rig["points_2d"][order], rig["camera_ind"][order], rig["point_ind"][order])
     cams_d, pts_d, rep_d, log_d = run(b)
     tol = 1e-10 if dtype == "f64" else 1e-5           # another summation order inside the per-point sums, nothing else
     assert rep_d.status == rep_i.status and abs(rep_d.cost - rep_i.cost) <= tol * rep_i.cost
+
+
+@pytest.mark.parametrize("C,N,vis", [(20, 1500, 0.8), (40, 900, 0.6), (64, 400, 0.5)])
+def test_diagonal_pairs_on_the_bf16_pipe_follow_the_f32_mfma_kernels(C, N, vis, monkeypatch):
+    """fp32, several camera groups: the diagonal group pairs run k_schur_diag_bf3 (f32 products formed exactly from six bf16
+    partial products, parameter-major tiles) instead of k_schur<float, true> (f32-input MFMAs, SBA_NO_BF3_PAIRS=1).  Same
+    mathematics, different summation order: iteration for iteration the costs of a fixed number of LM steps agree to fp32
+    rounding, and so does the fp64 engine's trajectory at the tolerance fp32 allows."""
+    rig = make_rig(C, N, seed=33, visibility=vis)
+    a = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    kw = dict(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=6, always_relinearize=True)
+
+    def run(dtype):
+        with _native.Problem(*a, dtype=dtype) as prob:
+            return prob.solve_lm(prob.make_opts(**kw))
+
+    _, _, rep_b, log_b = run("f32")
+    monkeypatch.setenv("SBA_NO_BF3_PAIRS", "1")
+    _, _, rep_f, log_f = run("f32")
+    monkeypatch.delenv("SBA_NO_BF3_PAIRS")
+    _, _, rep_d, log_d = run("f64")
+    assert len(log_b) == len(log_f) == len(log_d) == 6
+    for rb, rf, rd in zip(log_b, log_f, log_d):
+        if rd.cost_reduction > 1e-4 * rd.cost:      # below that a step's gain is fp32 rounding noise and accept/reject is a coin toss
+            assert rb.accepted == rf.accepted == rd.accepted == 1
+        assert abs(rb.cost - rf.cost) <= 2e-5 * rf.cost, (rb.iteration, rb.cost, rf.cost)
+        assert abs(rb.cost - rd.cost) <= 1e-4 * rd.cost, (rb.iteration, rb.cost, rd.cost)
