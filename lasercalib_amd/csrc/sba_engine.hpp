@@ -34,6 +34,7 @@ struct Engine : EngineBase {
   DevBuf<int32_t> grp_start;
   bool grp_indexed = false;
   bool no_bf3_pairs = false;         // SBA_NO_BF3_PAIRS=1: f32-input MFMA kernels for every group pair (A/B, equivalence test)
+  bool no_bf3_offdiag = false;       // SBA_NO_BF3_OFFDIAG=1: ... for the off-diagonal pairs only
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
   bool fused_bf3 = true;             // ... with the Schur products on the bf16 matrix pipe (k_schur_fused_bf3)
   DevBuf<double> gdpart;
@@ -186,6 +187,7 @@ struct Engine : EngineBase {
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_diag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_offdiag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3OffCfg::LDS_BYTES));
 #endif
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -411,6 +413,7 @@ struct Engine : EngineBase {
     pair_ga.upload(pga, stream); pair_gb.upload(pgb, stream);
     grp_indexed = false;
     no_bf3_pairs = getenv("SBA_NO_BF3_PAIRS") != nullptr;
+    no_bf3_offdiag = getenv("SBA_NO_BF3_OFFDIAG") != nullptr;
     if (ngroups > 1 && N > 0 && !getenv("SBA_SCHUR_SCAN")) {
       grp_mask.alloc((size_t)ngroups * N); grp_start.alloc((size_t)ngroups * N);
       if (up_flag.n == 0) up_flag.alloc(1);
@@ -634,6 +637,13 @@ struct Engine : EngineBase {
         fprintf(stderr, "  it %2d: P %7lld  C %7lld  out %7lld\n", i, st[3 * i] - st[2], st[3 * i + 1] - st[2], st[3 * i + 2] - st[2]);
       schur_debug = false;
     }
+#if SBA_NCP == 11
+    if (npairs > ngroups && offdiag_pairs_bf3()) {
+      hipLaunchKernelGGL(k_schur_offdiag_bf3, dim3(ksplit, npairs - ngroups), dim3(SCHUR_THREADS), SchurBf3OffCfg::LDS_BYTES, stream,
+                         ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, grp_mask.p, grp_start.p, N, pfac.p, pair_ga.p, pair_gb.p,
+                         ngroups, ksplit, slabs.p);
+    } else
+#endif
     if (npairs > ngroups)
       hipLaunchKernelGGL((k_schur<T, false, PARTIAL>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
                          CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
@@ -953,7 +963,7 @@ struct Engine : EngineBase {
       const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 15) / 16 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, npairs, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_bf3) ? 1 : (diag_pairs_bf3() ? 2 : 0));
+                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_bf3) ? 1 : (diag_pairs_bf3() ? (offdiag_pairs_bf3() ? 1 : 2) : 0));
     }
     prof_end(KP_REDUCE);
     return SBA_OK;
@@ -1091,6 +1101,7 @@ struct Engine : EngineBase {
     return false;
 #endif
   }
+  bool offdiag_pairs_bf3() const { return diag_pairs_bf3() && !no_bf3_offdiag; }
   bool bf3_path() const {
 #if SBA_NCP == 11
     return sizeof(T) == 4 && fused() && fused_bf3 && !sq_mode();

@@ -2188,6 +2188,232 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
     schur_store_v<Cfg>(cw, slab, lane, acc);
   }
 }
+
+// ------------------------------------------------------------------ off-diagonal group pair on the bf16 pipe
+// S(ga, gb) = - sum_p Ytilde_a Ytilde_b^T for two different camera groups: two panels, 121 tiles (row tiles = parameters of group a,
+// column tiles = parameters of group b).  Both panels of a 16-point chunk do not fit the LDS twice, so a chunk is 8 points = ONE
+// 32-deep k-step: 256 producer lanes = 8 points x (16 + 16) cameras, waves 0-1 build panel A, waves 2-3 panel B.
+//   LDS: per buffer 2 panels x 3 bf16 planes x [11 tiles][2 halves][16 rows][4 slots] of 8-byte point slots (32-byte rows):
+//   point q -> half q >> 2, slot (q & 3) ^ ((c >> 2) & 3).  A producer ds_write_b64 (16 lanes: one point, 16 cameras) covers all 32
+//   banks once; a consumer lane (i, g) reads points g and g + 4 of row i with one ds_read2st64_b64 (the halves are 512 B apart), the
+//   four lanes that share a bank column (i, i + 8; g, g ^ 1) hit four different slots.  2 x 67,584 B + camera tables.
+//   Consumers: 30-31 tiles per wave (124 accumulator VGPRs); the wave's <= 4 row fragments of all planes stay in registers for the
+//   chunk, the column tiles stream through a double-buffered 3-plane fragment set (loads of column Tc + 1 under the MFMAs of Tc).
+struct SchurBf3OffCfg {
+  using elem = float;
+  static constexpr bool diag = false;
+  static constexpr int THREADS = SCHUR_THREADS, NPROD = 256, NCW = 4, TS = 1, NV = 4;
+  static constexpr int NTILE = GROUP_TILES * GROUP_TILES;
+  static constexpr int TPW = (NTILE + NV - 1) / NV;
+  static constexpr int PTS = 8, K = 32;
+  static constexpr int HALF_BYTES = 16 * 32, TILE_BYTES = 2 * HALF_BYTES, PLANE_BYTES = GROUP_TILES * TILE_BYTES;
+  static constexpr int PANEL_BYTES = 3 * PLANE_BYTES, BUF_BYTES = 2 * PANEL_BYTES;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES + 2 * (size_t)GROUP_CAMS * CAMPRE * sizeof(float);
+};
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur_offdiag_bf3(
+    const ParamSets<float> ps, const LMState* __restrict__ st, int C,
+    const float2* __restrict__ uv, const float* __restrict__ w, const uint16_t* __restrict__ gmask, const int32_t* __restrict__ gstart,
+    int N, const float* __restrict__ pf, const int32_t* __restrict__ pair_ga, const int32_t* __restrict__ pair_gb, int pair0, int ksplit,
+    float* __restrict__ slabs) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using T = float;
+  using Cfg = SchurBf3OffCfg;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS;
+  if (st->status >= 0) return;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  const int pair = pair0 + blockIdx.y;
+  const int ga = pair_ga[pair], gb = pair_gb[pair];
+  T* s_cam = reinterpret_cast<T*>(smem + 2 * Cfg::BUF_BYTES);            // [2][16][CAMPRE]
+  {
+    uint4* z4 = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < 2 * Cfg::BUF_BYTES / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int cam0 = (h ? gb : ga) * GROUP_CAMS, nc = min(GROUP_CAMS, C - cam0);
+    for (int i = threadIdx.x; i < nc * CAMPRE; i += THREADS) s_cam[h * GROUP_CAMS * CAMPRE + i] = ps.campre[cur_][(size_t)cam0 * CAMPRE + i];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool producer = threadIdx.x < NPROD;
+  int per = (N + ksplit - 1) / ksplit;
+  per = ((per + PTS - 1) / PTS) * PTS;
+  const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
+  const int nchunk = (pend - pbeg + PTS - 1) / PTS;
+  __syncthreads();
+
+  if (producer) {
+    const int h = threadIdx.x >> 7, q = (threadIdx.x >> 4) & 7, c = threadIdx.x & 15;
+    const int g = h ? gb : ga;
+    const int nc = min(GROUP_CAMS, C - g * GROUP_CAMS);
+    const bool cam_ok = c < nc;
+    const T* cp_safe = s_cam + (h * GROUP_CAMS + (cam_ok ? c : 0)) * CAMPRE;
+    const uint16_t* __restrict__ gm = gmask + (size_t)g * N;
+    const int32_t* __restrict__ gs = gstart + (size_t)g * N;
+    float2 n_uv = make_float2(0.f, 0.f);
+    T n_w = 1, n_X[3] = {0, 0, 0}, n_f[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) n_f[k] = (T)0;
+    bool n_valid = false;
+    unsigned i_mask = 0; int i_start = 0; bool i_pt = false;
+    auto request_index = [&](int chunk) {
+      const int p = pbeg + chunk * PTS + q;
+      i_pt = chunk < nchunk && p < pend;
+      i_mask = 0; i_start = 0;
+      if (i_pt) { i_mask = gm[p]; i_start = gs[p]; }
+    };
+    auto request = [&](int chunk) {
+      const int p = pbeg + chunk * PTS + q;
+      n_valid = i_pt && cam_ok && ((i_mask >> c) & 1u);
+      if (i_pt) {
+        n_X[0] = ptsT[3 * (size_t)p]; n_X[1] = ptsT[3 * (size_t)p + 1]; n_X[2] = ptsT[3 * (size_t)p + 2];
+        const float4* f4 = reinterpret_cast<const float4*>(pf + (size_t)p * PF);
+        const float4 a = f4[0], b = f4[1];
+        n_f[0] = a.x; n_f[1] = a.y; n_f[2] = a.z; n_f[3] = a.w; n_f[4] = b.x; n_f[5] = b.y;      // L^-1 only: no right-hand side here
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) n_f[k] = (T)0;
+      }
+      if (n_valid) {
+        const size_t o = (size_t)i_start + __builtin_popcount(i_mask & ((1u << c) - 1u));
+        n_uv = uv[o];
+        n_w = w ? w[o] : (T)1;
+      }
+      request_index(chunk + 1);
+    };
+    request_index(0);
+    request(0);
+    const int lane_slot = h * Cfg::PANEL_BYTES + (q >> 2) * Cfg::HALF_BYTES + c * 32 + (((q & 3) ^ ((c >> 2) & 3)) << 3);
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it < nchunk) {
+        unsigned char* pbuf = smem + (it & 1) * Cfg::BUF_BYTES;
+        const bool valid = n_valid;
+        const float2 m = n_uv;
+        const T ww = n_w, X0 = n_X[0], X1 = n_X[1], X2 = n_X[2];
+        T f[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f[k] = n_f[k];
+        request(it + 1);
+        T r[2], Jc[2][NCP], Jp[2][3];
+        obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
+        (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+        T Jt[2][3];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          Jt[rr][0] = Jp[rr][0] * f[0];
+          Jt[rr][1] = Jp[rr][0] * f[1] + Jp[rr][1] * f[2];
+          Jt[rr][2] = Jp[rr][0] * f[3] + Jp[rr][1] * f[4] + Jp[rr][2] * f[5];
+        }
+        if (cam_ok) {
+          static_for<0, NCP>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            T y[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) y[d] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
+            auto pk = [](float lo, float hi) -> unsigned {
+              unsigned v;
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v) : "v"(lo), "v"(hi));
+              return v;
+            };
+            auto pk1 = [](float lo) -> unsigned {
+              unsigned v;
+              asm("v_cvt_pk_bf16_f32 %0, %1, 0" : "=v"(v) : "v"(lo));
+              return v;
+            };
+            auto lo_f = [](unsigned pkd) -> float { return __builtin_bit_cast(float, pkd << 16); };
+            auto hi_f = [](unsigned pkd) -> float { return __builtin_bit_cast(float, pkd & 0xffff0000u); };
+            const unsigned h01 = pk(y[0], y[1]), h2 = pk1(y[2]);
+            const float r0 = y[0] - lo_f(h01), r1 = y[1] - hi_f(h01), r2 = y[2] - lo_f(h2);
+            const unsigned m01 = pk(r0, r1), m2 = pk1(r2);
+            const float s0 = r0 - lo_f(m01), s1 = r1 - hi_f(m01), s2 = r2 - lo_f(m2);
+            const unsigned l01 = pk(s0, s1), l2 = pk1(s2);
+            unsigned char* dst = pbuf + lane_slot + e * Cfg::TILE_BYTES;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h2);
+            *reinterpret_cast<uint2*>(dst + Cfg::PLANE_BYTES) = make_uint2(m01, m2);
+            *reinterpret_cast<uint2*>(dst + 2 * Cfg::PLANE_BYTES) = make_uint2(l01, l2);
+          });
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    const int cw = wid - NPROD / 64;
+    typename Mfma<T>::acc_t acc[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) acc[s] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+    // fragment of a tile: points g and g + 4 of row i = lane & 15, slot g ^ ((i >> 2) & 3) of the two halves
+    const int frag_off = (lane & 15) * 32 + (((lane >> 4) ^ (((lane & 15) >> 2) & 3)) << 3);
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it >= 1) {
+        const unsigned char* pbuf = smem + ((it - 1) & 1) * Cfg::BUF_BYTES + frag_off;
+        static_for<0, Cfg::NV>([&](auto vc) {
+          constexpr int V = decltype(vc)::value;
+          if (cw == V) {
+            constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
+            constexpr int RMIN = schur_tile_R(false, LO), RMAX = schur_tile_R(false, HI - 1);
+            constexpr int NR = RMAX - RMIN + 1;
+            auto frag = [&](int panel, int plane, int b) -> bf16x8_t {
+              const unsigned char* rowp = pbuf + panel * Cfg::PANEL_BYTES + plane * Cfg::PLANE_BYTES + b * Cfg::TILE_BYTES;
+              const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(rowp);
+              const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(rowp + Cfg::HALF_BYTES);
+              return __builtin_bit_cast(bf16x8_t, u32x4_t{lo[0], lo[1], hi[0], hi[1]});
+            };
+            // registers: 124 accumulators + the wave's <= 4 row fragments of all three planes (stationary for the chunk) + the
+            // three planes of ONE column tile, double-buffered: column Tc + 1 is in flight while the <= 24 MFMAs of column Tc issue
+            bf16x8_t fa[3][NR], fb[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+              for (int rr = 0; rr < NR; ++rr) fa[pl][rr] = frag(0, pl, RMIN + rr);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fb[0][pl] = frag(1, pl, 0);
+            static_for<0, GROUP_TILES>([&](auto cc) {
+              constexpr int Tc = decltype(cc)::value;
+              constexpr int cur = Tc & 1;
+              if constexpr (Tc + 1 < GROUP_TILES) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) fb[cur ^ 1][pl] = frag(1, pl, Tc + 1);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              // the six partial products, row tiles interleaved so that consecutive MFMAs never share an accumulator
+              static_for<0, 6>([&](auto pc) {
+                constexpr int pr = decltype(pc)::value;
+                constexpr int pa = (pr == 0 || pr == 3 || pr == 5) ? 0 : (pr == 1 || pr == 4) ? 1 : 2;     // h h' | m h' | l h' | h m' | m m' | h l'
+                constexpr int pb = pr < 3 ? 0 : pr < 5 ? 1 : 2;
+                static_for<0, NR>([&](auto rc) {
+                  constexpr int R = RMIN + decltype(rc)::value;
+                  constexpr int t = R * GROUP_TILES + Tc;
+                  if constexpr (t >= LO && t < HI)
+                    acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][R - RMIN], fb[cur][pb], acc[t - LO], 0, 0, 0);
+                });
+              });
+              __builtin_amdgcn_sched_barrier(0);
+            });
+          }
+        });
+      }
+      __syncthreads();
+    }
+    float4* slab4 = reinterpret_cast<float4*>(slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256) + lane;
+    static_for<0, Cfg::NV>([&](auto vc) {
+      constexpr int V = decltype(vc)::value;
+      if (cw == V) {
+        constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
+        // a running pointer the compiler cannot fold back into 30 separate 64-bit address constants (those took 60 VGPRs and
+        // spilled around this epilogue)
+        float4* pt = slab4 + LO * 64;
+        static_for<LO, HI>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          *pt = make_float4(acc[t - LO][0], acc[t - LO][1], acc[t - LO][2], acc[t - LO][3]);     // [tile][lane][reg]
+          pt += 64;
+          asm volatile("" : "+v"(pt));
+        });
+      }
+    });
+  }
+}
 #endif  // SBA_NCP == 11 (fused linearise + Schur kernel)
 
 }  // namespace SBA_NS
