@@ -185,10 +185,14 @@ int sba_lm_solve_trial(sba_handle* h, const double* exchange_dev, double* scalar
 int sba_lm_decide(sba_handle* h, const double* scalars_all_dev /*n_ranks*8*/, int32_t n_ranks,
                   int32_t* status_out /* -1 = continue */, int32_t* accepted_out,
                   sba_lm_iter_log* row_out /* may be NULL */);
-/* Non-blocking variant: sba_lm_decide_async only enqueues the decision kernel (every later LM launch turns into
+/* Non-blocking variant: sba_lm_decide_async only enqueues the decision (every later LM launch turns into
  * a no-op on the device once the solve has terminated, and re-linearization after a rejected step is skipped on the
  * device), so a caller may enqueue several iterations back to back and call sba_lm_poll (one stream sync) now and then.
- * status_out: -1 while running, else the scipy status code. */
+ * status_out: -1 while running, else the scipy status code.
+ * The decision may be enqueued LATER than this call: on the fp32 one-group path it rides in the prologue of the next
+ * sba_lm_form_reduced's kernel (or is flushed by sba_lm_poll / sba_lm_finish).  scalars_all_dev must therefore stay
+ * allocated and unchanged until the next sba_lm_form_reduced, sba_lm_poll or sba_lm_finish on this handle has been
+ * CALLED (stream order takes care of the rest). */
 int sba_lm_decide_async(sba_handle* h, const double* scalars_all_dev /* NULL when n_ranks == 1 */, int32_t n_ranks);
 int sba_lm_poll(sba_handle* h, int32_t* status_out, int32_t* iterations_out);
 int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report);
