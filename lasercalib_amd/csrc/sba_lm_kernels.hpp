@@ -83,9 +83,19 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
       for (int q = 0; q < NG; ++q) s += s_p[q][l16];
       double v = -s;                 // fused linearisation: the slabs already hold (Schur partials - U)
       if (!gdpart && ci_ == cj_) v += U[(size_t)ci_ * NCP * NCP + (i - ci_ * NCP) * NCP + (j - cj_ * NCP)];
-      E[(size_t)i * n + j] = v;
-      if (!(diag && R == Tc)) E[(size_t)j * n + i] = v;
-      if (Pk && (i <= j || (emajor && R != Tc))) Pk[exch_packed_index(n, i < j ? i : j, i < j ? j : i)] = v;
+      const bool sym_tile = diag && R == Tc;          // the tile holds both (i, j) and (j, i)
+      if (!emajor) {
+        // camera-major tiles: a symmetric tile is panel^T panel with the SAME fragments on both sides, bitwise symmetric by itself
+        E[(size_t)i * n + j] = v;
+        if (!sym_tile) E[(size_t)j * n + i] = v;
+        if (Pk && i <= j) Pk[exch_packed_index(n, i, j)] = v;
+      } else if (!sym_tile || i <= j) {
+        // parameter-major tiles (bf16 x 3): the two halves of a symmetric tile add the same six partial products in a different
+        // order (h m' and m h' swap), so they differ in the last bits -- the upper half is the value of both, as in the packed copy
+        E[(size_t)i * n + j] = v;
+        E[(size_t)j * n + i] = v;
+        if (Pk) Pk[exch_packed_index(n, i < j ? i : j, i < j ? j : i)] = v;
+      }
     }
     return;
   }

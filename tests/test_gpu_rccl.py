@@ -40,8 +40,17 @@ def test_rccl_loop_equals_plain_loop(dtype, C, N, vis):
     # the trial-cost partials in a different order (k_decide itself vs k_trial_scalars + per-rank rows), so accept / reject
     # decisions at that level are not comparable
     (c0, p0, r0, l0), (c1, p1, r1, l1) = _pair(rig, dtype, ftol=1e-6 if dtype == "f64" else 1e-4)
-    assert r0.status == r1.status and r0.iterations == r1.iterations and r0.nfev == r1.nfev
-    assert [row.accepted for row in l0] == [row.accepted for row in l1]
+    assert r0.status == r1.status
+    if dtype == "f64":
+        assert r0.iterations == r1.iterations and r0.nfev == r1.nfev
+        assert [row.accepted for row in l0] == [row.accepted for row in l1]
+    else:
+        # identical while a step's gain is above fp32 rounding noise; below it the sign of `actual` is a coin toss and one flipped
+        # decision changes how many more (equally useless) steps the solve takes before ftol stops it
+        for a, b in zip(l0, l1):
+            if min(a.cost_reduction, b.cost_reduction) <= 1e-5 * a.cost:
+                break
+            assert a.accepted == b.accepted and abs(a.cost - b.cost) <= 1e-5 * a.cost
     if dtype == "f64":
         assert abs(r0.cost - r1.cost) <= 1e-12 * r0.cost and abs(r0.optimality - r1.optimality) <= 1e-9 * max(1.0, r0.optimality)
         assert np.allclose(c0, c1, rtol=1e-12, atol=1e-12) and np.allclose(p0, p1, rtol=1e-12, atol=1e-12)
