@@ -76,7 +76,10 @@ struct Engine : EngineBase {
   sba_lm_opts opts{};
   bool lm_active = false;
   bool chol_old = false;
-  int chol_big_min_n = CS_MAX_NB * CB;      // systems larger than this (47+ cameras) take the multi-workgroup factorisation
+  // systems larger than this take the multi-workgroup factorisation (sba_chol_big.hpp); up to CS_MAX_NB * CB = 512 unknowns the
+  // streamed one-workgroup kernel could run too, but it only wins below ~210 (measured at 50k points, fp32: 17 cameras 379 vs 388 us
+  // per iteration, 20: 417 vs 409, 24: 487 vs 454, 32: 647 vs 515)
+  int chol_big_min_n = 209;
   DevBuf<double> chol_sol, chol_work, chol_W, chol_Minv, chol_Ld, chol_yv;
   DevBuf<int> chol_info;
   bool chol_debug = false;
