@@ -135,6 +135,7 @@ struct Engine : EngineBase {
     if (have_hres) {
       if (stream) (void)hipStreamSynchronize(stream);     // nothing of this handle may still be in flight when its buffers are recycled
       (void)hipStreamSynchronize(hres.stream);
+      if (hres.copy_stream) (void)hipStreamSynchronize(hres.copy_stream);
       HostResPool::get().give(hres);
     }
   }
@@ -147,6 +148,7 @@ struct Engine : EngineBase {
     if (!HostResPool::get().take(device, &hres)) {
       hres.device = device;
       HIPCHK(hipStreamCreateWithFlags(&hres.stream, hipStreamNonBlocking));
+      HIPCHK(hipStreamCreateWithFlags(&hres.copy_stream, hipStreamNonBlocking));
       HIPCHK(hipHostMalloc(&hres.pinned, HostRes::PINNED_BYTES, hipHostMallocDefault));
       for (auto& e : hres.ev) HIPCHK(hipEventCreate(&e));
     }
@@ -1221,8 +1223,12 @@ struct Engine : EngineBase {
       for (int i = 0; i < n; ++i) gch[i] = 0.0;
     }
     if (cams_out) HIPCHK(hipMemcpyAsync(cams_l, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
-    if (pts_out) HIPCHK(hipMemcpyAsync(pts_out, pts[cur].p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost, stream));
+    // the points (1.2 MB at 50k points, into the caller's pageable array: a staged copy that holds the calling thread) go through the
+    // copy stream, beside the two gradient kernels enqueued above instead of behind them: the solve has been polled, nothing in
+    // flight writes them any more
+    if (pts_out) HIPCHK(hipMemcpyAsync(pts_out, pts[cur].p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost, hres.copy_stream));
     sync();
+    if (pts_out) HIPCHK(hipStreamSynchronize(hres.copy_stream));
     HIPCHK(hipGetLastError());
     if (cams_out) std::memcpy(cams_out, cams_l, sizeof(double) * n);
     double cost = 0;
