@@ -895,10 +895,9 @@ struct Engine : EngineBase {
     s.free_cams = (opts.mode == SBA_MODE_POINTS_ONLY) ? 0 : 1;
     *h_state = s;
     HIPCHK(hipMemcpyAsync(d_state.p, h_state, sizeof(LMState), hipMemcpyHostToDevice, stream));
-    D2p.zero(stream); D2c.zero(stream); delta_c.zero(stream);
-    // trial buffers start as copies so that points-only mode has valid trial cameras
-    HIPCHK(hipMemcpyAsync(cams[1 - cur].p, cams[cur].p, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
-    HIPCHK(hipMemcpyAsync(campre[1 - cur].p, campre[cur].p, sizeof(T) * C * CAMPRE, hipMemcpyDeviceToDevice, stream));
+    // column scalings and camera step cleared, trial camera buffers = copies of the current ones (points-only mode needs valid ones)
+    hipLaunchKernelGGL(k_lm_reset<T>, dim3(256), dim3(256), 0, stream, D2p.p, D2p.n, D2c.p, delta_c.p, n, cams[cur].p, cams[1 - cur].p,
+                       campre[cur].p, campre[1 - cur].p, C * CAMPRE);
     push_ptrs();
     cur_at_begin = cur;
     if (d_log.n == 0) d_log.alloc(LOG_CAP);

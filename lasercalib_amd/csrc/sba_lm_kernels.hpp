@@ -635,6 +635,20 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
   }
 }
 
+// ------------------------------------------------------------------ start of a solve
+// What lm_begin has to reset on the device, in one launch instead of three memsets and two copies (each a separate enqueue of a few
+// microseconds on the host): the monotone column scalings and the camera step are cleared, the trial camera buffers start as copies of
+// the current ones (points-only mode never writes them).
+template <typename T>
+__global__ void k_lm_reset(double* __restrict__ D2p, size_t n_d2p, double* __restrict__ D2c, double* __restrict__ delta_c, int n,
+                           const double* __restrict__ cams_cur, double* __restrict__ cams_trial,
+                           const T* __restrict__ campre_cur, T* __restrict__ campre_trial, int n_campre) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = i0; i < n_d2p; i += stride) D2p[i] = 0.0;
+  for (size_t i = i0; i < (size_t)n; i += stride) { D2c[i] = 0.0; delta_c[i] = 0.0; cams_trial[i] = cams_cur[i]; }
+  for (size_t i = i0; i < (size_t)n_campre; i += stride) campre_trial[i] = campre_cur[i];
+}
+
 // ------------------------------------------------------------------ accept / reject / terminate
 // The decision itself is decide_core (sba_kernels.hpp); this kernel runs it on the record in place.  k_schur_fused_bf3 runs
 // the same function in its prologue instead (every workgroup redundantly, one of them publishing the result), which takes
