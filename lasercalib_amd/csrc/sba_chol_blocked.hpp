@@ -8,10 +8,12 @@
 // Per block column jb (two barriers):
 //   B   the diagonal block already holds Linv^T (below); every wave forms its row blocks of L21 = A21 Linv^T with
 //       4 f64 MFMAs per 16x16 block, one wave forward-solves the rhs block (y = Linv rhs), and wave 0 -- which owns the
-//       block right below the diagonal -- downdates the next diagonal tile with it.
+//       block right below the diagonal -- downdates the next diagonal tile with it (chol_panel_update_diag: the panel product
+//       is formed transposed, so its accumulator registers are the operands of the downdate).
 //   C   wave 0 factors the next diagonal tile (look-ahead) while wave 1 downdates the rhs tail and waves 1..7 apply the
 //       rank-16 trailing update tile by tile (4 MFMAs per tile).
-//   The diagonal factorisation (chol16_wave) is the serial chain of the kernel: lanes 0..15 own the rows of the tile,
+//   The diagonal factorisation (chol16_wave) is the serial chain of the kernel (one cross-lane broadcast per pivot: the row's own
+//   diagonal entry is downdated with the lane's own l_ik): lanes 0..15 own the rows of the tile,
 //   lanes 16..31 run the rows of the identity through the same column operations and so end up with Linv^T, which is
 //   all that is stored (L11 itself is never needed again: B' and the back substitution both multiply by Linv).
 // After the last column the blocked back substitution runs right-looking over all waves.

@@ -34,7 +34,7 @@ constexpr int GROUP_TILES = GROUP_ROWS / 16;   // 11 (13)
 constexpr int NSCAL = 8;
 
 // Current / trial parameter buffers: both sets travel BY VALUE as a kernel argument (no extra dependent load), and
-// a kernel picks its side from LMState::cur, which k_decide flips when a step is accepted -- so the host never has
+// a kernel picks its side from LMState::cur, which decide_core flips when a step is accepted -- so the host never has
 // to learn the outcome of an iteration before enqueueing the next one.  `base` is the side that was current when
 // the solve began (or simply the current side for launches outside the LM loop, where st == nullptr).
 template <typename T> struct ParamSets {
