@@ -587,15 +587,13 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
     const double X0 = pts[pp * 3], X1 = pts[pp * 3 + 1], X2 = pts[pp * 3 + 2];
     T t0 = 0, t1 = 0, t2 = 0;
     if (free_cams && valid) {
-      T r[2], Jc[2][NCP], Jp[2][3];
-      obs_resjac<T>(cp, ptsT[pp * 3], ptsT[pp * 3 + 1], ptsT[pp * 3 + 2], m.x, m.y, ww, r, Jc, Jp);
-      if (ps.loss_delta > 0.f) (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
-      T s0 = 0, s1 = 0;
-#pragma unroll
-      for (int e = 0; e < NCP; ++e) { s0 += Jc[0][e] * dc[e]; s1 += Jc[1][e] * dc[e]; }
-      t0 = Jp[0][0] * s0 + Jp[1][0] * s1;
-      t1 = Jp[0][1] * s0 + Jp[1][1] * s1;
-      t2 = Jp[0][2] * s0 + Jp[1][2] * s1;
+      // W^T dc of this observation = Jp^T (Jc dc): the point block and the directional derivative along the camera step
+      T r[2], Jp[2][3], sj[2];
+      obs_jp_jvp<T>(cp, ptsT[pp * 3], ptsT[pp * 3 + 1], ptsT[pp * 3 + 2], m.x, m.y, ww, dc, r, Jp, sj);
+      if (ps.loss_delta > 0.f) robust_apply_jvp<T>((T)ps.loss_delta, r, Jp, sj);
+      t0 = Jp[0][0] * sj[0] + Jp[1][0] * sj[1];
+      t1 = Jp[0][1] * sj[0] + Jp[1][1] * sj[1];
+      t2 = Jp[0][2] * sj[0] + Jp[1][2] * sj[1];
     }
     const double T0 = (double)row16_sum(t0), T1 = (double)row16_sum(t1), T2 = (double)row16_sum(t2);
     double e0 = 0, e1 = 0, e2 = 0;
