@@ -191,9 +191,9 @@ struct Engine : EngineBase {
 #if SBA_NCP == 11
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_diag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_offdiag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3OffCfg::LDS_BYTES));
 #endif
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_diag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurPairCfg::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_offdiag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3OffCfg::LDS_BYTES));
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -621,13 +621,11 @@ struct Engine : EngineBase {
                            grp_indexed ? grp_mask.p : (const uint16_t*)nullptr, grp_indexed ? grp_start.p : (const int32_t*)nullptr);
       return;
     } else {
-#if SBA_NCP == 11
     if (diag_pairs_bf3()) {
-      hipLaunchKernelGGL(k_schur_diag_bf3, dim3(ksplit, ngroups), dim3(SCHUR_THREADS), SchurBf3Cfg::LDS_BYTES, stream,
+      hipLaunchKernelGGL(k_schur_diag_bf3, dim3(ksplit, ngroups), dim3(SCHUR_THREADS), SchurPairCfg::LDS_BYTES, stream,
                          ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, grp_mask.p, grp_start.p, N, pfac.p, pair_ga.p, 0, ksplit,
                          slabs.p, bpart.p);
     } else
-#endif
     hipLaunchKernelGGL((k_schur<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
                        stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
                        pfac.p, pair_ga.p, pair_gb.p, 0, ksplit, (int)dense, slabs.p, bpart.p,
@@ -642,13 +640,11 @@ struct Engine : EngineBase {
         fprintf(stderr, "  it %2d: P %7lld  C %7lld  out %7lld\n", i, st[3 * i] - st[2], st[3 * i + 1] - st[2], st[3 * i + 2] - st[2]);
       schur_debug = false;
     }
-#if SBA_NCP == 11
     if (npairs > ngroups && offdiag_pairs_bf3()) {
       hipLaunchKernelGGL(k_schur_offdiag_bf3, dim3(ksplit, npairs - ngroups), dim3(SCHUR_THREADS), SchurBf3OffCfg::LDS_BYTES, stream,
                          ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, grp_mask.p, grp_start.p, N, pfac.p, pair_ga.p, pair_gb.p,
                          ngroups, ksplit, slabs.p);
     } else
-#endif
     if (npairs > ngroups)
       hipLaunchKernelGGL((k_schur<T, false, PARTIAL>), dim3(ksplit, npairs - ngroups, CfgO::TS), dim3(CfgO::THREADS),
                          CfgO::LDS_BYTES, stream, ps_lm(), d_state.p, C, uv_pm.p,
@@ -1097,14 +1093,8 @@ struct Engine : EngineBase {
     pslot_advance();
     return SBA_OK;
   }
-  // several camera groups, fp32, 11 parameters, indexed producers: the diagonal group pairs run on the bf16 pipe (k_schur_diag_bf3)
-  bool diag_pairs_bf3() const {
-#if SBA_NCP == 11
-    return sizeof(T) == 4 && ngroups > 1 && grp_indexed && !fused() && !no_bf3_pairs;
-#else
-    return false;
-#endif
-  }
+  // several camera groups, fp32, indexed producers: the group pairs run on the bf16 pipe (k_schur_diag_bf3 / k_schur_offdiag_bf3)
+  bool diag_pairs_bf3() const { return sizeof(T) == 4 && ngroups > 1 && grp_indexed && !fused() && !no_bf3_pairs; }
   bool offdiag_pairs_bf3() const { return diag_pairs_bf3() && !no_bf3_offdiag; }
   bool bf3_path() const {
 #if SBA_NCP == 11

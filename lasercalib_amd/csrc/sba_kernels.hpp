@@ -1328,6 +1328,9 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
   }
 }
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
 #if SBA_NCP == 11
 // ------------------------------------------------------------------ K3+K4 fused (dense visibility, <= 16 cameras, f32)
 // When every point is seen by every camera and there is one camera group, the producer lane (q, c) = (point of the
@@ -1627,8 +1630,6 @@ struct SchurBf3Cfg {
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES + (size_t)GROUP_CAMS * CAMPRE * sizeof(float);
   static_assert(2 * (size_t)BUF_BYTES >= (size_t)(NPROD + GROUP_CAMS) * UPKB * sizeof(float), "the accumulator hand-over reuses the panel buffers");
 };
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 // The accept/reject decision of the PREVIOUS trial step can ride in this kernel's prologue (do_decide): every workgroup reads
 // the untouched record st_in and the trial partials, runs decide_core on its own LDS copy -- same inputs, same summation
@@ -1975,6 +1976,24 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
   }
 }
 
+#endif  // SBA_NCP == 11 (fused linearise + Schur kernels)
+
+// ------------------------------------------------------------------ group pairs of a multi-group rig on the bf16 pipe (both camera models)
+// LDS geometry of one 16-camera panel in parameter-major order (NCP tiles of 16 rows), shared with k_schur_fused_bf3
+struct SchurPairCfg {
+  using elem = float;
+  static constexpr bool diag = true;
+  static constexpr int THREADS = SCHUR_THREADS, NPROD = 256, NCW = 4, TS = 1, NV = 4;
+  static constexpr int NTILE = (GROUP_TILES * (GROUP_TILES + 1)) / 2;
+  static constexpr int TPW = (NTILE + NV - 1) / NV;
+  static constexpr int PTS = 16, K = 64;                           // 16-point chunks = 2 MFMA k-steps of 32
+  static constexpr int HALF_BYTES = 16 * 64;                       // one half of a tile: [16 rows][8 slots][4 bf16]
+  static constexpr int PLANE = GROUP_ROWS * K;                     // bf16 elements per plane (two half-planes)
+  static constexpr int BUF_BYTES = 3 * PLANE * 2;                  // h, m, l
+  static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES + (size_t)GROUP_CAMS * CAMPRE * sizeof(float);
+  static_assert(LDS_BYTES <= 160 * 1024, "the double-buffered panel has to fit the 160 KB LDS (13 parameters: 161,472 B)");
+};
+
 // ------------------------------------------------------------------ diagonal group pair of a multi-group rig on the bf16 pipe
 // The Schur block of ONE camera group with itself (16 cameras, 176 rows) when the rig has several groups: the producers and
 // consumers of k_schur_fused_bf3 without the linearisation around them -- the point factors L^-1, z come from k_point_factor
@@ -1990,7 +2009,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
     float* __restrict__ slabs, double* __restrict__ bpart) {
   extern __shared__ __align__(16) unsigned char smem[];
   using T = float;
-  using Cfg = SchurBf3Cfg;
+  using Cfg = SchurPairCfg;
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS;
   if (st->status >= 0) return;
   const int cur_ = ps_cur(ps, st);
@@ -2143,7 +2162,6 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
             constexpr int RMIN = schur_tile_R(true, LO);
 #pragma unroll
             for (int s = 0; s < Cfg::K / 32; ++s) {
-              bf16x8_t fh[GROUP_TILES], fm[GROUP_TILES], fl[GROUP_TILES];
               auto load = [&](bf16x8_t (&dst)[GROUP_TILES], int plane) {
 #pragma unroll
                 for (int b = RMIN; b < GROUP_TILES; ++b) {
@@ -2153,29 +2171,41 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
                   dst[b] = __builtin_bit_cast(bf16x8_t, u32x4_t{lo[0], lo[1], hi[0], hi[1]});
                 }
               };
-              load(fh, 0);
-              load(fm, 1);
-              load(fl, 2);
-              __builtin_amdgcn_sched_barrier(0);
-              static_for<LO, HI>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fh[Tc], acc[t - LO], 0, 0, 0);
-              });
-              static_for<LO, HI>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fm[Tc], acc[t - LO], 0, 0, 0);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[R], fh[Tc], acc[t - LO], 0, 0, 0);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[R], fm[Tc], acc[t - LO], 0, 0, 0);
-              });
-              static_for<LO, HI>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[R], fl[Tc], acc[t - LO], 0, 0, 0);
-                acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[R], fh[Tc], acc[t - LO], 0, 0, 0);
-              });
-              __builtin_amdgcn_sched_barrier(0);
+              auto products = [&](const bf16x8_t (&fx)[GROUP_TILES], const bf16x8_t (&fy)[GROUP_TILES], bool both) {
+                static_for<LO, HI>([&](auto tc) {
+                  constexpr int t = decltype(tc)::value;
+                  constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+                  acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[R], fy[Tc], acc[t - LO], 0, 0, 0);
+                  if (both) acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[R], fx[Tc], acc[t - LO], 0, 0, 0);
+                });
+              };
+              if constexpr (NCP <= 11) {
+                // 11 tiles: all three planes of the k-step in registers before the first MFMA (132 fragment + 68 accumulator VGPRs)
+                bf16x8_t fh[GROUP_TILES], fm[GROUP_TILES], fl[GROUP_TILES];
+                load(fh, 0);
+                load(fm, 1);
+                load(fl, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                products(fh, fh, false);
+                products(fh, fm, true);
+                products(fm, fm, false);
+                products(fh, fl, true);
+                __builtin_amdgcn_sched_barrier(0);
+              } else {
+                // 13 tiles (91 of them, 92 accumulator VGPRs): two fragment sets, the l plane reuses m's registers
+                bf16x8_t fh[GROUP_TILES], fo[GROUP_TILES];
+                load(fh, 0);
+                load(fo, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                products(fh, fh, false);
+                products(fh, fo, true);
+                products(fo, fo, false);
+                __builtin_amdgcn_sched_barrier(0);
+                load(fo, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                products(fh, fo, true);
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
           }
         });
@@ -2209,6 +2239,7 @@ struct SchurBf3OffCfg {
   static constexpr int HALF_BYTES = 16 * 32, TILE_BYTES = 2 * HALF_BYTES, PLANE_BYTES = GROUP_TILES * TILE_BYTES;
   static constexpr int PANEL_BYTES = 3 * PLANE_BYTES, BUF_BYTES = 2 * PANEL_BYTES;
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES + 2 * (size_t)GROUP_CAMS * CAMPRE * sizeof(float);
+  static_assert(LDS_BYTES <= 160 * 1024, "two double-buffered panels have to fit the 160 KB LDS (13 parameters: 163,200 B)");
 };
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_offdiag_bf3(
     const ParamSets<float> ps, const LMState* __restrict__ st, int C,
@@ -2360,37 +2391,71 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_offdiag_bf3(
               const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(rowp + Cfg::HALF_BYTES);
               return __builtin_bit_cast(bf16x8_t, u32x4_t{lo[0], lo[1], hi[0], hi[1]});
             };
-            // registers: 124 accumulators + the wave's <= 4 row fragments of all three planes (stationary for the chunk) + the
-            // three planes of ONE column tile, double-buffered: column Tc + 1 is in flight while the <= 24 MFMAs of column Tc issue
-            bf16x8_t fa[3][NR], fb[2][3];
+            if constexpr (NCP <= 11) {
+              // registers: 124 accumulators + the wave's <= 4 row fragments of all three planes (stationary for the chunk) + the
+              // three planes of ONE column tile, double-buffered: column Tc + 1 is in flight while the <= 24 MFMAs of column Tc issue
+              bf16x8_t fa[3][NR], fb[2][3];
+  #pragma unroll
+              for (int pl = 0; pl < 3; ++pl)
+  #pragma unroll
+                for (int rr = 0; rr < NR; ++rr) fa[pl][rr] = frag(0, pl, RMIN + rr);
+  #pragma unroll
+              for (int pl = 0; pl < 3; ++pl) fb[0][pl] = frag(1, pl, 0);
+              static_for<0, GROUP_TILES>([&](auto cc) {
+                constexpr int Tc = decltype(cc)::value;
+                constexpr int cur = Tc & 1;
+                if constexpr (Tc + 1 < GROUP_TILES) {
+  #pragma unroll
+                  for (int pl = 0; pl < 3; ++pl) fb[cur ^ 1][pl] = frag(1, pl, Tc + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the six partial products, row tiles interleaved so that consecutive MFMAs never share an accumulator
+                static_for<0, 6>([&](auto pc) {
+                  constexpr int pr = decltype(pc)::value;
+                  constexpr int pa = (pr == 0 || pr == 3 || pr == 5) ? 0 : (pr == 1 || pr == 4) ? 1 : 2;     // h h' | m h' | l h' | h m' | m m' | h l'
+                  constexpr int pb = pr < 3 ? 0 : pr < 5 ? 1 : 2;
+                  static_for<0, NR>([&](auto rc) {
+                    constexpr int R = RMIN + decltype(rc)::value;
+                    constexpr int t = R * GROUP_TILES + Tc;
+                    if constexpr (t >= LO && t < HI)
+                      acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][R - RMIN], fb[cur][pb], acc[t - LO], 0, 0, 0);
+                  });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+              });
+            } else {
+              // 13 parameters: 169 tiles, 42-43 per wave = 172 accumulator VGPRs.  The wave's <= 5 row fragments of ONE plane are
+              // stationary while the column tiles stream past (double-buffered, only the planes that pair with it):
+              // h x (h', m', l'), then m x (h', m'), then l x h' -- the columns are read three times, the consumers have the slack
+              static_for<0, 3>([&](auto pac) {
+                constexpr int pa = decltype(pac)::value;
+                constexpr int NB = 3 - pa;
+                bf16x8_t fa[NR], fb[2][NB];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+                for (int rr = 0; rr < NR; ++rr) fa[rr] = frag(0, pa, RMIN + rr);
 #pragma unroll
-              for (int rr = 0; rr < NR; ++rr) fa[pl][rr] = frag(0, pl, RMIN + rr);
+                for (int pl = 0; pl < NB; ++pl) fb[0][pl] = frag(1, pl, 0);
+                static_for<0, GROUP_TILES>([&](auto cc) {
+                  constexpr int Tc = decltype(cc)::value;
+                  constexpr int cur = Tc & 1;
+                  if constexpr (Tc + 1 < GROUP_TILES) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) fb[0][pl] = frag(1, pl, 0);
-            static_for<0, GROUP_TILES>([&](auto cc) {
-              constexpr int Tc = decltype(cc)::value;
-              constexpr int cur = Tc & 1;
-              if constexpr (Tc + 1 < GROUP_TILES) {
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) fb[cur ^ 1][pl] = frag(1, pl, Tc + 1);
-              }
-              __builtin_amdgcn_sched_barrier(0);
-              // the six partial products, row tiles interleaved so that consecutive MFMAs never share an accumulator
-              static_for<0, 6>([&](auto pc) {
-                constexpr int pr = decltype(pc)::value;
-                constexpr int pa = (pr == 0 || pr == 3 || pr == 5) ? 0 : (pr == 1 || pr == 4) ? 1 : 2;     // h h' | m h' | l h' | h m' | m m' | h l'
-                constexpr int pb = pr < 3 ? 0 : pr < 5 ? 1 : 2;
-                static_for<0, NR>([&](auto rc) {
-                  constexpr int R = RMIN + decltype(rc)::value;
-                  constexpr int t = R * GROUP_TILES + Tc;
-                  if constexpr (t >= LO && t < HI)
-                    acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][R - RMIN], fb[cur][pb], acc[t - LO], 0, 0, 0);
+                    for (int pl = 0; pl < NB; ++pl) fb[cur ^ 1][pl] = frag(1, pl, Tc + 1);
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                  static_for<0, NB>([&](auto pbc) {
+                    constexpr int pb = decltype(pbc)::value;
+                    static_for<0, NR>([&](auto rc) {
+                      constexpr int R = RMIN + decltype(rc)::value;
+                      constexpr int t = R * GROUP_TILES + Tc;
+                      if constexpr (t >= LO && t < HI)
+                        acc[t - LO] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[R - RMIN], fb[cur][pb], acc[t - LO], 0, 0, 0);
+                    });
+                  });
+                  __builtin_amdgcn_sched_barrier(0);
                 });
               });
-              __builtin_amdgcn_sched_barrier(0);
-            });
+            }
           }
         });
       }
@@ -2414,6 +2479,5 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_offdiag_bf3(
     });
   }
 }
-#endif  // SBA_NCP == 11 (fused linearise + Schur kernel)
 
 }  // namespace SBA_NS

@@ -154,13 +154,15 @@ def test_indexed_group_producers_equal_the_scanning_ones(C, N, vis, dtype, monke
     assert rep_d.status == rep_i.status and abs(rep_d.cost - rep_i.cost) <= tol * rep_i.cost
 
 
-@pytest.mark.parametrize("C,N,vis", [(20, 1500, 0.8), (40, 900, 0.6), (64, 400, 0.5)])
-def test_diagonal_pairs_on_the_bf16_pipe_follow_the_f32_mfma_kernels(C, N, vis, monkeypatch):
-    """fp32, several camera groups: the diagonal group pairs run k_schur_diag_bf3 (f32 products formed exactly from six bf16
-    partial products, parameter-major tiles) instead of k_schur<float, true> (f32-input MFMAs, SBA_NO_BF3_PAIRS=1).  Same
-    mathematics, different summation order: iteration for iteration the costs of a fixed number of LM steps agree to fp32
-    rounding, and so does the fp64 engine's trajectory at the tolerance fp32 allows."""
-    rig = make_rig(C, N, seed=33, visibility=vis)
+@pytest.mark.parametrize("C,N,vis,tangential", [(20, 1500, 0.8, False), (40, 900, 0.6, False), (64, 400, 0.5, False),
+                                                  (40, 900, 0.6, True), (48, 500, 0.5, True)])
+def test_group_pairs_on_the_bf16_pipe_follow_the_f32_mfma_kernels(C, N, vis, tangential, monkeypatch):
+    """fp32, several camera groups: the group pairs run k_schur_diag_bf3 / k_schur_offdiag_bf3 (f32 products formed exactly
+    from six bf16 partial products, parameter-major tiles; both camera models: 11 or 13 tiles per group) instead of
+    k_schur<float, DIAG> (f32-input MFMAs, SBA_NO_BF3_PAIRS=1).  Same mathematics, different summation order: iteration for
+    iteration the costs of a fixed number of LM steps agree to fp32 rounding, and so does the fp64 engine's trajectory at the
+    tolerance fp32 allows."""
+    rig = make_rig(C, N, seed=33, visibility=vis, tangential=tangential)
     a = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
     kw = dict(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=6, always_relinearize=True)
 

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig
 C, N, vis = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
-rig = make_rig(C, N, seed=33, visibility=vis)
+tang = len(sys.argv) > 4 and sys.argv[4] == 'tangential'
+rig = make_rig(C, N, seed=33, visibility=vis, tangential=tang)
 a = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
 kw = dict(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=8, always_relinearize=True)
 def run(dtype):
