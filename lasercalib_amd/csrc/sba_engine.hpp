@@ -84,6 +84,7 @@ struct Engine : EngineBase {
   DevBuf<int> chol_info;
   bool chol_debug = false;
   bool schur_debug = false;
+  int schur_debug_skip = 0;           // SBA_SCHUR_DEBUG=k: stamps of the (k+1)-th fused launch (k >= 1: one with the decision in its prologue)
   // multi-rank (one handle per GPU, points sharded, cameras replicated): RCCL communicator + exchange buffers
   DevBuf<double> raw_uv, raw_w;         // the caller's raw arrays on the device (dense fast path of upload)
   DevBuf<long long> raw_ci, raw_pi;
@@ -173,7 +174,7 @@ struct Engine : EngineBase {
       const long v = strtol(e, &end, 10);
       if (end != e && *end == 0 && v >= 0) chol_big_min_n = (int)std::min<long>(v, CS_MAX_NB * CB);
     }
-    if (getenv("SBA_SCHUR_DEBUG")) { schur_debug = true; schur_dbg.alloc(64); schur_dbg.zero(stream); }
+    if (const char* e = getenv("SBA_SCHUR_DEBUG")) { schur_debug = true; schur_debug_skip = std::max(0, atoi(e) - 1); schur_dbg.alloc(64); schur_dbg.zero(stream); }
     static bool attrs_set[16] = {};          // the function attributes are per process (and device), not per handle
     if (device < 16 && attrs_set[device]) return;
     // kernels whose dynamic LDS can exceed the 64 KB default
@@ -546,7 +547,7 @@ struct Engine : EngineBase {
           hipLaunchKernelGGL(k_schur_fused_bf3, dim3(ksplit), dim3(SCHUR_THREADS), SchurBf3Cfg::LDS_BYTES, stream,
                              ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
                              N, ksplit, D2p.p, gp.p, pfac.p,
-                             slabs.p, bpart.p, gdpart.p, cost_part.p, gm_out, schur_debug ? schur_dbg.p : nullptr);
+                             slabs.p, bpart.p, gdpart.p, cost_part.p, gm_out, (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr);
           d_state.p = fd.st_out;
           pending_decide = false;
           gmax_cur = gm_out;
@@ -555,6 +556,7 @@ struct Engine : EngineBase {
                              ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
                              N, ksplit, D2p.p, gp.p, pfac.p,
                              slabs.p, bpart.p, gdpart.p, cost_part.p, gmax_part.p, schur_debug ? schur_dbg.p : nullptr);
+        if (schur_debug && schur_debug_skip > 0) { --schur_debug_skip; return; }
         if (schur_debug) {
           std::vector<long long> st(64);
           HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
@@ -564,8 +566,10 @@ struct Engine : EngineBase {
           fprintf(stderr, "  phases (cycles): prologue %lld | main loop %lld | fold U %lld | slab stores %lld | tail %lld | whole kernel %lld\n",
                   st[49] - st[48], st[50] - st[49], st[51] - st[50], st[52] - st[51], st[53] - st[52], st[53] - st[48]);
           if (fused_bf3)
-            fprintf(stderr, "  prologue (cycles): loads requested + LDS zeroed %lld | first barrier passed (record arrived) %lld | camera table in LDS %lld | producers set up %lld\n",
-                    st[54] - st[48], st[55] - st[48], st[56] - st[48], st[49] - st[48]);
+            fprintf(stderr, "  prologue (cycles): loads requested + LDS zeroed %lld | first barrier passed (record arrived) %lld | decision taken %lld | camera table in LDS %lld | producers set up %lld\n",
+                    st[54] - st[48], st[55] - st[48], st[57] - st[48], st[56] - st[48], st[49] - st[48]);
+          if (fused_bf3 && st[58])
+            fprintf(stderr, "  decision (cycles since kernel start): partial sums folded %lld | record updated %lld\n", st[58] - st[48], st[59] - st[48]);
           schur_debug = false;
         }
         return;
@@ -1073,7 +1077,7 @@ struct Engine : EngineBase {
     launch_backsub_trial();
     prof_end(KP_BACKSUB);
     if (scal)
-      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(256), 0, stream, trial_part.p, gmax_rd(), n_trial_parts(), n_lin_parts(), d_state.p, scal);
+      hipLaunchKernelGGL(k_trial_scalars, dim3(1), dim3(DECIDE_THREADS), 0, stream, trial_part.p, gmax_rd(), n_trial_parts(), n_lin_parts(), d_state.p, scal);
     return SBA_OK;
   }
 
@@ -1105,7 +1109,7 @@ struct Engine : EngineBase {
   }
   const double* gmax_rd() const { return (bf3_path() && gmax_cur) ? gmax_cur : gmax_part.p; }
   void launch_decide(const double* scal_all, int n_ranks) {
-    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(1024), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
+    hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(DECIDE_THREADS), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,
                        gmax_rd(), sq_mode() ? nblk_sq : n_trial_parts(), sq_mode() ? nblk_sq : n_lin_parts(), reinterpret_cast<LMLogRow*>(d_log.p), LOG_CAP);
   }
   void flush_decide() {

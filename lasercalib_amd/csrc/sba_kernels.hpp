@@ -119,21 +119,63 @@ __device__ inline void decide_gather(DecidePartials& p, const double* __restrict
 // of the workgroup (it contains one barrier); thread 0 updates the record and fills *row; the caller adds a barrier before
 // other threads read either.  Returns (thread 0) whether the row belongs into the log.  Fixed summation order: every
 // workgroup that runs this on the same inputs reaches the same decision bit for bit.
+// Five block-wide reductions (four sums, one maximum) of the per-thread partials through LDS: every thread deposits its partials,
+// wave k folds array k 8 : 1 three times (512 -> 64 -> 8 -> 1) in a fixed order; result in out[0..4] of thread 0.  Called by all
+// DECIDE_THREADS threads of the workgroup (two barriers).  Every caller -- k_decide, k_trial_scalars, the prologue of
+// k_schur_fused_bf3 -- gathers with the same stride and folds in the same order, so they produce the same bits from the same
+// partials.  (Wave-level shuffles of doubles -- two ds_bpermute per step and value, six steps, five values -- took 4.2k cycles.)
+constexpr int DECIDE_THREADS = 512;
+__device__ inline void decide_fold(const DecidePartials& p, double* __restrict__ scr /* LDS, 5 x DECIDE_THREADS doubles */, double (&out)[5]) {
+  __shared__ double s_red[5];
+  constexpr int nt = DECIDE_THREADS;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  scr[tid] = p.a; scr[nt + tid] = p.b; scr[2 * nt + tid] = p.c; scr[3 * nt + tid] = p.d; scr[4 * nt + tid] = p.g;
+  __syncthreads();
+  if (wv < 5) {
+    double* a = scr + wv * nt;
+    const bool mx = wv == 4;
+    double v = 0;
+#pragma unroll
+    for (int j = 0; j < nt / 64; ++j) { const double x = a[lane + 64 * j]; v = mx ? fmax(v, x) : v + x; }
+    a[lane] = v;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 8) {
+      double u = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const double x = a[lane * 8 + j]; u = mx ? fmax(u, x) : u + x; }
+      a[lane * 8] = u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      double u = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const double x = a[j * 8]; u = mx ? fmax(u, x) : u + x; }
+      s_red[wv] = u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out[k] = s_red[k];
+  }
+}
+
 __device__ inline bool decide_core(LMState* st, const DecidePartials& p, const double* __restrict__ scal_all, int n_ranks,
-                                   LMLogRow* row, int log_cap) {
+                                   LMLogRow* row, int log_cap, double* __restrict__ scr /* LDS scratch, 5 x DECIDE_THREADS doubles */,
+                                   long long* dbgp = nullptr /* diagnostic cycle stamps */) {
   double cost_new = 0, pred = 0, dx2 = 0, x2 = 0, gmax = 0, failv = 0;
   if (scal_all == nullptr) {
-    // one LDS exchange for all five reductions
-    __shared__ double s_red[5][16];
-    const double a = wave_sum(p.a), b = wave_sum(p.b), c = wave_sum(p.c), d = wave_sum(p.d), g = wave_max(p.g);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (lane == 0) { s_red[0][wid] = a; s_red[1][wid] = b; s_red[2][wid] = c; s_red[3][wid] = d; s_red[4][wid] = g; }
-    __syncthreads();
-    if (threadIdx.x == 0)
-      for (int i = 0; i < nw; ++i) { cost_new += s_red[0][i]; pred += s_red[1][i]; dx2 += s_red[2][i]; x2 += s_red[3][i]; gmax = fmax(gmax, s_red[4][i]); }
+    double f5[5] = {0, 0, 0, 0, 0};
+    decide_fold(p, scr, f5);
+    cost_new = f5[0]; pred = f5[1]; dx2 = f5[2]; x2 = f5[3]; gmax = f5[4];
     failv = (double)st->chol_fail;
   }
   if (threadIdx.x != 0) return false;
+  if (dbgp) dbgp[0] = clock64();
+  // thread 0 works on a register copy of the record: as a chain of dependent LDS reads and writes the same logic took 6.5k cycles
+  LMState* const st_lds = st;
+  LMState L = *st_lds;
+  st = &L;
   if (scal_all != nullptr) {
     for (int r = 0; r < n_ranks; ++r) {
       const double* s = scal_all + (size_t)r * NSCAL;
@@ -186,6 +228,8 @@ __device__ inline bool decide_core(LMState* st, const DecidePartials& p, const d
   st->status = status;
   row->iteration = st->iter; row->accepted = accepted; row->nfev = st->nfev; row->cost = st->cost;
   row->cost_reduction = actual; row->step_norm = st->step_norm; row->optimality = gmax; row->lambda = st->lam; row->rho = rho;
+  *st_lds = L;
+  if (dbgp) dbgp[1] = clock64();
   return st->iter <= log_cap;
 }
 __device__ inline double block_max(double v, double* scratch) {
@@ -1685,21 +1729,32 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
       uint4* z4 = reinterpret_cast<uint4*>(smem);
       for (int i = threadIdx.x; i < 2 * Cfg::BUF_BYTES / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
     }
+    // pin the partial sums in front of the barrier: left alone, LLVM sinks their loads into the conditional block that uses them
+    // (behind the barrier), which put a whole memory round trip (4k cycles) back between the record's arrival and the decision
+    asm volatile("" : "+v"(dp.a), "+v"(dp.b), "+v"(dp.c), "+v"(dp.d), "+v"(dp.g));
     if (stamp_wg && threadIdx.x == 0) dbg[54] = clock64();
     __syncthreads();
     if (stamp_wg && threadIdx.x == 0) dbg[55] = clock64();
     if (fd.do_decide) {
       const bool running = s_st.status < 0;                 // uniform; a finished solve only has its record carried over
       bool have_row = false;
-      if (running) have_row = decide_core(&s_st, dp, fd.scal_all, fd.n_ranks, &s_row, fd.log_cap);
+      static_assert(THREADS == DECIDE_THREADS, "decide_fold is written for the thread count of this kernel");
+      // scratch of the reductions: the first 20 KB of the (zeroed, still unused) panel buffers, cleared again afterwards
+      if (running) have_row = decide_core(&s_st, dp, fd.scal_all, fd.n_ranks, &s_row, fd.log_cap, reinterpret_cast<double*>(smem),
+                                          stamp_wg ? dbg + 58 : nullptr);
       if (threadIdx.x == 0) s_have_row = have_row ? 1 : 0;
       __syncthreads();
+      if (running && fd.scal_all == nullptr) {
+        uint4* z4 = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < 5 * THREADS * (int)sizeof(double) / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
+      }
       if (blockIdx.x == 0) {
         if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(fd.st_out)[threadIdx.x] = reinterpret_cast<const int*>(&s_st)[threadIdx.x];
         if (threadIdx.x == 0 && s_have_row && fd.log) fd.log[s_st.iter - 1] = s_row;
       }
     }
   }
+  if (stamp_wg && threadIdx.x == 0) dbg[57] = clock64();
   if (s_st.status >= 0) return;
   const LMState* st = &s_st;
   const int cur_ = ps_cur(ps, st);

@@ -519,19 +519,18 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
   }
 }
 
-// one block: fold the per-block partials into this rank's 8 scalars
-__global__ void k_trial_scalars(const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
-                                int nblk, int n_gmax, const LMState* __restrict__ st, double* __restrict__ scal) {
-  __shared__ double scr[4];
+// one block of DECIDE_THREADS threads: fold the per-block partials into this rank's 8 scalars (same gather, same fold as the decision
+// itself, so a one-rank communicator reproduces the plain loop bit for bit)
+__global__ __launch_bounds__(DECIDE_THREADS) void k_trial_scalars(const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
+                                                                  int nblk, int n_gmax, const LMState* __restrict__ st, double* __restrict__ scal) {
+  __shared__ double s_scr[5 * DECIDE_THREADS];
   if (st->status >= 0) return;
-  double a = 0, b = 0, c = 0, d = 0, g = 0;
-  for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
-    a += trial_part[i]; b += trial_part[nblk + i]; c += trial_part[2 * nblk + i]; d += trial_part[3 * nblk + i];
-  }
-  for (int i = threadIdx.x; i < n_gmax; i += blockDim.x) g = fmax(g, gmax_part[i]);
-  a = block_sum(a, scr); b = block_sum(b, scr); c = block_sum(c, scr); d = block_sum(d, scr); g = block_max(g, scr);
+  DecidePartials dp;
+  decide_gather(dp, nullptr, trial_part, gmax_part, nblk, n_gmax);
+  double f5[5] = {0, 0, 0, 0, 0};
+  decide_fold(dp, s_scr, f5);
   if (threadIdx.x == 0) {
-    scal[0] = a; scal[1] = b; scal[2] = c; scal[3] = d; scal[4] = g; scal[5] = (double)st->chol_fail;
+    scal[0] = f5[0]; scal[1] = f5[1]; scal[2] = f5[2]; scal[3] = f5[3]; scal[4] = f5[4]; scal[5] = (double)st->chol_fail;
     scal[6] = 0; scal[7] = 0;
   }
 }
@@ -654,7 +653,7 @@ __global__ void k_lm_reset(double* __restrict__ D2p, size_t n_d2p, double* __res
 // scal_all: n_ranks x 8 scalars (already gathered), or -- single rank -- nullptr, in which case the block folds the
 // per-block partials itself (what k_trial_scalars does for the multi-rank path) and no separate launch is needed.
 template <typename T>
-__global__ __launch_bounds__(1024) void k_decide(LMState* st,
+__global__ __launch_bounds__(DECIDE_THREADS) void k_decide(LMState* st,
                                                 const double* __restrict__ scal_all, int n_ranks,
                                                 const double* __restrict__ trial_part, const double* __restrict__ gmax_part,
                                                 int nblk, int n_gmax /* entries of gmax_part (one per linearisation workgroup) */,
@@ -664,13 +663,14 @@ __global__ __launch_bounds__(1024) void k_decide(LMState* st,
   // sums), thread 0 works on that copy, writes it back with fire-and-forget stores and publishes `status` last.
   __shared__ LMState s_st;
   __shared__ LMLogRow s_row;
+  __shared__ double s_scr[5 * DECIDE_THREADS];
   constexpr int NWORD = sizeof(LMState) / 4;
   DecidePartials dp;
   decide_gather(dp, scal_all, trial_part, gmax_part, nblk, n_gmax);
   if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
   __syncthreads();
   if (s_st.status >= 0) return;
-  const bool have_row = decide_core(&s_st, dp, scal_all, n_ranks, &s_row, log_cap);      // result valid in thread 0
+  const bool have_row = decide_core(&s_st, dp, scal_all, n_ranks, &s_row, log_cap, s_scr);      // result valid in thread 0
   if (threadIdx.x != 0) return;
   if (have_row && log) log[s_st.iter - 1] = s_row;
   {
