@@ -74,15 +74,32 @@ template <> struct Vec2<float> { using type = float2; };
 
 // ------------------------------------------------------------------ small helpers
 __device__ inline double fmax_pos(double d) { return d > 0.0 ? d : 1.0; }   // scale 0 -> 1 (scipy common.py:598-610)
+// Wave-wide sum / maximum of a double, result in every lane.  Inside a row of 16 lanes: four DPP steps (two v_mov_dpp + one f64
+// op each); across the four rows: v_readlane of the row totals and three more operations.  (__shfl_xor on a double is two
+// ds_bpermute_b32 per step and six dependent steps: ~800 cycles per value against ~150.)
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_f64(double v, int src) {          // wave-uniform copy of lane `src` (compile-time constant)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);     // row_half_mirror
+  v += dpp_mov_f64<0x140>(v);     // row_mirror: every lane of a row holds the row total
+  return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
 }
 __device__ inline double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmax(v, dpp_mov_f64<0xB1>(v));
+  v = fmax(v, dpp_mov_f64<0x4E>(v));
+  v = fmax(v, dpp_mov_f64<0x141>(v));
+  v = fmax(v, dpp_mov_f64<0x140>(v));
+  return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
 }
 // block-wide sum of a double; result valid in thread 0.  scratch: >= blockDim/64 doubles of LDS.
 __device__ inline double block_sum(double v, double* scratch) {
