@@ -321,8 +321,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
         double x = 0;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { const int k = part + 4 * kk; x += LinvT[k * CLD + i] * s_y[jb * CB + k]; }
-        x += __shfl_xor(x, 16, 64);
-        x += __shfl_xor(x, 32, 64);
+        x = xrow_sum(x);
         __builtin_amdgcn_wave_barrier();
         if (part == 0) s_y[jb * CB + i] = x;
       }
@@ -368,8 +367,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
         double x = 0;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) { const int i = part + 4 * ii; x += LiT[i] * s_y[b * CB + i]; }
-        x += __shfl_xor(x, 16, 64);
-        x += __shfl_xor(x, 32, 64);
+        x = xrow_sum(x);
         __builtin_amdgcn_wave_barrier();
         if (part == 0) s_y[b * CB + j] = x;
       }
@@ -567,8 +565,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_stream(
       double x = 0;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) { const int k = part + 4 * kk; x += P[k * CLD + i] * s_y[j * CB + k]; }
-      x += __shfl_xor(x, 16, 64);
-      x += __shfl_xor(x, 32, 64);
+      x = xrow_sum(x);
       __builtin_amdgcn_wave_barrier();
       if (part == 0) s_y[j * CB + i] = x;
     }
@@ -621,8 +618,7 @@ __global__ __launch_bounds__(CHOLB_THREADS) void k_cholesky_stream(
         double x = 0;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) { const int i = part + 4 * ii; x += LiT[i] * s_y[b * CB + i]; }
-        x += __shfl_xor(x, 16, 64);
-        x += __shfl_xor(x, 32, 64);
+        x = xrow_sum(x);
         __builtin_amdgcn_wave_barrier();
         if (part == 0) s_y[b * CB + jcol] = x;
       }
