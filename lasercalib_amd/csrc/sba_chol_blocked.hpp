@@ -157,6 +157,37 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   // of the rounding error every entry of S already carries there -- and four dependent f64 operations leave each of the
   // 176 links of the pivot chain.
   constexpr bool PIV_NEWTON = !std::is_same<T, float>::value;
+  // The first block column of the system, the right-hand side and the scalings are requested BEFORE the state record is looked at:
+  // they depend on kernel arguments only, and the record's round trip (the workgroup's first, ~4.7k cycles) would otherwise sit
+  // in front of them.  (A finished solve returns below with these loads in flight: harmless.)
+  const int n = n_sys;           // rows of the system being solved
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const double* rhs = E + (size_t)n * n;
+  const double* dU = rhs + n;
+  const double* gct = dU + n;
+  const bool pair_ok = (n & 1) == 0;
+  constexpr int BPR = CHOLB_LDS_THREADS / 128;                                // blocks of the first column per load round (128 threads each)
+  constexpr int U0 = (CHOLB_MAX_NB + BPR - 1) / BPR;                           // rounds for the first block column
+  double c0[U0][2];
+  const int nlast = n - 1;
+  auto addr = [&](int I, int J) { return E + (size_t)min(I, nlast) * n + min(J, nlast - 1 + (pair_ok ? 0 : 1)); };
+  const int s4 = tid >> 7, ii0 = (tid >> 3) & 15, jp0 = tid & 7;
+  const int tclamp = min(tid, nlast);
+  if (pair_ok) {
+#pragma unroll
+    for (int u = 0; u < U0; ++u) {
+      const double2 t = *reinterpret_cast<const double2*>(addr((BPR * u + s4) * CB + ii0, 2 * jp0));
+      c0[u][0] = t.x; c0[u][1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U0; ++u) {
+      const double* q = addr((BPR * u + s4) * CB + ii0, 2 * jp0);
+      c0[u][0] = q[0]; c0[u][1] = q[(2 * jp0 + 1 < n) ? 1 : 0];
+    }
+  }
+  double in_d = D2c[tclamp], in_u = dU[tclamp], in_r = rhs[tclamp];
+  const double my_g = (tid < n) ? gct[tid] : 0.0;
   if (st->status >= 0) return;
   const int cur_ = ps_cur(ps, st);
   const double* __restrict__ cams = ps.cams[cur_];
@@ -166,7 +197,6 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
 #define CHOL_STAMP() do { if (dbg && threadIdx.x == 0) dbg[nstamp] = clock64(); ++nstamp; } while (0)
   CHOL_STAMP();
   const int ncam = C * NCP;      // camera parameters
-  const int n = n_sys;           // rows of the system being solved
   const int nb = (n + CB - 1) / CB;
   const int n16 = nb * CB;
   const int nblk = nb * (nb + 1) / 2;
@@ -177,16 +207,11 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   __shared__ short s_rc[CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2];   // block index -> (r << 8 | c)
   __shared__ short s_cm[CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2];   // column-major list of the blocks with c >= 1
   __shared__ double s_scr[4][CHOLB_LDS_THREADS / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const double* rhs = E + (size_t)n * n;
-  const double* dU = rhs + n;
-  const double* gct = dU + n;
   const double lam = st->lam;
   const bool fresh = st->fresh != 0;
   // operands of the epilogue, requested now so that their latency is hidden behind the factorisation
   const double my_cam = (tid < ncam) ? cams[tid] : 0.0;                       // camera parameter tid
   const double my_xs = (tid < n) ? cams[first ? first[tid] : tid] : 0.0;      // system unknown tid (a shared one counts once)
-  const double my_g = (tid < n) ? gct[tid] : 0.0;
 
   if (tid < nblk) {
     int r = 0;
@@ -207,29 +232,16 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   // The padded tail is the identity.
   // All loads are unconditional (out-of-range ones are clamped to a valid address and replaced afterwards) and sit in
   // straight-line code: only then can the compiler wait with vmcnt(N) for the first block column alone.
-  const bool pair_ok = (n & 1) == 0;
-  constexpr int BPR = CHOLB_LDS_THREADS / 128;                                // blocks of the first column per load round (128 threads each)
-  constexpr int U0 = (CHOLB_MAX_NB + BPR - 1) / BPR;                           // rounds for the first block column
   constexpr int NREM = CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2;                  // 55 other blocks
   constexpr int TREM = CHOLB_LDS_THREADS - 64;                                     // loaded by waves 1..7
   constexpr int U1 = (NREM * 128 + TREM - 1) / TREM;                           // 16 rounds
-  double c0[U0][2], c1[U1][2];
-  const int nlast = n - 1;
-  auto addr = [&](int I, int J) { return E + (size_t)min(I, nlast) * n + min(J, nlast - 1 + (pair_ok ? 0 : 1)); };
+  double c1[U1][2];
   auto fix = [&](int I, int J, double& v0, double& v1) {       // padded tail = identity
     if (I >= n || J >= n) v0 = (I == J) ? 1.0 : 0.0;
     if (I >= n || J + 1 >= n) v1 = (I == J + 1) ? 1.0 : 0.0;
   };
-  const int s4 = tid >> 7, ii0 = (tid >> 3) & 15, jp0 = tid & 7;
-  double in_d = 0, in_u = 0, in_r = 0;
-  const int tclamp = min(tid, nlast);
+  // (the first block column, c0, and the rhs / scaling entries were requested at the top of the kernel)
   if (pair_ok) {
-#pragma unroll
-    for (int u = 0; u < U0; ++u) {
-      const double2 t = *reinterpret_cast<const double2*>(addr((BPR * u + s4) * CB + ii0, 2 * jp0));
-      c0[u][0] = t.x; c0[u][1] = t.y;
-    }
-    in_d = D2c[tclamp]; in_u = dU[tclamp]; in_r = rhs[tclamp];
 #pragma unroll
     for (int u = 0; u < U1; ++u) {
       const int e = min(max(tid - 64, 0) + TREM * u, (nblk - nb) * 128 - 1);
@@ -238,12 +250,6 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
       c1[u][0] = t.x; c1[u][1] = t.y;
     }
   } else {
-#pragma unroll
-    for (int u = 0; u < U0; ++u) {
-      const double* q = addr((BPR * u + s4) * CB + ii0, 2 * jp0);
-      c0[u][0] = q[0]; c0[u][1] = q[(2 * jp0 + 1 < n) ? 1 : 0];
-    }
-    in_d = D2c[tclamp]; in_u = dU[tclamp]; in_r = rhs[tclamp];
 #pragma unroll
     for (int u = 0; u < U1; ++u) {
       const int e = min(max(tid - 64, 0) + TREM * u, (nblk - nb) * 128 - 1);
