@@ -40,7 +40,8 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
   // measured slower: 64-byte segments, four times the blocks).  Rows: 16 rows x 64 groups, see below.
   constexpr int EPB = 64, NG = 1024 / EPB, BPT = 256 / EPB;       // entries per block, groups, blocks per tile
   __shared__ double s_p[NG][EPB];
-  if (st->status >= 0) return;
+  // the record is requested now and looked at right before the first write: the slab loads do not wait for its round trip
+  const int st_status = st->status;
   __shared__ double scr[16];
   constexpr int NT = GROUP_TILES * GROUP_TILES;
   const int n = C * NCP;
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     const int ci_ = i / NCP, cj_ = j / NCP;
     s_p[g][l16] = (s0 + s1) + (s2 + s3);
     __syncthreads();
+    if (st_status >= 0) return;
     if (g == 0 && i < n && j < n) {
       double s = 0;
 #pragma unroll
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     }
     s_r[0][gr][lr] = b0; s_r[1][gr][lr] = g0; s_r[2][gr][lr] = d0;
     __syncthreads();
+    if (st_status >= 0) return;
     if (gr == 0 && i < n) {
       double bs = 0, gs = 0, dsv = 0;
 #pragma unroll 8
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
   double s = 0;
   for (int i = threadIdx.x; i < n_cost_part; i += blockDim.x) s += cost_part[i];
   s = block_sum(s, scr);
+  if (st_status >= 0) return;
   if (threadIdx.x == 0) {
     E[(size_t)n * n + 3 * n] = s;
     if (Pk) Pk[exch_packed_size(n) - 1] = s;
@@ -544,19 +548,22 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
     const ParamSets<T> ps, int C, const typename Vec2<T>::type* __restrict__ uv /* observation (p, c) at p*C + c */,
     const T* __restrict__ w, int N, const T* __restrict__ pf, const double* __restrict__ gp, const double* __restrict__ D2p,
     const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ trial_part, int nparts) {
-  __shared__ T s_cam[GROUP_CAMS * CAMPRE], s_camn[GROUP_CAMS * CAMPRE], s_dc[GROUP_CAMS * NCP];
+  __shared__ T s_cam01[2][GROUP_CAMS * CAMPRE], s_dc[GROUP_CAMS * NCP];
   __shared__ double s_scr[PM_BLOCK / 64];
+  // both camera tables are needed whichever is current: they and the camera step are requested before the state record's round trip
+  stage_campre(ps.campre[0], s_cam01[0], C);
+  stage_campre(ps.campre[1], s_cam01[1], C);
+  for (int i = threadIdx.x; i < C * NCP; i += PM_BLOCK) s_dc[i] = (T)delta_c[i];
   if (st->status >= 0) return;
   const int cur_ = ps_cur(ps, st);
+  const T* s_cam = s_cam01[cur_];
+  const T* s_camn = s_cam01[cur_ ^ 1];
   const double* __restrict__ pts = ps.pts[cur_];
   const T* __restrict__ ptsT = ps.ptsT[cur_];
   double* __restrict__ pts_new = ps.pts[cur_ ^ 1];
   T* __restrict__ ptsT_new = ps.ptsT[cur_ ^ 1];
   const bool free_cams = st->free_cams != 0;
   const double lam = st->lam;
-  stage_campre(ps.campre[cur_], s_cam, C);
-  stage_campre(ps.campre[cur_ ^ 1], s_camn, C);
-  for (int i = threadIdx.x; i < C * NCP; i += PM_BLOCK) s_dc[i] = (T)delta_c[i];
   __syncthreads();
   const int q = threadIdx.x >> 4, c = threadIdx.x & 15;
   const bool cam_ok = c < C;
