@@ -188,6 +188,31 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   }
   double in_d = D2c[tclamp], in_u = dU[tclamp], in_r = rhs[tclamp];
   const double my_g = (tid < n) ? gct[tid] : 0.0;
+  // ... and so are the other 55 blocks, column by column (waves 1..7; the factorisation of the first tile does not wait for them).
+  // Block k of that list sits in column cc, row cc + (k - base); k grows with the load round, so the search continues where it was.
+  constexpr int NREM = CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2;                  // 55 other blocks
+  constexpr int TREM = CHOLB_LDS_THREADS - 64;                                     // loaded by waves 1..7
+  constexpr int U1 = (NREM * 128 + TREM - 1) / TREM;                           // 16 rounds
+  double c1[U1][2];
+  {
+    const int nb_ = (n + CB - 1) / CB;
+    const int last = (nb_ * (nb_ + 1) / 2 - nb_) * 128 - 1;
+    int cc = 1, base = 0;
+#pragma unroll
+    for (int u = 0; u < U1; ++u) {
+      const int e = min(max(tid - 64, 0) + TREM * u, last);
+      const int k = e >> 7;
+      while (k >= base + (nb_ - cc) && cc < nb_) { base += nb_ - cc; ++cc; }
+      const int I = (cc + (k - base)) * CB + ((e >> 3) & 15), J = cc * CB + 2 * (e & 7);
+      if (pair_ok) {
+        const double2 t = *reinterpret_cast<const double2*>(addr(I, J));
+        c1[u][0] = t.x; c1[u][1] = t.y;
+      } else {
+        const double* q = addr(I, J);
+        c1[u][0] = q[0]; c1[u][1] = q[(J + 1 < n) ? 1 : 0];
+      }
+    }
+  }
   if (st->status >= 0) return;
   const int cur_ = ps_cur(ps, st);
   const double* __restrict__ cams = ps.cams[cur_];
@@ -232,33 +257,11 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   // The padded tail is the identity.
   // All loads are unconditional (out-of-range ones are clamped to a valid address and replaced afterwards) and sit in
   // straight-line code: only then can the compiler wait with vmcnt(N) for the first block column alone.
-  constexpr int NREM = CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2;                  // 55 other blocks
-  constexpr int TREM = CHOLB_LDS_THREADS - 64;                                     // loaded by waves 1..7
-  constexpr int U1 = (NREM * 128 + TREM - 1) / TREM;                           // 16 rounds
-  double c1[U1][2];
   auto fix = [&](int I, int J, double& v0, double& v1) {       // padded tail = identity
     if (I >= n || J >= n) v0 = (I == J) ? 1.0 : 0.0;
     if (I >= n || J + 1 >= n) v1 = (I == J + 1) ? 1.0 : 0.0;
   };
-  // (the first block column, c0, and the rhs / scaling entries were requested at the top of the kernel)
-  if (pair_ok) {
-#pragma unroll
-    for (int u = 0; u < U1; ++u) {
-      const int e = min(max(tid - 64, 0) + TREM * u, (nblk - nb) * 128 - 1);
-      const int rc = s_cm[e >> 7];
-      const double2 t = *reinterpret_cast<const double2*>(addr((rc >> 8) * CB + ((e >> 3) & 15), (rc & 255) * CB + 2 * (e & 7)));
-      c1[u][0] = t.x; c1[u][1] = t.y;
-    }
-  } else {
-#pragma unroll
-    for (int u = 0; u < U1; ++u) {
-      const int e = min(max(tid - 64, 0) + TREM * u, (nblk - nb) * 128 - 1);
-      const int rc = s_cm[e >> 7];
-      const int J = (rc & 255) * CB + 2 * (e & 7);
-      const double* q = addr((rc >> 8) * CB + ((e >> 3) & 15), J);
-      c1[u][0] = q[0]; c1[u][1] = q[(J + 1 < n) ? 1 : 0];
-    }
-  }
+  // (c0, c1 and the rhs / scaling entries were requested at the top of the kernel)
 #pragma unroll
   for (int u = 0; u < U0; ++u) fix((BPR * u + s4) * CB + ii0, 2 * jp0, c0[u][0], c0[u][1]);
   // camera scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
