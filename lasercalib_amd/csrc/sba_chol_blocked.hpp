@@ -194,6 +194,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   constexpr int TREM = CHOLB_LDS_THREADS - 64;                                     // loaded by waves 1..7
   constexpr int U1 = (NREM * 128 + TREM - 1) / TREM;                           // 16 rounds
   double c1[U1][2];
+  int rc1[U1];                     // (row << 8) | column of the round's block: the LDS stores below use it without a table lookup
   {
     const int nb_ = (n + CB - 1) / CB;
     const int last = (nb_ * (nb_ + 1) / 2 - nb_) * 128 - 1;
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
       const int e = min(max(tid - 64, 0) + TREM * u, last);
       const int k = e >> 7;
       while (k >= base + (nb_ - cc) && cc < nb_) { base += nb_ - cc; ++cc; }
+      rc1[u] = ((cc + (k - base)) << 8) | cc;
       const int I = (cc + (k - base)) * CB + ((e >> 3) & 15), J = cc * CB + 2 * (e & 7);
       if (pair_ok) {
         const double2 t = *reinterpret_cast<const double2*>(addr(I, J));
@@ -297,12 +299,20 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     for (int u = 0; u < U1; ++u) {
       const int e = (tid - 64) + TREM * u;
       if (e < (nblk - nb) * 128) {
-        const int rc = s_cm[e >> 7];
-        const int ii = (e >> 3) & 15, I = (rc >> 8) * CB + ii, J = (rc & 255) * CB + 2 * (e & 7);
-        double* dst = Lb + cb_off(rc >> 8, rc & 255) + ii * CLD + 2 * (e & 7);
+        // (row, column) from the load loop's registers: as a table lookup in LDS in front of every store, sixteen dependent
+        // LDS round trips per thread made this phase 9k cycles, twice the first tile's factorisation it runs beside
+        const int rc = rc1[u];
+        const int br = rc >> 8, bc = rc & 255;
+        const int ii = (e >> 3) & 15, I = br * CB + ii, J = bc * CB + 2 * (e & 7);
+        double* dst = Lb + cb_off(br, bc) + ii * CLD + 2 * (e & 7);
         fix(I, J, c1[u][0], c1[u][1]);
-        dst[0] = c1[u][0] + ((I == J && I < n) ? s_d[I] : 0.0);
-        dst[1] = c1[u][1] + ((I == J + 1 && I < n) ? s_d[I] : 0.0);
+        double d0 = 0.0, d1 = 0.0;
+        if (br == bc) {              // only a diagonal block carries damping (uniform for the 128 threads of a block)
+          d0 = (I == J && I < n) ? s_d[I] : 0.0;
+          d1 = (I == J + 1 && I < n) ? s_d[I] : 0.0;
+        }
+        dst[0] = c1[u][0] + d0;
+        dst[1] = c1[u][1] + d1;
       }
     }
   }
