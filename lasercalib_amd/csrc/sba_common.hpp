@@ -100,6 +100,7 @@ struct HostRes {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;   // for a large read-back that may run beside kernels of the main stream
   hipEvent_t ev[2 + 12] = {};
+  hipEvent_t ev_wait = nullptr;        // busy-poll event of Engine::sync_spin (no timing)
   void* pinned = nullptr;            // PINNED_BYTES of pinned host memory: 1 KB LM state mirror + a landing area for small device-to-host copies
   static constexpr size_t PINNED_BYTES = 64 * 1024, PINNED_STATE_BYTES = 1024;
   int device = 0;
@@ -118,6 +119,7 @@ struct HostResPool {
     std::lock_guard<std::mutex> lk(mu);
     if (free_res.size() < 8) { free_res.push_back(r); return; }
     for (auto e : r.ev) if (e) (void)hipEventDestroy(e);
+    if (r.ev_wait) (void)hipEventDestroy(r.ev_wait);
     if (r.stream) (void)hipStreamDestroy(r.stream);
     if (r.copy_stream) (void)hipStreamDestroy(r.copy_stream);
     if (r.pinned) (void)hipHostFree(r.pinned);
