@@ -1700,8 +1700,10 @@ struct SchurBf3Cfg {
   static constexpr int PLANE = GROUP_ROWS * K;                     // bf16 elements per plane (two half-planes)
   static constexpr int BUF_BYTES = 3 * PLANE * 2;                  // h, m, l
   static constexpr int UPKB = UPK + NCP;                           // per-lane accumulators handed over at the end: U (66) + g (11) + b (11)
+  static constexpr int UPKS = UPKB | 1;                            // their row stride in the hand-over area: odd, so that the 64 lanes of a
+                                                                   // store hit all banks (a stride of 88 floats put them on 4 banks, 16-way)
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES + (size_t)GROUP_CAMS * CAMPRE * sizeof(float);
-  static_assert(2 * (size_t)BUF_BYTES >= (size_t)(NPROD + GROUP_CAMS) * UPKB * sizeof(float), "the accumulator hand-over reuses the panel buffers");
+  static_assert(2 * (size_t)BUF_BYTES >= (size_t)(NPROD + GROUP_CAMS) * UPKS * sizeof(float), "the accumulator hand-over reuses the panel buffers");
 };
 
 // The accept/reject decision of the PREVIOUS trial step can ride in this kernel's prologue (do_decide): every workgroup reads
@@ -1731,7 +1733,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
   extern __shared__ __align__(16) unsigned char smem[];
   using T = float;
   using Cfg = SchurBf3Cfg;
-  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, UPKB = Cfg::UPKB;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, UPKB = Cfg::UPKB, UPKS = Cfg::UPKS;
   const bool stamp_wg = dbg && blockIdx.x == 0;
   if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();
   __shared__ LMState s_st;
@@ -1739,8 +1741,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
   __shared__ int s_have_row;
   __shared__ double s_scr[2][NPROD / 64];
   T* s_cam = reinterpret_cast<T*>(smem + 2 * Cfg::BUF_BYTES);            // [16][CAMPRE]
-  T* s_U = reinterpret_cast<T*>(smem);                                   // [256][UPKB] once the panels are done with
-  T* s_Ured = s_U + NPROD * UPKB;                                        // [C][UPKB]
+  T* s_U = reinterpret_cast<T*>(smem);                                   // [256][UPKS] once the panels are done with
+  T* s_Ured = s_U + NPROD * UPKS;                                        // [C][UPKB]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool producer = threadIdx.x < NPROD;
   int per = (N + ksplit - 1) / ksplit;
@@ -1796,7 +1798,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
       const int c = o / UPKB, k = o - c * UPKB;
       T sum = 0;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) sum += s_U[(q * 16 + c) * UPKB + k];
+      for (int q = 0; q < 16; ++q) sum += s_U[(q * 16 + c) * UPKS + k];
       s_Ured[o] = sum;
     }
   };
@@ -1944,7 +1946,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
     }
     if (stamp_wg && threadIdx.x == 0) dbg[50] = clock64();
     __syncthreads();                       // the consumers have read the last panel: the buffers become the hand-over area
-    static_for<0, UPKB>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * UPKB + k] = Uacc[k]; });
+    static_for<0, UPKB>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * UPKS + k] = Uacc[k]; });
     const double cs = wave_sum((double)sq), gm = wave_max((double)gmx);
     if (lane == 0) { s_scr[0][wid] = cs; s_scr[1][wid] = gm; }
     __syncthreads();
