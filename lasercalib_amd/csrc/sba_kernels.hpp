@@ -90,14 +90,17 @@ __device__ __forceinline__ double lane_f64(double v, int src) {          // wave
 // sum over the four 16-lane rows (lanes l, l^16, l^32, l^48), result in all four: the gfx950 row-swap instructions, two per dword
 // and step, instead of __shfl_xor's ds_bpermute round trips (tools/micro/permlane_swap.hip: 113 vs 189 cycles per dependent sum)
 __device__ __forceinline__ double xrow_sum(double v) {
-  unsigned lo = __double2loint(v), hi = __double2hiint(v);
-  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  const double p = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  lo = __double2loint(p); hi = __double2hiint(p);
-  const auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+  // Written as inline assembly with explicit wait states around every swap: the compiler (ROCm 7.2 clang) does not insert the ones
+  // these instructions need -- 88 swaps generated from the builtins in a row produced wrong sums in k_schur_fused_bf3's hand-over
+  // experiment and right ones with the s_nops; a single sum from the builtins happened to be right here.
+  unsigned lo0 = __double2loint(v), hi0 = __double2hiint(v), lo1 = lo0, hi1 = hi0;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
+               : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
+  const double p = __hiloint2double(hi0, lo0) + __hiloint2double(hi1, lo1);
+  lo0 = __double2loint(p); hi0 = __double2hiint(p); lo1 = lo0; hi1 = hi0;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1"
+               : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
+  return __hiloint2double(hi0, lo0) + __hiloint2double(hi1, lo1);
 }
 __device__ inline double wave_sum(double v) {
   v += dpp_mov_f64<0xB1>(v);      // quad_perm [1,0,3,2]
