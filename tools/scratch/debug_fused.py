@@ -1,6 +1,6 @@
 """Per-iteration costs of the fused bf16x3 kernel vs the f32-MFMA fused kernel vs fp64 on a small one-group rig."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig
 C, N = int(sys.argv[1]), int(sys.argv[2])

@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig
 for C, N in ((16, 500), (16, 512), (16, 1024), (16, 4096), (16, 8192)):

@@ -1,6 +1,6 @@
 """Per-iteration costs of a multi-group fp32 solve: diagonal pairs on the bf16 pipe vs f32-input MFMAs vs the fp64 engine."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig
 C, N, vis = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])

@@ -1,6 +1,6 @@
 """One-rank RCCL loop vs plain loop, iteration by iteration (multi-group fp32)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig

@@ -1,6 +1,6 @@
 """Where does an LM iteration's time go at a large camera count?  Phase API with a stream sync (lm_poll) after each phase."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig

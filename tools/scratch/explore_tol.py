@@ -1,6 +1,6 @@
 """Exploration for test tolerances (prints measured values)."""
 import sys, os, io, contextlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig

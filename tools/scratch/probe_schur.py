@@ -1,6 +1,6 @@
 """Debug probe: compare the device exchange buffer [S|rhs|diagU|gc|cost] with the numpy model."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig

@@ -1,6 +1,6 @@
 """Quick per-kernel timing at BASELINE config 3 (16 cams x 50k points)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig
