@@ -1,0 +1,83 @@
+"""GPU: what a caller of the drop-in class gets back, checked through this repo's own API.
+
+The reference's caller (scripts/calibrate_camera.py) cannot run where a GPU is; this test does not restate it.  It feeds
+the product functions that stand either side of ``PySBA.bundleAdjust`` -- ``dataset.concatenate_datasets``,
+``convert_params.initialize_from_checkerboard`` / ``camera_array_to_readable`` / ``readable_to_red_format``,
+``report.*`` -- and checks their results against the reference-generated fixtures F6 (conversions of the 17 shipped example
+cameras) and against the oracle, plus the properties a downstream reader relies on: pickles under the reference's module
+path, the '%f' red table, positional call shapes of the class.
+"""
+import os
+import pickle as pkl
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from lasercalib import convert_params as shim  # noqa: E402  (the import path a caller uses)
+from lasercalib.pySBA import PySBA  # noqa: E402
+from lasercalib_amd import _native, convert_params as cp, dataset as ds, report  # noqa: E402
+from oracle import io_oracle, sba_oracle as orc  # noqa: E402
+from test_gpu_workflow import _example_problem  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def f6():
+    return np.load(os.path.join(GOLD, "f6_convert.npz"))
+
+
+def test_inputs_from_files_match_reference_fixtures(tmp_path, f6):
+    """YAML files -> cameraArray -> readable -> red: every stage equals the reference-generated F6 values bit for bit."""
+    names = [str(n) for n in f6["names"]]
+    for i, name in enumerate(names):
+        cp.write_opencv_yaml(os.path.join(tmp_path, name + ".yaml"),
+                             {"camera_matrix": f6["K"][i], "distortion_coefficients": f6["dist"][i], "rc_ext": f6["R"][i], "tc_ext": f6["T"][i]})
+    cams = shim.initialize_from_checkerboard(str(tmp_path), len(names), names)
+    assert np.array_equal(cams, f6["example_cameraArray"])
+    readable = cp.camera_array_to_readable(cams)
+    rows = [int(np.nonzero(np.all(f6["cameraArray"] == cams[i], axis=1))[0][0]) for i in range(len(names))]
+    assert all(np.array_equal(readable[i]["K"], f6["readable_K"][k]) and np.array_equal(readable[i]["R"], f6["readable_R"][k])
+               for i, k in enumerate(rows))
+    assert np.array_equal(shim.readable_to_red_format(readable), f6["red"][rows])
+
+
+def test_solve_and_exports_on_the_example_rig(tmp_path, capsys):
+    assert _native.device_count() > 0
+    P = _example_problem(seed=3, n_frames=(500, 400))
+    # the stacked inputs come from the product's concatenation (pinned by F7 in tests/test_dataset_convert.py)
+    n_cams, p3, p2, ci, pi = ds.concatenate_datasets(P["sets"])
+    assert n_cams == 17 and np.array_equal(pi, P["pi"]) and ds.is_point_major(pi)
+    sba = PySBA(P["cams0"], p3, p2, ci, pi)                       # positional, five arguments
+    assert sba.cameraArray.shape == (17, 11) and sba.pointWeights.shape == (ci.size, 1)
+    err0 = report.reprojection_errors(sba)                        # device project kernel
+    assert np.max(np.abs(err0 - io_oracle.reprojection_errors(orc.project, p3, P["cams0"], p2, ci, pi))) <= 1e-7
+    assert report.camera_extrinsics(sba).shape == (17, 6)
+    assert sba.bundleAdjust(1e-4) is not None                     # callers ignore the return value; it is scipy-shaped anyway
+    out = capsys.readouterr().out
+    assert "`ftol` termination condition is satisfied." in out or "`xtol`" in out
+    ref, _, _ = orc.bundle_adjust(P["cams0"], p3, p2, ci, pi, ftol=1e-4)
+    cost = 0.5 * np.sum(orc.fun(np.hstack((sba.cameraArray.ravel(), sba.points3D.ravel())), 17, p3.shape[0], ci, pi, p2, 1.0) ** 2)
+    # both solvers stop on ftol = 1e-4 (relative cost decrease per step): they end within a fraction of that of each other
+    assert abs(cost - ref.cost) <= 5e-5 * ref.cost
+    assert abs(orc.rms_reprojection(sba.cameraArray, sba.points3D, p2, ci, pi) - np.sqrt(2 * ref.cost / ci.size)) <= 1e-4
+    # exports: conversion of the optimised cameras = the pinned restatement (F6), red table survives '%f', pickles keep the module path
+    readable = cp.camera_array_to_readable(sba.cameraArray)
+    red = cp.readable_to_red_format(readable)
+    for i in range(17):
+        want = io_oracle.readable_from_row(sba.cameraArray[i])
+        assert all(np.array_equal(readable[i][k], want[k]) for k in ("K", "R", "t", "d"))
+        assert np.array_equal(red[i], io_oracle.red_row(want))
+    path = os.path.join(tmp_path, "red.csv")
+    np.savetxt(path, red, delimiter=",", newline=",\n", fmt="%f")
+    lines = open(path).read().strip().split("\n")
+    back = np.array([[float(v) for v in ln.rstrip(",").split(",")] for ln in lines])
+    assert back.shape == (17, 25) and np.max(np.abs(back - red)) <= 5e-7
+    blob = pkl.dumps(sba)
+    sba2 = pkl.loads(blob)
+    assert type(sba2).__module__ == "lasercalib.pySBA"
+    assert np.array_equal(sba2.cameraArray, sba.cameraArray) and np.array_equal(sba2.points3D, sba.points3D)
+    assert np.array_equal(sba2.pointWeights, sba.pointWeights)
+    assert np.array_equal(pkl.loads(pkl.dumps(readable))[3]["K"], readable[3]["K"])
