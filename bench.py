@@ -146,8 +146,10 @@ def main():
     phase_api = rehearsal or bool(os.environ.get("SBA_BENCH_PHASE_API"))
     comm_note = None
     if world > 1 and not rehearsal:
-        # the library's own RCCL communicator; should binding or initialising it fail on ANY rank, every rank falls back to the
-        # phase-API loop with torch.distributed collectives (slower, but the run still measures the sharded solve) and says so
+        # the library's own RCCL communicator; should binding or initialising it fail on EVERY rank alike (library missing,
+        # version mismatch: symmetric failures), every rank falls back to the phase-API loop with torch.distributed collectives
+        # (slower, but the run still measures the sharded solve) and says so.  A ONE-SIDED failure inside sba_comm_init cannot
+        # be rescued here: the other ranks are inside ncclCommInitRank by then and only RCCL's own timeout ends that.
         failed = 0
         try:
             ids = [_native.comm_unique_id() if rank == 0 else None]

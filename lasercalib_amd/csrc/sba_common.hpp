@@ -19,6 +19,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>     // types and enum values only: the library itself is bound with dlopen (Rccl below), never linked
 
 namespace sba_host {
 
@@ -168,24 +169,29 @@ void par_for(int64_t n, F&& f /* (lo, hi, thread) */) {
 // these on the engine's own stream: one ncclAllReduce (reduced camera system, upper triangle) and one ncclAllGather
 // (8 scalars per rank) per LM trial -- SURVEY 8(e); torch.distributed is not involved in a step.
 struct Rccl {
-  static constexpr int ID_BYTES = 128;             // NCCL_UNIQUE_ID_BYTES
-  struct UniqueId { char internal[ID_BYTES]; };
+  static constexpr int ID_BYTES = NCCL_UNIQUE_ID_BYTES;
+  using UniqueId = ncclUniqueId;
   using comm_t = void*;
-  enum { kFloat64 = 8 };                           // ncclDataType_t: ncclFloat64
-  enum { kSum = 0, kMax = 2 };                     // ncclRedOp_t
+  // enum values from the header this library was compiled against; load() checks that the library found at run time is of the
+  // same major version, i.e. that they mean the same thing there
+  enum { kFloat64 = (int)ncclFloat64 };
+  enum { kSum = (int)ncclSum, kMax = (int)ncclMax };
   int (*get_unique_id)(UniqueId*) = nullptr;
   int (*comm_init_rank)(comm_t*, int, UniqueId, int) = nullptr;
   int (*comm_destroy)(comm_t) = nullptr;
   int (*all_reduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
   int (*all_gather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
+  int (*get_version)(int*) = nullptr;
   const char* (*error_string)(int) = nullptr;
   bool ok = false;
+  int version = 0;
   std::string why;
   static Rccl& get() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+    static Rccl r = load();        // C++11 magic static: initialised once, other threads wait for it
+    return r;
+  }
+  static Rccl load() {
+    Rccl r;
     // a copy the process already holds (PyTorch-ROCm bundles its own librccl.so) is reused; otherwise the system library
     void* lib = nullptr;
     for (const char* name : {"librccl.so", "librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }
@@ -200,9 +206,15 @@ struct Rccl {
     r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
     r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(lib, "ncclAllReduce"));
     r.all_gather = reinterpret_cast<decltype(r.all_gather)>(dlsym(lib, "ncclAllGather"));
+    r.get_version = reinterpret_cast<decltype(r.get_version)>(dlsym(lib, "ncclGetVersion"));
     r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(lib, "ncclGetErrorString"));
-    r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_reduce && r.all_gather && r.error_string;
-    if (!r.ok) r.why = "librccl.so lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclAllGather";
+    r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_reduce && r.all_gather && r.error_string && r.get_version;
+    if (!r.ok) { r.why = "librccl.so lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclAllGather / ncclGetVersion"; return r; }
+    if (r.get_version(&r.version) != 0 || r.version / 10000 != NCCL_MAJOR) {
+      r.ok = false;
+      r.why = "librccl.so reports version " + std::to_string(r.version) + ", this library was built against the NCCL " +
+              std::to_string(NCCL_MAJOR) + ".x API (rccl.h " + std::to_string(NCCL_VERSION_CODE) + ")";
+    }
     return r;
   }
 };

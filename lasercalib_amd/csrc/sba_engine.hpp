@@ -503,7 +503,7 @@ struct Engine : EngineBase {
   void push_ptrs() {                 // (re)build the by-value kernel argument for the host's notion of `cur`
     for (int b = 0; b < 2; ++b) { psets.cams[b] = cams[b].p; psets.pts[b] = pts[b].p; psets.ptsT[b] = ptsT[b].p; psets.campre[b] = campre[b].p; }
     psets.base = cur;
-    psets.loss_delta = (float)loss_delta;
+    psets.loss_delta = (T)loss_delta;
     psets.fixed = has_fixed ? pt_fixed_mask.p : nullptr;
   }
   // argument for launches inside the LM loop (side = base ^ LMState::cur) ...
@@ -844,7 +844,10 @@ struct Engine : EngineBase {
     memcpy(uid.internal, id, Rccl::ID_BYTES);
     RCCLCHK(r.comm_init_rank(&comm, n_ranks, uid, rank));
     comm_rank = rank; comm_n = n_ranks;
-    sc_loc.alloc(NSCAL); sc_all.alloc((size_t)NSCAL * n_ranks); comm_tmp.alloc(std::max(n, 1) + 8);
+    // (a handle may be given a new communicator: the bump arena never returns memory, so only grow)
+    if (sc_loc.n < (size_t)NSCAL) sc_loc.alloc(NSCAL);
+    if (sc_all.n < (size_t)NSCAL * n_ranks) sc_all.alloc((size_t)NSCAL * n_ranks);
+    if (comm_tmp.n < (size_t)std::max(n, 1) + 8) comm_tmp.alloc(std::max(n, 1) + 8);
     if (!h_comm) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_comm), sizeof(double) * (std::max(n, 1) + 8), hipHostMallocDefault));
     return SBA_OK;
   }
@@ -875,15 +878,27 @@ struct Engine : EngineBase {
     if (opts.mode == SBA_MODE_SHARED_INTR) build_tie_tables();
     // initial cost; scipy raises ValueError when it is not finite (least_squares.py:844-845)
     double c0 = 0;
-    int rc = residual(nullptr, nullptr, &c0);
-    if (rc) return rc;
+    int rc = SBA_OK;
+    if (comm && sq_mode() && comm_n > 1) { err = "the squared-error variants (camonly, transform_points_3d) run on one GPU only"; return SBA_ERR_UNSUPPORTED; }  // (same on every rank)
+    // With a communicator a failure on THIS rank must not keep it out of the collective its peers are about to enter: the
+    // failure travels as a flag inside that all-reduce and every rank returns an error together.
+    try { rc = residual(nullptr, nullptr, &c0); }
+    catch (const HipError& e) {
+      if (!comm) throw;
+      err = std::string("HIP error in lm_begin: ") + hipGetErrorString(e.e) + " (" + e.what + ")";
+      rc = SBA_ERR_HIP;
+    }
+    if (rc && !comm) return rc;
     N_global = N;
     if (comm) {
-      if (sq_mode() && comm_n > 1) { err = "the squared-error variants (camonly, transform_points_3d) run on one GPU only"; return SBA_ERR_UNSUPPORTED; }
       // every rank must see the same initial cost (a non-finite one on ANY rank fails the solve on ALL of them, before the
       // first collective of the loop) and the same default evaluation budget, 100 x the GLOBAL number of parameters
-      double v[2] = {c0, (double)N};
-      comm_sum(v, 2);
+      double v[3] = {rc ? 0.0 : c0, (double)N, rc ? 1.0 : 0.0};
+      comm_sum(v, 3);
+      if (v[2] > 0) {
+        if (!rc) { err = "lm_begin failed on " + std::to_string((int)(v[2] + 0.5)) + " peer rank(s)"; rc = SBA_ERR_STATE; }
+        return rc;
+      }
       c0 = v[0];
       N_global = (long long)(v[1] + 0.5);
     }
@@ -1282,7 +1297,10 @@ struct Engine : EngineBase {
       // solve has terminated, and a rejected step skips its re-linearization on the device, not on the host
       // (profiling: one event pair per kernel class, read at every poll.  Two iterations per poll, so that the pairs time the
       //  SECOND one, whose fused kernel carries the previous step's decision in its prologue like every iteration of a normal batch)
-      const int pbatch = bf3_path() && defer_decide ? 2 : 1;
+      // With a communicator the number of iterations (= collectives) enqueued per poll must not depend on anything rank-local
+      // (bf3_path() follows the shard's own visibility density): a rank that enqueues one more all-reduce than its peers after
+      // the device-side termination waits for it forever.
+      const int pbatch = comm ? 2 : (bf3_path() && defer_decide ? 2 : 1);
       int batch = prof_on ? pbatch : BATCH;
       if (o->max_iter > 0) batch = std::min(std::max(1, o->max_iter - iters), prof_on ? pbatch : 64);
       for (int b = 0; b < batch; ++b) {

@@ -40,7 +40,7 @@ constexpr int NSCAL = 8;
 template <typename T> struct ParamSets {
   double* cams[2]; double* pts[2]; T* ptsT[2]; T* campre[2];
   int base;
-  float loss_delta;                 // > 0: Huber loss with this f_scale on every residual component (sba_set_robust_loss); 0: linear
+  T loss_delta;                     // (the engine's real type: the same rounded value everywhere, launch_residual included) > 0: Huber loss with this f_scale on every residual component (sba_set_robust_loss); 0: linear
   const unsigned char* fixed;       // per point: 1 = held fixed (gauge anchor, sba_set_fixed_points); NULL: every point is free
 };
 template <typename T> __device__ inline bool pt_fixed(const ParamSets<T>& ps, size_t p) { return ps.fixed != nullptr && ps.fixed[p] != 0; }

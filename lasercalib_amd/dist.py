@@ -269,13 +269,34 @@ def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device,
     use_rccl = os.environ.get("LASERCALIB_SBA_COMM", "rccl" if comm.d.get_backend() == "nccl" else "torch") == "rccl"
     if use_rccl:
         # the library owns the collectives: hand it a communicator and make ONE call
-        ids = [_native.comm_unique_id() if comm.r == 0 else None]
+        ids = [None]
+        if comm.r == 0:
+            try:
+                ids = [_native.comm_unique_id()]
+            except Exception as e:      # noqa: BLE001  (RCCL missing / wrong version: the peers are waiting for the broadcast)
+                ids = [("error", f"{type(e).__name__}: {e}")]
         comm.d.broadcast_object_list(ids, src=0)
-        prob = _native.Problem(cams, shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], weights=shard["w"],
-                               dtype=dtype, device=device)
+        if isinstance(ids[0], tuple):
+            raise ValueError(f"sba_comm_get_unique_id failed on rank 0: {ids[0][1]}")
+        # Everything that can fail on ONE rank (allocation, upload, a bad mask) happens before the first collective the
+        # library enters (ncclCommInitRank), and the outcome is agreed over the torch group first: a rank that raised would
+        # otherwise leave its peers blocked inside RCCL.  What this cannot cover is a failure inside ncclCommInitRank itself
+        # (the peers are already in it) -- RCCL's own timeout is the only way out of that one.
+        prob, local_err = None, None
         try:
+            prob = _native.Problem(cams, shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], weights=shard["w"],
+                                   dtype=dtype, device=device)
             fm = sba._fixed_mask(pts.shape[0])
             sba._apply_extensions(prob, shard["pts"].shape[0], None if fm is None else fm[shard["p0"]:shard["p1"]])
+        except Exception as e:      # noqa: BLE001  (whatever it was, every rank has to hear about it)
+            local_err = f"{type(e).__name__}: {e}"
+        try:
+            raise_everywhere(comm, local_err)
+        except ValueError:
+            if prob is not None:
+                prob.close()
+            raise
+        try:
             prob.comm_init(ids[0], comm.r, comm.n)
             bad = None
             try:
