@@ -36,11 +36,34 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # f32-in MFMA = vector rate 157.3 TF; f64 MFMA is half that on CDNA4
-# HBM bytes per launch from rocprofv3 PMC passes (profiles/r2_pmc_*: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
-# 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).  Valid for the default workload only
-# (16 cams x 50k points, f32, one GPU); other shapes report null.
-PMC_TRAFFIC_BYTES_16x50k_F32 = {"schur_fused": 30.72e6, "schur": 26.58e6, "resjac": 104.62e6, "linearize_points": 19.93e6,
-                                "linearize_cams": 15.53e6, "backsub": 14.56e6, "residual": 13.12e6}
+# HBM bytes per launch come from the rocprofv3 PMC summaries committed under profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE
+# passes folded by tools/pmc_summary.py; traffic = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).
+# They are read at run time, newest round first, and only for the shape they were measured on; any other shape reports null.
+PMC_KERNEL_OF_SLOT = {"schur_fused": ("k_schur_fused_bf3", "k_schur_fused"), "schur": ("k_schur<", "k_schur_sym<"),
+                      "resjac": ("k_resjac<",), "linearize_points": ("k_linearize_points<",), "linearize_cams": ("k_linearize_cams<",),
+                      "backsub": ("k_backsub_dense<", "k_backsub_trial<"), "residual": ("k_residual<",)}
+
+
+def pmc_traffic_bytes(slot, C, Np, dtype, tangential=False, visibility=1.0):
+    """(bytes per launch, source file) of the kernel behind a profile slot, or (None, None) when profiles/ holds no PMC
+    summary for this exact shape."""
+    import glob
+    import re
+    if tangential or visibility < 1.0:
+        return None, None
+    tag = f"{C}x{Np // 1000}k_{dtype}"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{tag}.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)), reverse=True)
+    for f in files:
+        try:
+            tab = json.load(open(f))
+        except Exception:
+            continue
+        for want in PMC_KERNEL_OF_SLOT.get(slot, ()):
+            for name, v in tab.items():
+                if want in name:
+                    return (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def parse():
@@ -51,6 +74,11 @@ def parse():
     ap.add_argument("--cams", type=int, default=16)
     ap.add_argument("--points", type=int, default=50000, help="points PER GPU")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--tangential", action="store_true", help="13-parameter camera rows (radial + tangential: BASELINE config 5)")
+    ap.add_argument("--visibility", type=float, default=1.0, help="probability that a camera sees a point (1.0 = dense, BASELINE's shape)")
+    ap.add_argument("--min-views", type=int, default=2, help="cameras every point keeps at least (the reference's example uses 4)")
+    ap.add_argument("--f64-record", default="auto", choices=["auto", "off"], help="also time the f64 engine (PySBA's default dtype) "
+                    "on the same workload and report it as the `f64` block (N=1, f32 runs only)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline solve; 0 = the GPU workload's own point count "
                     "(16 x 50,000: about 2 minutes of scipy); pass e.g. 5000 for a short sample")
@@ -72,14 +100,19 @@ def algorithmic_bytes_per_obs(kernel, s, C, N, M):
     raise KeyError(kernel)
 
 
-def cpu_baseline(C, n_points_sample, ftol=1e-4):
+def cpu_baseline(C, n_points_sample, ftol=1e-4, rig_kw=None):
     """Reference algorithm on the host: scipy TRF + 3-point FD Jacobian through oracle.bundle_adjust (the reference's exact
     least_squares call, pySBA.py:141), run to its own convergence at the caller's ftol on the SAME rig recipe and, by
-    default, the same size as the GPU workload (16 x 50,000 = 800k observations: ~2 min, 4 LM iterations).
-    The path is numpy elementwise + scipy sparse FD/LSMR: effectively one core, whatever the host has."""
+    default, the same size as the GPU workload (16 x 50,000 = 800k observations: ~1 min, 3-4 LM iterations).
+    The path is numpy elementwise + scipy sparse FD/LSMR: effectively one core, whatever the host has.
+    13-parameter rigs (--tangential) use oracle/sba_oracle_tangential.py: the reference's call around the extended model."""
     from lasercalib_amd.synth import make_rig
-    from oracle import sba_oracle as orc
-    rig = make_rig(C, n_points_sample, seed=0)
+    rig_kw = dict(rig_kw or {})
+    if rig_kw.get("tangential"):
+        from oracle import sba_oracle_tangential as orc
+    else:
+        from oracle import sba_oracle as orc
+    rig = make_rig(C, n_points_sample, seed=0, **rig_kw)
     M = rig["camera_ind"].size
     t0 = time.perf_counter()
     res, _, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], ftol=ftol)
@@ -97,6 +130,51 @@ def cpu_baseline(C, n_points_sample, ftol=1e-4):
             "lm_iters_per_s": iters / dt, "seconds": dt, "nfev": int(res.nfev), "njev": int(res.njev),
             "final_cost": float(res.cost), "host_cpus": os.cpu_count(), "blas_threads": threads,
             "note": "numpy elementwise + scipy sparse FD/LSMR: effectively one core"}
+
+
+def roofline_of_step(kt, dtype, P, C, Nloc, M_local, shape):
+    """`roofline` object for the heaviest streaming / MFMA kernel of a step (kt = in-loop kernel durations in us)."""
+    s = 4 if dtype == "f32" else 8
+    n = P * C
+    traffic = lambda slot: pmc_traffic_bytes(slot, *shape)
+    # one camera group + f32 (+ dense or mask-able visibility): the linearisation runs inside the Schur kernel
+    fused = kt["linearize_points"] == 0 and kt["linearize_cams"] == 0 and kt["schur"] > 0
+    streaming = ("schur", "linearize_cams", "linearize_points", "backsub")
+    # latency-bound single-workgroup / reduction stages (cholesky_solve, schur_reduce) have no meaningful bandwidth roofline:
+    # the heaviest streaming or MFMA kernel is reported, those are listed in kernel_us
+    dominant = max(streaming, key=lambda k: kt[k])
+    if dominant == "schur":
+        flops_mfma = (n * (n + 1) / 2) * 3 * Nloc * 2                      # symmetric S: n(n+1)/2 entries x K=3N x 2
+        # the fused kernel also carries the whole linearisation on the VALU (SURVEY.md 8d: 60 residual + 330 Jacobian +
+        # 480 block accumulation flops per observation, 50 + 198 C per point); on gfx950 the f32 MFMA and the f32 VALU
+        # share the SIMD's FMA lanes (tools/micro/mix_waves.hip: their times add), reported beside `frac`, not in it
+        flops_valu = (870.0 * M_local + (50.0 + 198.0 * C) * Nloc) if fused else 0.0
+        ach = flops_mfma / (kt["schur"] * 1e-6) / 1e12                     # roofline fraction = MFMA work only
+        bf3 = fused and dtype == "f32" and os.environ.get("SBA_FUSED_MFMA", "bf3") != "f32"
+        if fused:
+            kname = "k_schur_fused_bf3" if bf3 else "k_schur_fused"
+        elif dtype == "f64":
+            kname = "k_schur_sym<double>"
+        else:
+            kname = "k_schur_diag_bf3 + k_schur_offdiag_bf3" if C > 16 else "k_schur<float>"
+        tb, tsrc = traffic("schur_fused" if fused else "schur")
+        return {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dtype],
+                "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[dtype], "traffic": tb, "traffic_source": tsrc,
+                "algorithmic_flops_per_launch": flops_mfma, "launch_us": kt["schur"],
+                # the linearisation the fused kernel also carries on the VALU (SURVEY 8d estimate), kept apart from `frac`
+                "valu_flops_estimate": flops_valu,
+                "frac_with_valu_estimate": (flops_mfma + flops_valu) / (kt["schur"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS[dtype],
+                "note": ("algorithmic f32 flops of the symmetric Schur product against the f32-input MFMA peak (= f32 vector peak). "
+                         "k_schur_fused_bf3 forms every f32 product exactly from six bf16 partial products on the bf16 matrix pipe "
+                         "(3-way split of the f32 panel), so the f32 MFMA peak is the yardstick BASELINE/SURVEY name, not a hard ceiling "
+                         "for this kernel; its own limit is the producers' VALU work (DESIGN.md 4.2).  launch_us is the kernel as it runs "
+                         "in the loop: its prologue also takes the accept/reject decision of the previous LM step (about 3 us; a separate "
+                         "6.6 us k_decide launch before, SBA_DECIDE_KERNEL=1 restores it)") if bf3 else None}
+    by = algorithmic_bytes_per_obs(dominant, s, C, Nloc, M_local) * M_local
+    ach = by / (kt[dominant] * 1e-6) / 1e9
+    tb, tsrc = traffic(dominant)
+    return {"kernel": "k_" + dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": tb, "traffic_source": tsrc, "algorithmic_bytes_per_launch": by, "launch_us": kt[dominant]}
 
 
 def main():
@@ -132,12 +210,15 @@ def main():
         torch.cuda.synchronize()
 
     C, Np = a.cams, a.points
+    P = 13 if a.tangential else 11
     N_total = Np * world
-    rig = make_rig(C, N_total, seed=0)                 # every rank builds the same job, then takes its slice
+    rig_kw = dict(visibility=a.visibility, min_cams_per_point=a.min_views, tangential=a.tangential)
+    rig = make_rig(C, N_total, seed=0, **rig_kw)       # every rank builds the same job, then takes its slice
     M_total = rig["camera_ind"].size
     shard = sdist.make_shard(rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], None, world, rank)
     M_local = shard["ci"].size
-    s = 4 if a.dtype == "f32" else 8
+    Nloc = shard["pts"].shape[0]
+    shape = (C, Np, a.dtype, a.tangential, a.visibility)
     stream = torch.cuda.current_stream().cuda_stream
     prob = _native.Problem(rig["cams0"], shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], dtype=a.dtype,
                            device=local, stream=stream)
@@ -174,36 +255,40 @@ def main():
     elif os.environ.get("SBA_BENCH_RCCL_1"):          # one GPU through the same RCCL code path (a 1-rank communicator)
         prob.comm_init(_native.comm_unique_id(), 0, 1)
     comm = sdist.TorchComm() if (world > 1 and phase_api) else sdist.SoloComm()
-    E = torch.empty(prob.exchange_size(), dtype=torch.float64, device="cuda")
-    sc = torch.empty(sdist.NSCALARS, dtype=torch.float64, device="cuda")
 
-    def run(iters, profile=False):
-        """`iters` LM iterations from the initial guess; returns (seconds, last log row)."""
-        prob.set_params(x0)
-        opts = prob.make_opts(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=iters, always_relinearize=True, profile=profile)
-        barrier()
-        t0 = time.perf_counter()
-        if not phase_api:
-            cams, pts, rep, log = prob.solve_lm(opts)          # N > 1: the library runs the sharded loop and its collectives
-            costs = [r.cost for r in log]
-        else:
-            prob.lm_begin(opts)
-            done = 0
-            while done < iters:
-                for _ in range(min(32, iters - done)):      # 32 steps enqueued between two host polls
-                    prob.lm_linearize()
-                    prob.lm_form_reduced(E.data_ptr())
-                    if world > 1:
-                        dist.all_reduce(E)
-                    prob.lm_solve_trial(E.data_ptr(), sc.data_ptr())
-                    sc_all = comm.all_gather_rows(sc)
-                    prob.lm_decide_async(sc_all.data_ptr(), world)
-                status, done = prob.lm_poll()
-            costs = [r.cost for r in prob.iteration_log()]
-            prob.lm_finish()
-        barrier()
-        return time.perf_counter() - t0, costs
+    def make_runner(pr):
+        E = torch.empty(pr.exchange_size(), dtype=torch.float64, device="cuda")
+        sc = torch.empty(sdist.NSCALARS, dtype=torch.float64, device="cuda")
 
+        def run(iters, profile=False):
+            """`iters` LM iterations from the initial guess; returns (seconds, costs)."""
+            pr.set_params(x0)
+            opts = pr.make_opts(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=iters, always_relinearize=True, profile=profile)
+            barrier()
+            t0 = time.perf_counter()
+            if not phase_api:
+                cams, pts, rep, log = pr.solve_lm(opts)          # N > 1: the library runs the sharded loop and its collectives
+                costs = [r.cost for r in log]
+            else:
+                pr.lm_begin(opts)
+                done = 0
+                while done < iters:
+                    for _ in range(min(32, iters - done)):      # 32 steps enqueued between two host polls
+                        pr.lm_linearize()
+                        pr.lm_form_reduced(E.data_ptr())
+                        if world > 1:
+                            dist.all_reduce(E)
+                        pr.lm_solve_trial(E.data_ptr(), sc.data_ptr())
+                        sc_all = comm.all_gather_rows(sc)
+                        pr.lm_decide_async(sc_all.data_ptr(), world)
+                    status, done = pr.lm_poll()
+                costs = [r.cost for r in pr.iteration_log()]
+                pr.lm_finish()
+            barrier()
+            return time.perf_counter() - t0, costs
+        return run
+
+    run = make_runner(prob)
     if a.warmup > 0:
         run(a.warmup)
     dt, costs = run(a.steps)
@@ -220,54 +305,27 @@ def main():
     step_us = dt / a.steps * 1e6
     out = None
     if rank == 0:
-        n = 11 * C
-        default_shape = (C == 16 and Np == 50000 and a.dtype == "f32" and world == 1)
-        traffic = lambda k: PMC_TRAFFIC_BYTES_16x50k_F32.get(k) if default_shape else None
-        # dense visibility + one camera group + f32: the linearisation runs inside the Schur kernel (k_schur_fused)
+        n = P * C
+        s = 4 if a.dtype == "f32" else 8
         fused = kt["linearize_points"] == 0 and kt["linearize_cams"] == 0 and kt["schur"] > 0
-        dominant = max(("schur", "linearize_cams", "linearize_points", "backsub", "cholesky_solve", "schur_reduce"), key=lambda k: kt[k])
-        if dominant in ("cholesky_solve", "schur_reduce"):
-            # latency-bound single-workgroup / reduction stages have no meaningful bandwidth roofline; report the
-            # heaviest streaming or MFMA kernel instead and list these in kernel_us
-            dominant = max(("schur", "linearize_cams", "linearize_points", "backsub"), key=lambda k: kt[k])
-        if dominant == "schur":
-            Nloc = shard["pts"].shape[0]
-            flops_mfma = (n * (n + 1) / 2) * 3 * Nloc * 2                      # symmetric S: n(n+1)/2 entries x K=3N x 2
-            # the fused kernel also carries the whole linearisation on the VALU (60 residual + 330 Jacobian +
-            # 480 block accumulation flops per observation, 50 + 198 C per point); on gfx950 the f32 MFMA and the f32 VALU
-            # share the SIMD's FMA lanes (tools/micro/mix_waves.hip: their times add), reported beside `frac`, not in it
-            flops_valu = (870.0 * M_local + (50.0 + 198.0 * C) * Nloc) if fused else 0.0
-            ach = flops_mfma / (kt["schur"] * 1e-6) / 1e12                     # roofline fraction = MFMA work only
-            bf3 = fused and os.environ.get("SBA_FUSED_MFMA", "bf3") != "f32"
-            roof = {"kernel": ("k_schur_fused_bf3" if bf3 else "k_schur_fused") if fused else ("k_schur_sym" if a.dtype == "f64" else "k_schur"), "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[a.dtype],
-                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype], "traffic": traffic("schur_fused" if fused else "schur"),
-                    "algorithmic_flops_per_launch": flops_mfma, "launch_us": kt["schur"],
-                    # the linearisation the fused kernel also carries on the VALU (SURVEY 8d estimate), kept apart from `frac`
-                    "valu_flops_estimate": flops_valu,
-                    "frac_with_valu_estimate": (flops_mfma + flops_valu) / (kt["schur"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS[a.dtype],
-                    "note": ("algorithmic f32 flops of the symmetric Schur product against the f32-input MFMA peak (= f32 vector peak). "
-                             "k_schur_fused_bf3 forms every f32 product exactly from six bf16 partial products on the bf16 matrix pipe "
-                             "(3-way split of the f32 panel), so the f32 MFMA peak is the yardstick BASELINE/SURVEY name, not a hard ceiling "
-                             "for this kernel; its own limit is the producers' VALU work (DESIGN.md 4.2).  launch_us is the kernel as it runs "
-                             "in the loop: its prologue also takes the accept/reject decision of the previous LM step (about 3 us; a separate "
-                             "6.6 us k_decide launch before, SBA_DECIDE_KERNEL=1 restores it)") if bf3 else None}
-        else:
-            by = algorithmic_bytes_per_obs(dominant, s, C, shard["pts"].shape[0], M_local) * M_local
-            ach = by / (kt[dominant] * 1e-6) / 1e9
-            roof = {"kernel": "k_" + dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic(dominant), "algorithmic_bytes_per_launch": by, "launch_us": kt[dominant]}
-        rj_bytes = algorithmic_bytes_per_obs("resjac", s, C, shard["pts"].shape[0], M_local) * M_local
+        roof = roofline_of_step(kt, a.dtype, P, C, Nloc, M_local, shape)
+        rj_bytes = algorithmic_bytes_per_obs("resjac", s, C, Nloc, M_local) * M_local
+        if P == 13:
+            rj_bytes += 4 * s * M_local          # two more camera columns of the 2 x P block
+        tb, tsrc = pmc_traffic_bytes("resjac", *shape)
         rj = {"kernel": "k_resjac", "bound": "hbm", "achieved": rj_bytes / (kt["resjac"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": rj_bytes / (kt["resjac"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "launch_us": kt["resjac"],
-              "algorithmic_bytes_per_launch": rj_bytes, "mobs_per_s": M_local / kt["resjac"], "traffic": traffic("resjac")}
+              "algorithmic_bytes_per_launch": rj_bytes, "mobs_per_s": M_local / kt["resjac"], "traffic": tb, "traffic_source": tsrc}
+        vis_txt = "full visibility" if a.visibility >= 1.0 else f"visibility {a.visibility:g} (>= {a.min_views} views per point)"
         out = {
             "metric": "LM iters/sec and residual+Jacobian Mobs/s at 16 cams x 50k points",
             "value": M_total * a.steps / dt / 1e6,
             "unit": "Mobs/s (observations x LM iterations per second, whole job)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"{C} cams x {Np} points per GPU, full visibility ({M_local} obs per GPU, {M_total} total), "
+            "config": {"workload": f"{C} cams x {Np} points per GPU, {vis_txt}, {P}-parameter cameras ({M_local} obs per GPU, {M_total} total), "
                                    "full on-device Schur-complement LM iteration", "cams": C, "points_per_gpu": Np,
+                       "camera_parameters": P, "visibility": a.visibility,
                        "observations_total": int(M_total), "parallelism": f"points sharded x{world}, cameras replicated",
                        "collectives_fallback_reason": comm_note,
                        "collectives": ("none" if world == 1 else "torch.distributed through the phase C ABI (rehearsal / fallback)" if phase_api else
@@ -281,9 +339,27 @@ def main():
             "cost_first_last": [costs[0], costs[-1]] if costs else None,
             "roofline": roof, "roofline_resjac": rj,
         }
+    # the f64 engine on the same workload: PySBA's default dtype (the reference computes in f64), i.e. what an unmodified
+    # calibrate_camera.py runs.  Outside the timed headline; same step definition, fewer steps.
+    if world == 1 and a.dtype == "f32" and a.f64_record != "off":
+        prob.close()
+        prob = _native.Problem(rig["cams0"], shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], dtype="f64",
+                               device=local, stream=stream)
+        run64 = make_runner(prob)
+        k64 = min(a.steps, 20)
+        run64(min(max(a.warmup, 1), 5))
+        dt64, costs64 = run64(k64)
+        run64(k64, profile=True)
+        kt64 = prob.kernel_profile()
+        out["f64"] = {"dtype": "f64", "steps": k64, "ms_per_step": dt64 / k64 * 1e3, "lm_iters_per_s": k64 / dt64,
+                      "value": M_total * k64 / dt64 / 1e6, "kernel_us": kt64,
+                      "cost_first_last": [costs64[0], costs64[-1]] if costs64 else None,
+                      "roofline": roofline_of_step(kt64, "f64", P, C, Nloc, M_local, (C, Np, "f64", a.tangential, a.visibility)),
+                      "note": "the drop-in class's default engine (LASERCALIB_SBA_DTYPE unset): same workload and step as the headline"}
+    if rank == 0:
         if a.cpu_baseline != "off" and world == 1:
             cpu_pts = a.cpu_points if a.cpu_points > 0 else Np
-            cb = cpu_baseline(C, cpu_pts)
+            cb = cpu_baseline(C, cpu_pts, rig_kw=rig_kw)
             out["cpu_baseline"] = cb
             if cpu_pts == Np:      # same configuration on both sides: the ratio of LM iterations per second is meaningful
                 out["speedup_vs_cpu_lm_iters_per_s"] = out["lm_iters_per_s"] / cb["lm_iters_per_s"]

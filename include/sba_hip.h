@@ -196,6 +196,10 @@ int sba_lm_decide(sba_handle* h, const double* scalars_all_dev /*n_ranks*8*/, in
 int sba_lm_decide_async(sba_handle* h, const double* scalars_all_dev /* NULL when n_ranks == 1 */, int32_t n_ranks);
 int sba_lm_poll(sba_handle* h, int32_t* status_out, int32_t* iterations_out);
 int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report);
+/* Camera step delta_c (n_cams * params doubles) of the last sba_lm_solve_trial: the solution of the damped reduced camera
+ * system the exchange buffer described.  A test hook -- the reduced system may be ANY symmetric positive definite matrix the
+ * caller wrote into the exchange buffer, which is how tests/test_gpu_cholesky.py checks every factorisation kernel on its own. */
+int sba_lm_get_step(sba_handle* h, double* delta_c_out);
 /* Rows of the per-iteration log collected so far (filled in by sba_lm_poll / sba_lm_finish). */
 int sba_lm_get_log(sba_handle* h, sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows);
 

@@ -24,7 +24,7 @@ NSCALARS = 8
 EXPORTED_SYMBOLS = (
     "sba_abi_version", "sba_device_count", "sba_last_error", "sba_rotate", "sba_project", "sba_project_model",
     "sba_create", "sba_upload", "sba_set_params", "sba_get_params", "sba_destroy",
-    "sba_get_gradient", "sba_get_transform", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
+    "sba_get_gradient", "sba_get_transform", "sba_lm_get_step", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
     "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_finish", "sba_lm_get_log", "sba_time_kernel", "sba_get_kernel_profile",
     "sba_comm_get_unique_id", "sba_comm_init", "sba_set_fixed_points", "sba_set_robust_loss",
@@ -115,6 +115,7 @@ def load():
         "sba_destroy": (C.c_int, [H]),
         "sba_get_gradient": (C.c_int, [H, dp, dp]),
         "sba_get_transform": (C.c_int, [H, dp]),
+        "sba_lm_get_step": (C.c_int, [H, dp]),
         "sba_residual": (C.c_int, [H, dp, dp, dp]),
         "sba_residual_jacobian": (C.c_int, [H, dp, dp, dp, dp]),
         "sba_solve_lm": (C.c_int, [H, C.POINTER(LmOpts), dp, dp, C.POINTER(LmReport),
@@ -375,6 +376,12 @@ class Problem:
 
     def lm_solve_trial(self, exchange_ptr, scalars_ptr):
         _check(self._lib.sba_lm_solve_trial(self._h, C.c_void_p(exchange_ptr), C.c_void_p(scalars_ptr)), self._h)
+
+    def lm_get_step(self):
+        """delta_c of the last lm_solve_trial (test hook for the reduced-system factorisations)."""
+        d = np.empty((self.C, self.P))
+        _check(self._lib.sba_lm_get_step(self._h, _dptr(d)), self._h)
+        return d
 
     def lm_decide(self, scalars_all_ptr, n_ranks):
         status, acc = C.c_int32(), C.c_int32()

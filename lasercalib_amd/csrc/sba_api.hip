@@ -148,6 +148,11 @@ int sba_get_transform(sba_handle* h, double* theta12_out) {
   return h->eng->get_transform(theta12_out);
 }
 
+int sba_lm_get_step(sba_handle* h, double* delta_c_out) {
+  if (!h || !delta_c_out) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return h->eng->get_step(delta_c_out); });
+}
+
 int sba_get_gradient(sba_handle* h, double* gc_out, double* gp_out) {
   if (!h) return SBA_ERR_INVALID;
   return guarded(h, [&] { return h->eng->get_gradient(gc_out, gp_out); });

@@ -237,6 +237,7 @@ struct EngineBase {
   virtual int get_params(double* cams_out, double* pts_out) = 0;
   virtual int get_gradient(double* gc_out, double* gp_out) = 0;
   virtual int get_transform(double* theta12) = 0;
+  virtual int get_step(double* delta_c_out) = 0;
   virtual int residual(const double* x, double* r_out, double* cost_out) = 0;
   virtual int residual_jacobian(const double* x, double* r_out, double* Jc_out, double* Jp_out) = 0;
   virtual int solve(const sba_lm_opts* o, double* cams_out, double* pts_out, sba_lm_report* rep, sba_lm_iter_log* lg, int cap, int32_t* rows) = 0;

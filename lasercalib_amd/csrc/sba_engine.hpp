@@ -5,6 +5,7 @@
 #include "sba_common.hpp"
 #include "sba_lm_kernels.hpp"
 #include "sba_chol_blocked.hpp"
+#include "sba_chol_ll.hpp"
 #include "sba_chol_big.hpp"
 #include "sba_sq_kernels.hpp"
 
@@ -76,6 +77,10 @@ struct Engine : EngineBase {
   sba_lm_opts opts{};
   bool lm_active = false;
   bool chol_old = false;
+  // one-workgroup factorisations of up to 256 unknowns: the right-looking all-in-LDS kernel up to 176 (k_cholesky_blocked),
+  // the left-looking kernel with the factor on chip above that (k_cholesky_ll, sba_chol_ll.hpp: 17..23 cameras).
+  // SBA_CHOL=ll: the left-looking kernel for every size up to 256; SBA_CHOL=blocked: never (the streamed kernel above 176) -- A/B runs, tests
+  bool chol_ll = true, chol_ll_all = false;
   // systems larger than this take the multi-workgroup factorisation (sba_chol_big.hpp); up to CS_MAX_NB * CB = 512 unknowns the
   // streamed one-workgroup kernel could run too, but it only wins below ~210 (measured at 50k points, fp32: 17 cameras 379 vs 388 us
   // per iteration, 20: 417 vs 409, 24: 487 vs 454, 32: 647 vs 515)
@@ -168,7 +173,9 @@ struct Engine : EngineBase {
     // SBA_FUSED_MFMA=f32 keeps the f32-input MFMA kernel (A/B measurements, equivalence test); default: bf16 x 3 split
     if (const char* e = getenv("SBA_FUSED_MFMA")) fused_bf3 = (std::string(e) != "f32");
 #endif
-    if (const char* e = getenv("SBA_CHOL")) chol_old = (std::string(e) == "old");
+    if (const char* e = getenv("SBA_CHOL")) {
+      chol_old = (std::string(e) == "old"); chol_ll = (std::string(e) != "blocked") && !chol_old; chol_ll_all = (std::string(e) == "ll");
+    }
     if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
     if (const char* e = getenv("SBA_CHOL_BIG_MIN_N")) {      // diagnostic: route smaller systems through the big path too
       char* end = nullptr;
@@ -201,6 +208,7 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_ll<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -1045,7 +1053,36 @@ struct Engine : EngineBase {
                            E_tied.p, d_state.p);
         Esys = E_tied.p;
       }
-      if (n_sys <= CHOL_LDS_MAX_N && !chol_old) {
+      if (chol_ll && (n_sys > CHOL_LDS_MAX_N || chol_ll_all) && n_sys <= CLL_MAX_NB * CB && C * NCP <= CLL_THREADS) {
+        // up to 256 unknowns (23 cameras): left-looking, factor on chip (sba_chol_ll.hpp)
+        const int nb = (n_sys + CB - 1) / CB;
+        if (chol_work.n < (size_t)nb * (nb + 1) / 2 * CB * CB) chol_work.alloc((size_t)CLL_MAX_NB * (CLL_MAX_NB + 1) / 2 * CB * CB);
+        if (chol_debug && chol_dbg.n < 128) { chol_dbg.alloc(128); chol_dbg.zero(stream); }
+        hipLaunchKernelGGL(k_cholesky_ll<T>, dim3(1), dim3(CLL_THREADS), CLL_LDS_BYTES, stream, Esys, C, d_state.p, D2c.p,
+                           ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr, chol_work.p,
+                           chol_debug ? chol_dbg.p : nullptr);
+        if (chol_debug) {
+          std::vector<long long> st(128);
+          HIPCHK(hipMemcpyAsync(st.data(), chol_dbg.p, 128 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+          sync();
+          if (nb > 6) {
+            const long long x0 = st[2 + 2 * 3], y0 = st[3 + 2 * 3];      // start of X_3 / Y_3 (thread 0)
+            fprintf(stderr, "[chol_ll step 3, cycles after the step's barrier, per wave] X done:");
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " %lld", st[64 + w] - x0);
+            fprintf(stderr, " | Y done:");
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " %lld", st[72 + w] - y0);
+            fprintf(stderr, "\n[chol_ll back substitution, block row 5] x done (per wave, from wave 0's):");
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " %lld", st[80 + w] - st[80]);
+            fprintf(stderr, " | barrier passed %lld | update done:", st[96] - st[80]);
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " %lld", st[88 + w] - st[96]);
+            fprintf(stderr, " | barrier passed %lld\n", st[97] - st[96]);
+          }
+          fprintf(stderr, "[chol_ll stamps, cycles] setup %lld  chol0 %lld |", st[1] - st[0], st[2] - st[1]);
+          for (int j = 0; j < nb; ++j) fprintf(stderr, " X%d %lld Y%d %lld |", j, st[3 + 2 * j] - st[2 + 2 * j], j, st[4 + 2 * j] - st[3 + 2 * j]);
+          fprintf(stderr, " backsub %lld  epilogue %lld  total %lld\n", st[3 + 2 * nb] - st[2 + 2 * nb], st[4 + 2 * nb] - st[3 + 2 * nb], st[4 + 2 * nb] - st[0]);
+          chol_debug = false;
+        }
+      } else if (n_sys <= CHOL_LDS_MAX_N && !chol_old) {
         const int nb = (n_sys + CB - 1) / CB;
         const size_t lds = ((size_t)(nb * (nb + 1) / 2) * CBS + 2 * (size_t)nb * CB) * sizeof(double);
         if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }
@@ -1424,6 +1461,12 @@ struct Engine : EngineBase {
     if (!uploaded) { err = "not uploaded"; return SBA_ERR_STATE; }
     if (gc_out) HIPCHK(hipMemcpyAsync(gc_out, gc.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
     if (gp_out) HIPCHK(hipMemcpyAsync(gp_out, gp.p, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost, stream));
+    sync();
+    return SBA_OK;
+  }
+  int get_step(double* delta_c_out) override {
+    if (!uploaded) { err = "not uploaded"; return SBA_ERR_STATE; }
+    HIPCHK(hipMemcpyAsync(delta_c_out, delta_c.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
     sync();
     return SBA_OK;
   }

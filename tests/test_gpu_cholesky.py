@@ -1,0 +1,99 @@
+"""GPU: every factorisation kernel of the reduced camera system on its own, against numpy.
+
+The phase API takes the reduced system from a device buffer the caller owns (the exchange buffer
+``[S n*n | rhs n | diagU n | g_c n | cost 1]``, include/sba_hip.h), so a test can hand ``sba_lm_solve_trial`` ANY symmetric
+positive definite S and read the camera step back with ``sba_lm_get_step``: the damped solve
+``(S + lam diag(max(D, diagU)))^-1 rhs`` must agree with numpy whatever kernel the size selects --
+
+    n <= 176 (<= 16 cameras):        k_cholesky_blocked (right-looking, all in LDS)
+    176 < n <= 256 (17..23 cameras): k_cholesky_ll      (left-looking, factor on chip, sba_chol_ll.hpp)
+    SBA_CHOL=ll:                     k_cholesky_ll for every n <= 256
+    SBA_CHOL=blocked, n <= 209:      k_cholesky_stream instead of k_cholesky_ll
+    larger:                          k_chol_big_*
+
+including sizes that are not multiples of the 16-wide blocks, an ill-conditioned matrix, and an indefinite one (the step
+must come back as zero with the failure flag set, which the LM control turns into a rejected trial).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from lasercalib_amd import _native  # noqa: E402
+from lasercalib_amd.synth import make_rig  # noqa: E402
+
+
+def _spd(n, rng, cond=1e3):
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.geomspace(1.0, cond, n)
+    A = (Q * ev) @ Q.T
+    return 0.5 * (A + A.T)
+
+
+def _solve_on_device(C, S, rhs, dU, dtype, lam=1e-3):
+    rig = make_rig(C, 40, seed=C)
+    n = 11 * C
+    with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], dtype=dtype) as prob:
+        prob.lm_begin(prob.make_opts(ftol=0, xtol=0, gtol=0, lambda0=lam))
+        assert prob.exchange_size() == n * n + 3 * n + 1
+        E = torch.zeros(prob.exchange_size(), dtype=torch.float64, device="cuda")
+        E[: n * n] = torch.from_numpy(S.ravel())
+        E[n * n: n * n + n] = torch.from_numpy(rhs)
+        E[n * n + n: n * n + 2 * n] = torch.from_numpy(dU)
+        sc = torch.zeros(8, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        prob.lm_solve_trial(E.data_ptr(), sc.data_ptr())
+        step = prob.lm_get_step().ravel()
+        prob.lm_finish()
+    return step
+
+
+CASES = [(2, "f64"), (5, "f64"), (11, "f64"), (16, "f64"), (16, "f32"), (17, "f64"), (17, "f32"), (19, "f64"), (20, "f32"),
+         (23, "f64"), (23, "f32"), (24, "f64"), (32, "f32")]
+
+
+@pytest.mark.parametrize("mode", ["default", "blocked", "ll"])
+@pytest.mark.parametrize("C,dtype", CASES)
+def test_reduced_system_solve_matches_numpy(monkeypatch, C, dtype, mode):
+    if mode != "default":
+        monkeypatch.setenv("SBA_CHOL", mode)
+    else:
+        monkeypatch.delenv("SBA_CHOL", raising=False)
+    rng = np.random.default_rng(100 + C)
+    n = 11 * C
+    S = _spd(n, rng)
+    rhs = rng.standard_normal(n)
+    dU = np.abs(rng.standard_normal(n)) + 0.5
+    lam = 1e-3
+    step = _solve_on_device(C, S, rhs, dU, dtype, lam)
+    A = S + lam * np.diag(dU)            # first linearisation: D = max(0, diagU)
+    ref = np.linalg.solve(A, rhs)
+    # f64 engine: pivots refined to 4e-15; f32 engine: the 5e-8 hardware estimate of 1/sqrt is used as it is, which
+    # perturbs the factored matrix by 1e-7 relative => solution error <= cond * 1e-7
+    tol = 1e-9 if dtype == "f64" else 1e3 * 2e-7
+    assert np.max(np.abs(step - ref)) <= tol * np.max(np.abs(ref)), np.max(np.abs(step - ref)) / np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("mode", ["default", "ll"])
+@pytest.mark.parametrize("C", [16, 17, 21, 23])
+def test_ill_conditioned_and_indefinite(monkeypatch, C, mode):
+    if mode != "default":
+        monkeypatch.setenv("SBA_CHOL", mode)
+    else:
+        monkeypatch.delenv("SBA_CHOL", raising=False)
+    rng = np.random.default_rng(7 + C)
+    n = 11 * C
+    S = _spd(n, rng, cond=1e9)
+    rhs = rng.standard_normal(n)
+    dU = np.ones(n)
+    step = _solve_on_device(C, S, rhs, dU, "f64", lam=1e-6)
+    ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
+    assert np.max(np.abs(step - ref)) <= 1e-5 * np.max(np.abs(ref))
+    # an indefinite system: the factorisation must notice and return a zero step
+    S2 = S.copy()
+    k = n - 5
+    S2[k, k] = -1.0
+    step = _solve_on_device(C, S2, rhs, dU, "f64", lam=1e-6)
+    assert np.all(step == 0.0)
