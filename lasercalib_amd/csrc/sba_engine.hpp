@@ -8,6 +8,7 @@
 #include "sba_chol_ll.hpp"
 #include "sba_chol_big.hpp"
 #include "sba_sq_kernels.hpp"
+#include "sba_schur_wide.hpp"
 
 namespace SBA_NS {
 using namespace sba_host;
@@ -38,6 +39,7 @@ struct Engine : EngineBase {
   bool no_bf3_offdiag = false;       // SBA_NO_BF3_OFFDIAG=1: ... for the off-diagonal pairs only
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
   bool fused_bf3 = true;             // ... with the Schur products on the bf16 matrix pipe (k_schur_fused_bf3)
+  bool fused_wide = false;           // 17 .. 23 cameras: k_schur_fused_wide (compact rows, one launch; implies fused_ok)
   DevBuf<double> gdpart;
   std::vector<int64_t> perm;          // pm position -> caller's observation index
   int nblk = 0, nchunk = 0, ngroups = 0, npairs = 0, ksplit = 1;
@@ -200,6 +202,11 @@ struct Engine : EngineBase {
 #if SBA_NCP == 11
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<12>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<13>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<14>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<14>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<15>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<16>::LDS_BYTES));
 #endif
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_diag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurPairCfg::LDS_BYTES));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_offdiag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3OffCfg::LDS_BYTES));
@@ -454,6 +461,20 @@ struct Engine : EngineBase {
       sync();
       grp_indexed = (flag == 0);     // cameras strictly ascending inside every point; otherwise the producers scan
     }
+    // 17 .. 23 cameras (<= 256 rows), f32, 11 parameters: the one-launch fused kernel of sba_schur_wide.hpp.  Like the masked
+    // one-group kernel its producer cost does not shrink with the visibility, so below ~35 % the three-pass path stays.
+    fused_wide = false;
+#if SBA_NCP == 11
+    if constexpr (sizeof(T) == 4) {
+      fused_wide = C > GROUP_CAMS && C * NCP <= 16 * WIDE_MAX_NTW && N > 0 && fused_bf3 && !getenv("SBA_NO_FUSED") && !getenv("SBA_NO_WIDE") &&
+                   (dense || (grp_indexed && (double)M >= 0.35 * (double)N * C));
+      if (fused_wide) {
+        int target = 256;
+        if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
+        ksplit = std::max(1, std::min(target, (N + 7) / 8));
+      }
+    }
+#endif
 
     for (int b = 0; b < 2; ++b) {
       cams[b].alloc((size_t)C * NCP); pts[b].alloc((size_t)N * 3);
@@ -462,8 +483,8 @@ struct Engine : EngineBase {
     pfac.alloc((size_t)std::max(N, 1) * PF);
     V.alloc((size_t)N * 6); gp.alloc((size_t)N * 3); D2p.alloc((size_t)N * 3); D2c.alloc(n);
     U.alloc((size_t)C * NCP * NCP); gc.alloc(n); Upart.alloc((size_t)std::max(1, nchunk) * 256);
-    bpart.alloc((size_t)ngroups * ksplit * GROUP_ROWS);
-    slabs.alloc((size_t)npairs * ksplit * GROUP_TILES * GROUP_TILES * 256);
+    bpart.alloc(std::max((size_t)ngroups * ksplit * GROUP_ROWS, fused_wide ? (size_t)ksplit * WIDE_ROWS : (size_t)0));
+    slabs.alloc(std::max((size_t)npairs * ksplit * GROUP_TILES * GROUP_TILES * 256, fused_wide ? (size_t)ksplit * WIDE_SLOTS * 256 : (size_t)0));
     E_own.alloc((size_t)n * n + 3 * n + 1); scal_own.alloc(NSCAL); delta_c.alloc(n);
     const int nres_blocks = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
     dense_one_group = dense && C <= GROUP_CAMS && N > 0 && !getenv("SBA_NO_DENSE");
@@ -472,11 +493,11 @@ struct Engine : EngineBase {
     // does not shrink with the number of observations, so below ~35 % visibility the three-pass path is used
     const bool masked_fused = masked_ok && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
     // (the fused kernel is built for the 11-parameter model only: 77 register accumulators per lane; 13 parameters need 104)
-    fused_ok = NCP == 11 && (dense_one_group || masked_fused) && sizeof(T) == 4 && !getenv("SBA_NO_FUSED");
-    fused_masked = fused_ok && !dense_one_group;
+    fused_ok = (NCP == 11 && (dense_one_group || masked_fused) && sizeof(T) == 4 && !getenv("SBA_NO_FUSED")) || fused_wide;
+    fused_masked = fused_ok && !dense_one_group && !fused_wide;
     lin_pts_ok = (dense_one_group || masked_fused) && SCHUR_LIN_OK<T> && !getenv("SBA_NO_FUSED");
     if (fused_masked || (lin_pts_ok && !dense_one_group)) vis_mask.upload(vmask, stream);
-    if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * GROUP_ROWS);
+    if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * (fused_wide ? WIDE_ROWS : GROUP_ROWS));
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1)); gmax_alt.alloc(std::max(std::max(nblk, ksplit), 1));
     trial_part.alloc((size_t)4 * std::max(nblk, 1));
     up_lap("allocations + H2D enqueue");
@@ -554,6 +575,7 @@ struct Engine : EngineBase {
 #if SBA_NCP == 11
     if constexpr (sizeof(T) == 4) {
       if (fused()) {
+        if (fused_wide) { launch_schur_wide(); return; }
         if (fused_bf3) {
           FusedDecide fd{};
           fd.st_in = fd.st_out = d_state.p;
@@ -621,6 +643,60 @@ struct Engine : EngineBase {
     }
     launch_schur_kernels<false>();
   }
+#if SBA_NCP == 11
+  FusedDecide make_fused_decide(double*& gm_out) {
+    FusedDecide fd{};
+    fd.st_in = fd.st_out = d_state.p;
+    gm_out = (gmax_cur == gmax_part.p) ? gmax_alt.p : gmax_part.p;      // never the array a decision may still read
+    if (pending_decide) {
+      st_slot ^= 1;
+      fd.st_out = d_state_buf.p + st_slot;
+      fd.do_decide = 1;
+      fd.scal_all = pend_scal; fd.n_ranks = pend_ranks;
+      fd.trial_part = trial_part.p; fd.gmax_in = gmax_cur;
+      fd.n_trial = n_trial_parts(); fd.n_gmax = n_lin_parts();
+      fd.log = reinterpret_cast<LMLogRow*>(d_log.p); fd.log_cap = LOG_CAP;
+    }
+    return fd;
+  }
+  void launch_schur_wide() {
+    if constexpr (sizeof(T) == 4) {
+      double* gm_out = nullptr;
+      const FusedDecide fd = make_fused_decide(gm_out);
+      const bool tables = !dense;
+      auto go = [&](auto ntw_c) {
+        constexpr int NTW = decltype(ntw_c)::value;
+        hipLaunchKernelGGL(k_schur_fused_wide<NTW>, dim3(ksplit), dim3(SCHUR_THREADS), SchurWideCfg<NTW>::LDS_BYTES, stream,
+                           ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, tables ? grp_mask.p : (const uint16_t*)nullptr,
+                           tables ? grp_start.p : (const int32_t*)nullptr, N, ksplit, D2p.p, gp.p, pfac.p, slabs.p, bpart.p, gdpart.p,
+                           cost_part.p, gm_out, (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr);
+      };
+      switch (wide_ntw(C)) {
+        case 12: go(std::integral_constant<int, 12>{}); break;
+        case 13: go(std::integral_constant<int, 13>{}); break;
+        case 14: go(std::integral_constant<int, 14>{}); break;
+        case 15: go(std::integral_constant<int, 15>{}); break;
+        default: go(std::integral_constant<int, 16>{}); break;
+      }
+      d_state.p = fd.st_out;
+      pending_decide = false;
+      gmax_cur = gm_out;
+      if (schur_debug && schur_debug_skip > 0) { --schur_debug_skip; return; }
+      if (schur_debug) {
+        std::vector<long long> st(64);
+        HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+        sync();
+        fprintf(stderr, "[schur_fused_wide stamps, cycles since the first producer stamp; per round: producer-done consumer-done]\n");
+        for (int i = 0; i < 14; ++i) fprintf(stderr, "  it %2d: P %7lld  C %7lld\n", i, st[2 * i] - st[0], st[2 * i + 1] - st[0]);
+        fprintf(stderr, "  phases (cycles): prologue %lld | main loop %lld | fold U %lld | slab stores %lld | tail %lld | whole kernel %lld\n",
+                st[49] - st[48], st[50] - st[49], st[51] - st[50], st[52] - st[51], st[53] - st[52], st[53] - st[48]);
+        schur_debug = false;
+      }
+    }
+  }
+#else
+  void launch_schur_wide() {}
+#endif
   template <bool PARTIAL> void launch_schur_kernels() {
     using CfgD = SchurSel<T, true>;
     using CfgO = SchurSel<T, false>;
@@ -1002,10 +1078,15 @@ struct Engine : EngineBase {
     prof_begin(KP_REDUCE);
     {
       const int fc = (int)h_state->free_cams;
-      const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * npairs + (n + 15) / 16 : 0) + 1;
+      const bool wide = fused() && fused_wide;
+      // (wide: one slab per workgroup with ntw (ntw + 1) / 2 tiles; the kernel counts its tile blocks as 4 * 121 * npairs, so one
+      //  "pair" of 121 tile slots per 121 tiles is passed)
+      const int ntw = wide_ntw(C), wide_pairs = (ntw * (ntw + 1) / 2 + GROUP_TILES * GROUP_TILES - 1) / (GROUP_TILES * GROUP_TILES);
+      const int np_arg = wide ? wide_pairs : npairs;
+      const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * np_arg + (n + 15) / 16 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
-                         pair_gb.p, npairs, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_bf3) ? 1 : (diag_pairs_bf3() ? (offdiag_pairs_bf3() ? 1 : 2) : 0));
+                         pair_gb.p, np_arg, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
+                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_wide) ? 3 : (fused() && fused_bf3) ? 1 : (diag_pairs_bf3() ? (offdiag_pairs_bf3() ? 1 : 2) : 0));
     }
     prof_end(KP_REDUCE);
     return SBA_OK;

@@ -32,6 +32,17 @@ constexpr int GROUP_CAMS = 16;     // cameras per Schur camera group: 16*11 = 17
 constexpr int GROUP_ROWS = GROUP_CAMS * NCP;   // 176 (208)
 constexpr int GROUP_TILES = GROUP_ROWS / 16;   // 11 (13)
 constexpr int NSCAL = 8;
+// k_schur_fused_wide (sba_schur_wide.hpp: 17 .. 23 cameras in one launch): compact parameter-major rows e*C + c in NTW = ceil(11 C / 16)
+// tiles, slabs [workgroup][WIDE_SLOTS tiles][64 lanes][4], row partials with a stride of WIDE_ROWS
+constexpr int WIDE_ROWS = 256;
+constexpr int WIDE_MAX_NTW = 16;
+constexpr int WIDE_SLOTS = WIDE_MAX_NTW * (WIDE_MAX_NTW + 1) / 2;
+__host__ __device__ constexpr int wide_ntw(int C) { return (C * NCP + 15) / 16; }
+__host__ __device__ inline void wide_tile_rc(int ntw, int t, int& R, int& Tc) {      // row-major enumeration of the upper tile triangle
+  int r = 0, rem = t;
+  while (rem >= ntw - r) { rem -= ntw - r; ++r; }
+  R = r; Tc = r + rem;
+}
 
 // Current / trial parameter buffers: both sets travel BY VALUE as a kernel argument (no extra dependent load), and
 // a kernel picks its side from LMState::cur, which decide_core flips when a step is accepted -- so the host never has

@@ -34,7 +34,9 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     double* __restrict__ Pk = nullptr /* multi-rank: the same system once more, upper triangle packed row by row
                                          [S n(n+1)/2 | rhs | diagU | gc | cost] -- what travels through the all-reduce */,
     int emajor_mode = 0 /* parameter-major tiles (tile (R, Tc) holds parameters (R, Tc) of the camera pairs, row 16 e + c):
-                           1 = every pair (k_schur_fused_bf3), 2 = the diagonal pairs (k_schur_diag_bf3) */) {
+                           1 = every pair (k_schur_fused_bf3), 2 = the diagonal pairs (k_schur_diag_bf3),
+                           3 = k_schur_fused_wide: one slab per workgroup, compact rows e*C + c in ceil(11 C / 16) tiles, row partials
+                               (bpart / gdpart) in the exchange buffer's own order with a stride of WIDE_ROWS */) {
   using M_ = Mfma<T>;
   // tiles: 64 entries x 16 k-split groups per block (256-byte segments per group load; 16 entries x 64 groups was
   // measured slower: 64-byte segments, four times the blocks).  Rows: 16 rows x 64 groups, see below.
@@ -50,21 +52,32 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
   const int g = threadIdx.x / EPB, l16 = threadIdx.x & (EPB - 1);
   int bid = blockIdx.x;
   if (bid < tile_blocks) {
-    const int pair = bid / (BPT * NT);
+    const bool wide = emajor_mode == 3;
+    const int pair = wide ? 0 : bid / (BPT * NT);
     const int rem = bid - pair * BPT * NT;
     const int t = rem / BPT, part = rem - t * BPT;
     const int ga = pair_ga[pair], gb = pair_gb[pair];
-    const bool diag = (ga == gb);
-    const int ntile = diag ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : NT;
+    const bool diag = wide || (ga == gb);
+    const int ntw = wide_ntw(C);
+    const int ntile = wide ? ntw * (ntw + 1) / 2 : diag ? (GROUP_TILES * (GROUP_TILES + 1)) / 2 : NT;
     if (t >= ntile) return;
     int R, Tc;
-    schur_tile_rc(diag, t, R, Tc);
+    if (wide) wide_tile_rc(ntw, t, R, Tc);
+    else schur_tile_rc(diag, t, R, Tc);
     const int e = part * EPB + l16;                   // entry of the tile's register dump: lane = e>>2, reg = e&3
     const int rg = e & 3, lane = e >> 2;            // slab layout [tile][lane][reg]
-    const bool emajor = emajor_mode == 1 || (emajor_mode == 2 && diag);
-    const int i = emajor ? (ga * GROUP_CAMS + M_::row_of(lane, rg)) * NCP + R : ga * GROUP_ROWS + 16 * R + M_::row_of(lane, rg);
-    const int j = emajor ? (gb * GROUP_CAMS + (lane & 15)) * NCP + Tc : gb * GROUP_ROWS + 16 * Tc + (lane & 15);
-    const size_t stride = (size_t)NT * 256;
+    const bool emajor = wide || emajor_mode == 1 || (emajor_mode == 2 && diag);
+    int i, j;
+    if (wide) {                                       // compact rows: row = e C + c  ->  exchange index c * NCP + e
+      const int rho = 16 * R + M_::row_of(lane, rg), kap = 16 * Tc + (lane & 15);
+      const int er = rho / C, ek = kap / C;
+      i = rho < n ? (rho - er * C) * NCP + er : n;
+      j = kap < n ? (kap - ek * C) * NCP + ek : n;
+    } else {
+      i = emajor ? (ga * GROUP_CAMS + M_::row_of(lane, rg)) * NCP + R : ga * GROUP_ROWS + 16 * R + M_::row_of(lane, rg);
+      j = emajor ? (gb * GROUP_CAMS + (lane & 15)) * NCP + Tc : gb * GROUP_ROWS + 16 * Tc + (lane & 15);
+    }
+    const size_t stride = wide ? (size_t)WIDE_SLOTS * 256 : (size_t)NT * 256;
     const T* src = slabs + (size_t)pair * ksplit * stride + (size_t)t * 256 + e;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int k = g;
@@ -114,14 +127,16 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     const int i = bid * RB + lr;
     double b0 = 0, g0 = 0, d0 = 0;
     if (i < n) {
-      const int grp = i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;
+      const bool wide = emajor_mode == 3;
+      const int rstride = wide ? WIDE_ROWS : GROUP_ROWS;
+      const int grp = wide ? 0 : i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;
       const double* src = bpart + (size_t)grp * ksplit * GROUP_ROWS + rho;
       if (gdpart) {        // fused linearisation: g_c and diag(U) are per-workgroup partial rows laid out like bpart (one group)
         const double* gs_ = gdpart + rho;
         for (int k = gr; k < ksplit; k += RG) {
-          b0 += src[(size_t)k * GROUP_ROWS];
-          g0 += gs_[(size_t)k * 2 * GROUP_ROWS];
-          d0 += gs_[((size_t)k * 2 + 1) * GROUP_ROWS];
+          b0 += src[(size_t)k * rstride];
+          g0 += gs_[(size_t)k * 2 * rstride];
+          d0 += gs_[((size_t)k * 2 + 1) * rstride];
         }
       } else {
         for (int k = gr; k < ksplit; k += RG) b0 += src[(size_t)k * GROUP_ROWS];

@@ -1,0 +1,125 @@
+"""GPU: the one-launch fused linearise + Schur kernel for 17 .. 23 cameras (k_schur_fused_wide, csrc/sba_schur_wide.hpp) and the
+on-chip left-looking Cholesky behind it (k_cholesky_ll) -- the fp32 path of the reference's own rig shape (17 cameras,
+example/config.json:24-42).
+
+* the reduced camera system [S | rhs | diagU | g_c | cost] and the trial scalars of the wide kernel against the three-pass
+  path (SBA_NO_WIDE=1: k_linearize_* + pair kernels) on the same shuffled, weighted problem: agreement at fp32 rounding;
+* converged solves against the reference oracle (scipy, the reference's least_squares call) at the fp32 bar of SURVEY 8(d)
+  (cost 1e-4 relative) and against the fp64 engine; dense and sparse visibility; every tile count 12 .. 16;
+* Huber loss and fixed points go through the same kernel (extensions: against the three-pass path).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from lasercalib_amd import _native  # noqa: E402
+from lasercalib_amd.synth import make_rig  # noqa: E402
+from oracle import sba_oracle as orc  # noqa: E402
+
+
+def _system(rig, uv, ci, pi, wts, monkeypatch, no_wide, lam=1e-4):
+    if no_wide:
+        monkeypatch.setenv("SBA_NO_WIDE", "1")
+    else:
+        monkeypatch.delenv("SBA_NO_WIDE", raising=False)
+    torch.cuda.set_device(0)
+    with _native.Problem(rig["cams0"], rig["pts0"], uv, ci, pi, weights=wts, dtype="f32",
+                         stream=torch.cuda.current_stream().cuda_stream) as prob:
+        prob.lm_begin(prob.make_opts(ftol=1e-6, lambda0=lam))
+        prob.lm_linearize()
+        E = torch.zeros(prob.exchange_size(), dtype=torch.float64, device="cuda")
+        prob.lm_form_reduced(E.data_ptr())
+        sc = torch.zeros(8, dtype=torch.float64, device="cuda")
+        prob.lm_solve_trial(E.data_ptr(), sc.data_ptr())
+        torch.cuda.synchronize()
+        step = prob.lm_get_step().ravel().copy()
+        Eh, sch = E.cpu().numpy().copy(), sc.cpu().numpy().copy()
+        prob.lm_finish()
+    return Eh, sch, step
+
+
+@pytest.mark.parametrize("C,N,vis", [(17, 333, 1.0), (17, 500, 0.5), (18, 200, 1.0), (19, 203, 0.8), (20, 150, 1.0), (21, 97, 0.7),
+                                     (22, 120, 1.0), (23, 260, 0.6)])
+def test_wide_kernel_builds_the_three_pass_system(monkeypatch, C, N, vis):
+    rig = make_rig(C, N, seed=31 + C, visibility=vis)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(rig["camera_ind"].size)              # the upload must restore (point, camera) order
+    uv, ci, pi = rig["points_2d"][perm], rig["camera_ind"][perm], rig["point_ind"][perm]
+    wts = rng.uniform(0.5, 1.5, ci.size)
+    Ea, sa, da = _system(rig, uv, ci, pi, wts, monkeypatch, no_wide=False)
+    Eb, sb, db = _system(rig, uv, ci, pi, wts, monkeypatch, no_wide=True)
+    n = 11 * C
+    S_a, S_b = Ea[: n * n].reshape(n, n), Eb[: n * n].reshape(n, n)
+    assert np.array_equal(S_a, S_a.T)
+    scale = np.sqrt(np.outer(np.abs(np.diag(S_b)), np.abs(np.diag(S_b))))
+    assert np.max(np.abs(S_a - S_b) / scale) <= 2e-5             # fp32 sums of ~N terms in two different orders
+    for k, name in enumerate(("rhs", "diagU", "g_c")):
+        a, b = Ea[n * n + k * n: n * n + (k + 1) * n], Eb[n * n + k * n: n * n + (k + 1) * n]
+        assert np.max(np.abs(a - b)) <= 2e-5 * np.max(np.abs(b)), name
+    assert abs(Ea[-1] - Eb[-1]) <= 1e-6 * Eb[-1]                  # cost
+    assert np.max(np.abs(sa[:4] - sb[:4]) / (np.abs(sb[:4]) + 1e-30)) <= 1e-3        # trial cost, predicted reduction, step norms
+    assert np.max(np.abs(da - db)) <= 2e-3 * np.max(np.abs(db))   # camera step: the damped solve amplifies the 1e-5 of S
+
+
+@pytest.mark.parametrize("C,N,vis", [(17, 400, 1.0), (17, 600, 0.45), (20, 300, 0.7), (23, 250, 1.0)])
+def test_wide_path_converges_to_the_reference_solution(C, N, vis):
+    rig = make_rig(C, N, seed=9 + C, visibility=vis, min_cams_per_point=4)
+    args = (rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    with _native.Problem(rig["cams0"], rig["pts0"], *args, dtype="f32") as prob:
+        cams, pts, rep, log = prob.solve_lm(prob.make_opts(ftol=1e-4))
+    ref, _, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], *args, ftol=1e-4)
+    assert rep.status in (2, 3, 4)
+    assert abs(rep.cost - ref.cost) <= 1e-4 * ref.cost            # fp32 bar of SURVEY 8(d)
+    cost64 = 0.5 * np.sum(orc.fun(np.hstack((cams.ravel(), pts.ravel())), C, N, rig["camera_ind"], rig["point_ind"], rig["points_2d"], 1.0) ** 2)
+    assert abs(cost64 - rep.cost) <= 1e-4 * cost64                # the reported cost is the oracle's cost at the returned point
+    assert abs(orc.rms_reprojection(cams, pts, *args) - np.sqrt(2 * ref.cost / rig["camera_ind"].size)) <= 1e-3
+    with _native.Problem(rig["cams0"], rig["pts0"], *args, dtype="f64") as prob:
+        _, _, rep64, _ = prob.solve_lm(prob.make_opts(ftol=1e-4))
+    assert abs(rep.cost - rep64.cost) <= 1e-4 * rep64.cost
+
+
+def test_wide_path_full_size_17x50k_properties():
+    """The shape the timing quotes: 17 cameras x 50,000 points, dense."""
+    rig = make_rig(17, 50000, seed=0)
+    args = (rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    with _native.Problem(rig["cams0"], rig["pts0"], *args, dtype="f32") as prob:
+        r0, c0 = prob.residual()
+        cams, pts, rep, log = prob.solve_lm(prob.make_opts(ftol=1e-4))
+        r1, c1 = prob.residual(np.hstack((cams.ravel(), pts.ravel())))
+    assert rep.status == 2 and rep.cost < 1e-3 * c0 and abs(c1 - rep.cost) <= 1e-4 * c1
+    costs = [row.cost for row in log if row.accepted]
+    assert all(b <= a for a, b in zip(costs, costs[1:]))
+    rms = np.sqrt(np.mean(np.sum(r1.reshape(-1, 2) ** 2, axis=1)))
+    assert 0.35 < rms < 0.45                                      # 0.3 px noise per axis
+    intr, ratios = orc.gauge_invariants(cams)
+    intr_t, ratios_t = orc.gauge_invariants(rig["cams_true"])
+    assert np.max(np.abs(ratios - ratios_t)) <= 1e-3 and np.max(np.abs(intr[:, 0] - intr_t[:, 0])) <= 3.0
+
+
+def test_wide_path_with_huber_loss_and_fixed_points(monkeypatch):
+    rig = make_rig(17, 300, seed=4, visibility=0.8)
+    uv = rig["points_2d"].copy()
+    rng = np.random.default_rng(1)
+    bad = rng.choice(uv.shape[0], 30, replace=False)
+    uv[bad] += rng.normal(0, 40.0, (30, 2))
+    fixed = np.zeros(300, dtype=np.uint8)
+    fixed[:6] = 1
+
+    def run(no_wide):
+        if no_wide:
+            monkeypatch.setenv("SBA_NO_WIDE", "1")
+        else:
+            monkeypatch.delenv("SBA_NO_WIDE", raising=False)
+        with _native.Problem(rig["cams0"], rig["pts0"], uv, rig["camera_ind"], rig["point_ind"], dtype="f32") as prob:
+            prob.set_fixed_points(fixed)
+            prob.set_robust_loss("huber", 1.0)
+            cams, pts, rep, _ = prob.solve_lm(prob.make_opts(ftol=1e-6))
+        return cams, pts, rep
+
+    ca, pa, ra = run(False)
+    cb, pb, rb = run(True)
+    assert np.array_equal(pa[:6], rig["pts0"][:6]) and np.array_equal(pb[:6], rig["pts0"][:6])
+    assert abs(ra.cost - rb.cost) <= 1e-4 * rb.cost
