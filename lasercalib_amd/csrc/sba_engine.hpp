@@ -40,6 +40,7 @@ struct Engine : EngineBase {
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
   bool fused_bf3 = true;             // ... with the Schur products on the bf16 matrix pipe (k_schur_fused_bf3)
   bool fused_wide = false;           // 17 .. 23 cameras: k_schur_fused_wide (compact rows, one launch; implies fused_ok)
+  int wide_pw = 2;                   // ... points per producer wave: 3 (packed lanes, 12-point rounds) for 17 and 18 cameras, else 2
   DevBuf<double> gdpart;
   std::vector<int64_t> perm;          // pm position -> caller's observation index
   int nblk = 0, nchunk = 0, ngroups = 0, npairs = 0, ksplit = 1;
@@ -202,11 +203,13 @@ struct Engine : EngineBase {
 #if SBA_NCP == 11
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<12>::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<13>::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<14>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<14>::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<15>::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<16>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<12, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<12, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<13, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<13, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<14, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<14, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<15, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<15, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<16, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<12, 3>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<13, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<13, 3>::LDS_BYTES));
 #endif
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_diag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurPairCfg::LDS_BYTES));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_offdiag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3OffCfg::LDS_BYTES));
@@ -471,7 +474,8 @@ struct Engine : EngineBase {
       if (fused_wide) {
         int target = 256;
         if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
-        ksplit = std::max(1, std::min(target, (N + 7) / 8));
+        wide_pw = (wide_ntw(C) <= 13 && !getenv("SBA_WIDE_PW2")) ? 3 : 2;
+        ksplit = std::max(1, std::min(target, (N + 4 * wide_pw - 1) / (4 * wide_pw)));
       }
     }
 #endif
@@ -664,19 +668,22 @@ struct Engine : EngineBase {
       double* gm_out = nullptr;
       const FusedDecide fd = make_fused_decide(gm_out);
       const bool tables = !dense;
-      auto go = [&](auto ntw_c) {
-        constexpr int NTW = decltype(ntw_c)::value;
-        hipLaunchKernelGGL(k_schur_fused_wide<NTW>, dim3(ksplit), dim3(SCHUR_THREADS), SchurWideCfg<NTW>::LDS_BYTES, stream,
+      auto go = [&](auto ntw_c, auto pw_c) {
+        constexpr int NTW = decltype(ntw_c)::value, PW = decltype(pw_c)::value;
+        constexpr size_t lds = SchurWideCfg<NTW, PW>::LDS_BYTES;
+        hipLaunchKernelGGL((k_schur_fused_wide<NTW, PW>), dim3(ksplit), dim3(SCHUR_THREADS), lds, stream,
                            ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, tables ? grp_mask.p : (const uint16_t*)nullptr,
                            tables ? grp_start.p : (const int32_t*)nullptr, N, ksplit, D2p.p, gp.p, pfac.p, slabs.p, bpart.p, gdpart.p,
                            cost_part.p, gm_out, (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr);
       };
+      using P2 = std::integral_constant<int, 2>;
+      using P3 = std::integral_constant<int, 3>;
       switch (wide_ntw(C)) {
-        case 12: go(std::integral_constant<int, 12>{}); break;
-        case 13: go(std::integral_constant<int, 13>{}); break;
-        case 14: go(std::integral_constant<int, 14>{}); break;
-        case 15: go(std::integral_constant<int, 15>{}); break;
-        default: go(std::integral_constant<int, 16>{}); break;
+        case 12: if (wide_pw == 3) go(std::integral_constant<int, 12>{}, P3{}); else go(std::integral_constant<int, 12>{}, P2{}); break;
+        case 13: if (wide_pw == 3) go(std::integral_constant<int, 13>{}, P3{}); else go(std::integral_constant<int, 13>{}, P2{}); break;
+        case 14: go(std::integral_constant<int, 14>{}, P2{}); break;
+        case 15: go(std::integral_constant<int, 15>{}, P2{}); break;
+        default: go(std::integral_constant<int, 16>{}, P2{}); break;
       }
       d_state.p = fd.st_out;
       pending_decide = false;

@@ -17,6 +17,10 @@
 //             tiles stay in registers for the k-step, the column tiles beyond them stream through a double-buffered 3-plane
 //             fragment set; six bf16 MFMAs per tile (h h', m h', l h', h m', m m', h l');
 //   prologue  the LM decision of the previous step (FusedDecide), as in k_schur_fused_bf3.
+// PW = 3 (17 and 18 cameras, <= 13 tiles): THREE points per wave, packed -- lane l serves point l / C, camera l % C -- so that 51
+// or 54 of the 64 lanes work instead of 34 or 36.  A round then covers 12 points = one and a half k-steps: the k-step buffers
+// form a ring of four, a round writes wherever its points fall, and the consumers take whatever k-steps the rounds so far have
+// completed (one or two per barrier interval).  The per-point sums become segment sums of a wave-wide DPP prefix scan.
 // Outputs: slabs [workgroup][tile][lane][reg] (k_build_exchange, emajor_mode 3 maps row -> (camera, parameter)), and
 // bpart / gdpart rows in the exchange buffer's own order with a row stride of WIDE_ROWS.
 #pragma once
@@ -25,20 +29,22 @@
 #if SBA_NCP == 11
 namespace SBA_NS {
 
-template <int NTW> struct SchurWideCfg {
+template <int NTW, int PW = 2> struct SchurWideCfg {
   using elem = float;
   static constexpr int THREADS = SCHUR_THREADS, NPROD = 256, NV = 4;
   static constexpr int NTILE = NTW * (NTW + 1) / 2;
   static constexpr int TPW = (NTILE + NV - 1) / NV;
-  static constexpr int PTS = 8;                                   // points per round = one k-step
+  static constexpr int PTS = 4 * PW;                              // points per round: 8 = one k-step, 12 = one and a half
+  static constexpr int NBUF = PW == 3 ? 4 : 2;                    // k-step buffers (ring)
   static constexpr int HALF_BYTES = 16 * 32, TILE_BYTES = 2 * HALF_BYTES, PLANE_BYTES = NTW * TILE_BYTES;
   static constexpr int BUF_BYTES = 3 * PLANE_BYTES;
   static constexpr int UPKB = UPK + NCP, UPKS = UPKB | 1;
-  static constexpr int MAXC = 32;
+  static constexpr int MAXC = 24;                                 // cameras the camera table and the hand-over area are sized for (<= 23 used)
   static constexpr size_t HAND_BYTES = (size_t)(NPROD + MAXC) * UPKS * sizeof(float);          // accumulator hand-over area
-  static constexpr size_t PANEL_BYTES = 2 * (size_t)BUF_BYTES > HAND_BYTES ? 2 * (size_t)BUF_BYTES : HAND_BYTES;
+  static constexpr size_t PANEL_BYTES = NBUF * (size_t)BUF_BYTES > HAND_BYTES ? NBUF * (size_t)BUF_BYTES : HAND_BYTES;
   static constexpr size_t LDS_BYTES = PANEL_BYTES + (size_t)MAXC * CAMPRE * sizeof(float);
-  static_assert(LDS_BYTES + 2048 <= 160 * 1024, "panels + camera table must fit the LDS");
+  static_assert(LDS_BYTES + 1024 <= 160 * 1024, "panels + camera table must fit the LDS");
+  static_assert(PW == 2 || PW == 3, "two points per wave (32-lane halves) or three (packed)");
 };
 // row-major enumeration of the upper triangle of an NTW x NTW tile grid
 template <int NTW> __host__ __device__ constexpr int wide_tile_R(int t) {
@@ -59,7 +65,23 @@ __device__ __forceinline__ float half32_sum(float v) {
   return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 
-template <int NTW>
+// inclusive prefix sum over the 64 lanes of the wave: Hillis-Steele inside every DPP row (row_shr 1, 2, 4, 8; lanes shifted in from
+// outside the row read 0), then the row totals travel on: row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3
+__device__ __forceinline__ float wave_scan(float v) {
+  auto dpp = [](float x, auto ctrl, auto rmask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true));
+  };
+  using I = std::integral_constant<int, 0xf>;
+  v += dpp(v, std::integral_constant<int, 0x111>{}, I{});      // row_shr:1
+  v += dpp(v, std::integral_constant<int, 0x112>{}, I{});      // row_shr:2
+  v += dpp(v, std::integral_constant<int, 0x114>{}, I{});      // row_shr:4
+  v += dpp(v, std::integral_constant<int, 0x118>{}, I{});      // row_shr:8
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});      // row_bcast:15 -> rows 1, 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});      // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+template <int NTW, int PW>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
     const ParamSets<float> ps, const FusedDecide fd, int C,
     const float2* __restrict__ uv, const float* __restrict__ w,
@@ -70,7 +92,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
     double* __restrict__ cost_part, double* __restrict__ gmax_part, long long* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem[];
   using T = float;
-  using Cfg = SchurWideCfg<NTW>;
+  using Cfg = SchurWideCfg<NTW, PW>;
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, UPKB = Cfg::UPKB, UPKS = Cfg::UPKS;
   const bool stamp_wg = dbg && blockIdx.x == 0;
   if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();
@@ -96,7 +118,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
     if (fd.do_decide) decide_gather(dp, fd.scal_all, fd.trial_part, fd.gmax_in, fd.n_trial, fd.n_gmax);
     {   // zero both k-step buffers meanwhile: padding rows and the slots of absent points are never written
       uint4* z4 = reinterpret_cast<uint4*>(smem);
-      for (int i = threadIdx.x; i < 2 * Cfg::BUF_BYTES / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
+      for (int i = threadIdx.x; i < Cfg::NBUF * Cfg::BUF_BYTES / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
     }
     asm volatile("" : "+v"(dp.a), "+v"(dp.b), "+v"(dp.c), "+v"(dp.d), "+v"(dp.g));
     __syncthreads();
@@ -124,13 +146,16 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
   const T* __restrict__ ptsT = ps.ptsT[cur_];
   for (int i = threadIdx.x; i < C * CAMPRE; i += THREADS) s_cam[i] = ps.campre[cur_][i];
   const T lam = (T)st->lam;
-  // the 8 lanes that served camera c (4 waves x 2 halves) fold their accumulators
+  // the 4 PW lanes that served camera c (4 waves x PW points) fold their accumulators
   auto fold_u = [&]() {
     for (int o = threadIdx.x; o < C * UPKB; o += THREADS) {
       const int c = o / UPKB, k = o - c * UPKB;
       T sum = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) sum += s_U[(q * 32 + c) * UPKS + k];
+      for (int q = 0; q < 4 * PW; ++q) {
+        const int t = PW == 2 ? q * 32 + c : (q / 3) * 64 + (q % 3) * C + c;
+        sum += s_U[t * UPKS + k];
+      }
       s_Ured[o] = sum;
     }
   };
@@ -138,8 +163,22 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
   __syncthreads();
 
   if (producer) {
-    const int q = threadIdx.x >> 5, c = threadIdx.x & 31;                // point of the round (0..7), camera slot
-    const bool cam_ok = c < C;
+    // point of the round, camera slot.  PW = 2: one point per 32-lane half; PW = 3: lane l of the wave -> point l / C, camera l % C
+    const int hseg = PW == 2 ? (lane >> 5) : ((lane >= C) + (lane >= 2 * C) + (lane >= 3 * C));
+    const int q = PW * wid + min(hseg, PW - 1);
+    const int c = PW == 2 ? (lane & 31) : lane - hseg * C;
+    const bool cam_ok = PW == 2 ? c < C : hseg < 3;
+    auto point_sum = [&](T v) -> T {
+      if constexpr (PW == 2) return half32_sum(v);
+      else {
+        const T sc = wave_scan(v);
+        const int si = __builtin_bit_cast(int, sc);
+        const T e0 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(si, C - 1));
+        const T e1 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(si, 2 * C - 1));
+        const T e2 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(si, 3 * C - 1));
+        return hseg == 0 ? e0 : hseg == 1 ? e1 - e0 : e2 - e1;
+      }
+    };
     const T* cp_safe = s_cam + (cam_ok ? c : 0) * CAMPRE;
     const int grp = c >> 4, cc = c & 15;
     const uint16_t* __restrict__ gm = gmask ? gmask + (size_t)grp * N : nullptr;
@@ -177,15 +216,35 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
     request(0);
     // byte offset of this lane's 8-byte point slot inside a plane, for parameter e: row e C + c -> tile, row of the tile; the
     // point of the round is the lane's own for the whole kernel (half q >> 2, slot (q & 3) ^ ((row >> 2) & 3))
+    // (PW = 3: the point's place inside its k-step changes from round to round; slot_off then holds the row part with the row's
+    //  swizzle bits, and the round adds buffer, half and slot)
     int slot_off[NCP];
 #pragma unroll
     for (int e = 0; e < NCP; ++e) {
-      const int row = e * C + c, i = row & 15;
-      slot_off[e] = (row >> 4) * Cfg::TILE_BYTES + (q >> 2) * Cfg::HALF_BYTES + i * 32 + (((q & 3) ^ ((i >> 2) & 3)) << 3);
+      const int row = e * (cam_ok ? C : 0) + (cam_ok ? c : 0), i = row & 15;
+      if constexpr (PW == 2) slot_off[e] = (row >> 4) * Cfg::TILE_BYTES + (q >> 2) * Cfg::HALF_BYTES + i * 32 + (((q & 3) ^ ((i >> 2) & 3)) << 3);
+      else slot_off[e] = (row >> 4) * Cfg::TILE_BYTES + i * 32 + (((i >> 2) & 3) << 3);
     }
     for (int it = 0; it <= nchunk; ++it) {
       if (it < nchunk) {
-        unsigned char* pbuf = smem + (it & 1) * Cfg::BUF_BYTES;
+        unsigned char* pbuf;
+        int sxor = 0;
+        if constexpr (PW == 2) pbuf = smem + (it & 1) * Cfg::BUF_BYTES;
+        else {
+          const int g = it * PTS + q, kk = g >> 3, sp = g & 7;             // k-step of the point, its place in it
+          pbuf = smem + (kk & 3) * Cfg::BUF_BYTES + (sp >> 2) * Cfg::HALF_BYTES;
+          sxor = (sp & 3) << 3;
+          if ((nchunk & 1) && it == nchunk - 1) {
+            // an odd number of rounds leaves the last k-step half filled: its second half (points 4..7) still holds what the ring
+            // slot carried four k-steps ago -- zero it now (nobody reads that slot during this round)
+            const int kl = (nchunk * PTS) >> 3;
+            unsigned char* zb = smem + (kl & 3) * Cfg::BUF_BYTES + Cfg::HALF_BYTES;
+            for (int i = threadIdx.x; i < 3 * NTW * (Cfg::HALF_BYTES / 16); i += NPROD) {
+              const int blk = i / (Cfg::HALF_BYTES / 16), off = i - blk * (Cfg::HALF_BYTES / 16);
+              *reinterpret_cast<uint4*>(zb + blk * Cfg::TILE_BYTES + off * 16) = make_uint4(0, 0, 0, 0);
+            }
+          }
+        }
         const bool valid = n_valid, have_pt = n_pt;
         const float2 m = n_uv;
         const T ww = n_w, X0 = n_X[0], X1 = n_X[1], X2 = n_X[2];
@@ -196,15 +255,15 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
         obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
         sq += robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
         T v6[6], g3[3];
-        v6[0] = half32_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
-        v6[1] = half32_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
-        v6[2] = half32_sum(Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2]);
-        v6[3] = half32_sum(Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1]);
-        v6[4] = half32_sum(Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2]);
-        v6[5] = half32_sum(Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2]);
-        g3[0] = half32_sum(Jp[0][0] * r[0] + Jp[1][0] * r[1]);
-        g3[1] = half32_sum(Jp[0][1] * r[0] + Jp[1][1] * r[1]);
-        g3[2] = half32_sum(Jp[0][2] * r[0] + Jp[1][2] * r[1]);
+        v6[0] = point_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
+        v6[1] = point_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
+        v6[2] = point_sum(Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2]);
+        v6[3] = point_sum(Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1]);
+        v6[4] = point_sum(Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2]);
+        v6[5] = point_sum(Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2]);
+        g3[0] = point_sum(Jp[0][0] * r[0] + Jp[1][0] * r[1]);
+        g3[1] = point_sum(Jp[0][1] * r[0] + Jp[1][1] * r[1]);
+        g3[2] = point_sum(Jp[0][2] * r[0] + Jp[1][2] * r[1]);
         const bool fixedp = have_pt && pt_fixed(ps, (size_t)p);
         if (!fixedp) gmx = fmaxf(gmx, fmaxf(fabsf(g3[0]), fmaxf(fabsf(g3[1]), fabsf(g3[2]))));
         const double E0 = fmax(D0, (double)v6[0]), E1 = fmax(D1, (double)v6[3]), E2 = fmax(D2, (double)v6[5]);
@@ -222,7 +281,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
           f[8] = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
           f[9] = (T)1;
         }
-        if (have_pt && c == 0) {
+        if (have_pt && cam_ok && c == 0) {
           D2p[3 * (size_t)p] = E0; D2p[3 * (size_t)p + 1] = E1; D2p[3 * (size_t)p + 2] = E2;
           gp[3 * (size_t)p] = (double)g3[0]; gp[3 * (size_t)p + 1] = (double)g3[1]; gp[3 * (size_t)p + 2] = (double)g3[2];
           float4* o4 = reinterpret_cast<float4*>(pf + (size_t)p * PF);
@@ -261,7 +320,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
             const unsigned m01 = pk(r0, r1), m2 = pk1(r2);
             const float s0 = r0 - lo_f(m01), s1 = r1 - hi_f(m01), s2 = r2 - lo_f(m2);
             const unsigned l01 = pk(s0, s1), l2 = pk1(s2);
-            unsigned char* dst = pbuf + slot_off[e];
+            unsigned char* dst = pbuf + (PW == 2 ? slot_off[e] : (slot_off[e] ^ sxor));
             *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h2);
             *reinterpret_cast<uint2*>(dst + Cfg::PLANE_BYTES) = make_uint2(m01, m2);
             *reinterpret_cast<uint2*>(dst + 2 * Cfg::PLANE_BYTES) = make_uint2(l01, l2);
@@ -298,9 +357,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
     const int frag_off = (lane & 15) * 32 + (((lane >> 4) ^ (((lane & 15) >> 2) & 3)) << 3);
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    for (int it = 0; it <= nchunk; ++it) {
-      if (it >= 1) {
-        const unsigned char* pbuf = smem + ((it - 1) & 1) * Cfg::BUF_BYTES + frag_off;
+    auto process = [&](const unsigned char* pbuf) {
         static_for<0, Cfg::NV>([&](auto vc) {
           constexpr int V = decltype(vc)::value;
           if (cw == V) {
@@ -353,6 +410,17 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
             });
           }
         });
+    };
+    int kprev = 0;
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it >= 1) {
+        if constexpr (PW == 2) process(smem + ((it - 1) & 1) * Cfg::BUF_BYTES + frag_off);
+        else {
+          // k-steps the rounds before this one have completed (the last interval also takes the half-filled one)
+          const int kd = it == nchunk ? (nchunk * PTS + 7) >> 3 : (it * PTS) >> 3;
+          for (int kk = kprev; kk < kd; ++kk) process(smem + (kk & 3) * Cfg::BUF_BYTES + frag_off);
+          kprev = kd;
+        }
       }
       if (stamp_wg && threadIdx.x == NPROD && it < 20) dbg[2 * it + 1] = clock64();
       __syncthreads();

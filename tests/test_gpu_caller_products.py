@@ -54,7 +54,7 @@ def test_solve_and_exports_on_the_example_rig(tmp_path, capsys):
     assert sba.cameraArray.shape == (17, 11) and sba.pointWeights.shape == (ci.size, 1)
     err0 = report.reprojection_errors(sba)                        # device project kernel
     assert np.max(np.abs(err0 - io_oracle.reprojection_errors(orc.project, p3, P["cams0"], p2, ci, pi))) <= 1e-7
-    assert report.camera_extrinsics(sba).shape == (17, 6)
+    assert report.camera_extrinsics(sba).shape == (17, 4, 4)
     assert sba.bundleAdjust(1e-4) is not None                     # callers ignore the return value; it is scipy-shaped anyway
     out = capsys.readouterr().out
     assert "`ftol` termination condition is satisfied." in out or "`xtol`" in out

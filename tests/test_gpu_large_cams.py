@@ -138,6 +138,7 @@ def test_indexed_group_producers_equal_the_scanning_ones(C, N, vis, dtype, monke
         with _native.Problem(*args, dtype=dtype) as prob:
             return prob.solve_lm(prob.make_opts(ftol=1e-6))
 
+    monkeypatch.setenv("SBA_NO_WIDE", "1")            # 20 cameras would otherwise take k_schur_fused_wide (tests/test_gpu_wide.py): this test is about the pair kernels
     monkeypatch.setenv("SBA_NO_BF3_PAIRS", "1")       # same consumer kernels on both sides (fp32 diagonal pairs: f32-input MFMAs)
     cams_i, pts_i, rep_i, log_i = run(a)
     monkeypatch.setenv("SBA_SCHUR_SCAN", "1")
@@ -165,6 +166,7 @@ def test_group_pairs_on_the_bf16_pipe_follow_the_f32_mfma_kernels(C, N, vis, tan
     rig = make_rig(C, N, seed=33, visibility=vis, tangential=tangential)
     a = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
     kw = dict(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=6, always_relinearize=True)
+    monkeypatch.setenv("SBA_NO_WIDE", "1")            # (20 cameras: keep the pair kernels this test is about; the wide kernel has tests/test_gpu_wide.py)
 
     def run(dtype):
         with _native.Problem(*a, dtype=dtype) as prob:

@@ -43,6 +43,18 @@ def test_project13_matches_oracle_and_reduces_to_the_reference_model():
     assert np.max(np.abs(uv32 - uv)) <= 3e-3
 
 
+def test_device_project13_against_exact_opencv_formula_vectors():
+    """F8 (oracle/make_opencv_vectors.py): OpenCV's published model in exact rational arithmetic, exact rotations."""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "f8_opencv_tangential.json")))
+    P = np.array([r["point"] for r in d["rows"]])
+    cam = np.array([r["camera"] for r in d["rows"]])
+    uv = np.array([r["uv"] for r in d["rows"]])
+    assert np.max(np.abs(_native.project_rows(P, cam) - uv)) <= 1e-9
+    assert np.max(np.abs(_native.project_rows(P, cam, dtype="f32") - uv)) <= 3e-3
+
+
 @pytest.mark.parametrize("C,N,vis", [(3, 60, 0.8), (16, 40, 1.0), (20, 50, 0.6)])
 def test_residual_and_jacobian_13_vs_oracle_fd(C, N, vis):
     rig = make_rig(C, N, seed=21, visibility=vis, tangential=True)

@@ -1,6 +1,8 @@
 """CPU: the oracle (oracle/sba_oracle.py) is pinned against fixtures produced by the reference itself
 (oracle/make_golden.py imports /root/reference/lasercalib/pySBA.py), and the numpy model of the device
 algorithm (oracle/lm_schur_model.py) is pinned against the same fixtures."""
+import os
+
 import numpy as np
 import pytest
 import scipy
@@ -139,3 +141,20 @@ def test_tangential_oracle_is_the_reference_model_plus_one_term(golden):
     dy = 1e-3 * (r2 + 2 * y * y) - 2 * 2e-3 * x * y
     extra = np.stack([dx, dy], axis=1) * rows[:, 6:7]
     assert np.max(np.abs(t13.project(g["points"], rows13)[far] - (g["projected"] + extra)[far])) <= 1e-9
+
+
+def test_tangential_oracle_against_exact_opencv_formula_vectors():
+    """F8: the only pin the 13-parameter extension can have -- the published OpenCV formula evaluated in exact rational
+    arithmetic (oracle/make_opencv_vectors.py), poses with exact rotations.  The last row has p1 = p2 = 0 and must also be the
+    11-parameter reference model's value."""
+    import json
+    from oracle import sba_oracle_tangential as orc13
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "f8_opencv_tangential.json")))
+    P = np.array([r["point"] for r in d["rows"]])
+    cam = np.array([r["camera"] for r in d["rows"]])
+    uv = np.array([r["uv"] for r in d["rows"]])
+    assert np.max(np.abs(orc13.project(P, cam) - uv)) <= 1e-9
+    last = cam[-1]
+    assert last[9] == 0 and last[10] == 0
+    row11 = np.hstack([last[:9], last[11:13]])
+    assert np.max(np.abs(orc.project(P[-1:], row11[None]) - uv[-1:])) <= 1e-9
