@@ -152,7 +152,8 @@ def roofline_of_step(kt, dtype, P, C, Nloc, M_local, shape):
         ach = flops_mfma / (kt["schur"] * 1e-6) / 1e12                     # roofline fraction = MFMA work only
         bf3 = fused and dtype == "f32" and os.environ.get("SBA_FUSED_MFMA", "bf3") != "f32"
         if fused:
-            kname = "k_schur_fused_bf3" if bf3 else "k_schur_fused"
+            wide = C > 16 or P == 13        # csrc/sba_schur_wide.hpp: 17 .. 23 cameras, and every one-launch rig of the 13-parameter model
+            kname = "k_schur_fused_wide" if (wide and bf3) else "k_schur_fused_bf3" if bf3 else "k_schur_fused"
         elif dtype == "f64":
             kname = "k_schur_sym<double>"
         else:

@@ -172,10 +172,8 @@ struct Engine : EngineBase {
     d_state_buf.alloc(2);
     d_state.p = d_state_buf.p;
     if (getenv("SBA_DECIDE_KERNEL")) defer_decide = false;
-#if SBA_NCP == 11
     // SBA_FUSED_MFMA=f32 keeps the f32-input MFMA kernel (A/B measurements, equivalence test); default: bf16 x 3 split
     if (const char* e = getenv("SBA_FUSED_MFMA")) fused_bf3 = (std::string(e) != "f32");
-#endif
     if (const char* e = getenv("SBA_CHOL")) {
       chol_old = (std::string(e) == "old"); chol_ll = (std::string(e) != "blocked") && !chol_old; chol_ll_all = (std::string(e) == "ll");
     }
@@ -203,6 +201,7 @@ struct Engine : EngineBase {
 #if SBA_NCP == 11
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_fused)));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3Cfg::LDS_BYTES));
+#endif
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<12, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<12, 2>::LDS_BYTES));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<13, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<13, 2>::LDS_BYTES));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<14, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<14, 2>::LDS_BYTES));
@@ -210,7 +209,8 @@ struct Engine : EngineBase {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<16, 2>::LDS_BYTES));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<12, 3>::LDS_BYTES));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<13, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<13, 3>::LDS_BYTES));
-#endif
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<8, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide<8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWideCfg<8, 3>::LDS_BYTES));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_diag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurPairCfg::LDS_BYTES));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_offdiag_bf3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurBf3OffCfg::LDS_BYTES));
     }
@@ -464,21 +464,22 @@ struct Engine : EngineBase {
       sync();
       grp_indexed = (flag == 0);     // cameras strictly ascending inside every point; otherwise the producers scan
     }
-    // 17 .. 23 cameras (<= 256 rows), f32, 11 parameters: the one-launch fused kernel of sba_schur_wide.hpp.  Like the masked
+    // Up to 256 reduced-system rows, f32: the one-launch fused kernel of sba_schur_wide.hpp -- 17 .. 23 cameras of the 11-parameter
+    // model (one group has k_schur_fused_bf3), every rig of up to 19 cameras of the 13-parameter model.  Like the masked
     // one-group kernel its producer cost does not shrink with the visibility, so below ~35 % the three-pass path stays.
     fused_wide = false;
-#if SBA_NCP == 11
     if constexpr (sizeof(T) == 4) {
-      fused_wide = C > GROUP_CAMS && C * NCP <= 16 * WIDE_MAX_NTW && N > 0 && fused_bf3 && !getenv("SBA_NO_FUSED") && !getenv("SBA_NO_WIDE") &&
-                   (dense || (grp_indexed && (double)M >= 0.35 * (double)N * C));
+      const bool dense_enough = (double)M >= 0.35 * (double)N * C;
+      const bool rig_ok = C > GROUP_CAMS ? (dense || (grp_indexed && dense_enough))
+                                         : (NCP != 11 && !getenv("SBA_NO_DENSE") && (dense || (masked_ok && dense_enough)));
+      fused_wide = rig_ok && C * NCP <= 16 * WIDE_MAX_NTW && N > 0 && fused_bf3 && !getenv("SBA_NO_FUSED") && !getenv("SBA_NO_WIDE");
       if (fused_wide) {
         int target = 256;
         if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
-        wide_pw = (wide_ntw(C) <= 13 && !getenv("SBA_WIDE_PW2")) ? 3 : 2;
+        wide_pw = (wide_ntw(C) <= 13 && 3 * C <= 64 && !getenv("SBA_WIDE_PW2")) ? 3 : 2;
         ksplit = std::max(1, std::min(target, (N + 4 * wide_pw - 1) / (4 * wide_pw)));
       }
     }
-#endif
 
     for (int b = 0; b < 2; ++b) {
       cams[b].alloc((size_t)C * NCP); pts[b].alloc((size_t)N * 3);
@@ -500,7 +501,7 @@ struct Engine : EngineBase {
     fused_ok = (NCP == 11 && (dense_one_group || masked_fused) && sizeof(T) == 4 && !getenv("SBA_NO_FUSED")) || fused_wide;
     fused_masked = fused_ok && !dense_one_group && !fused_wide;
     lin_pts_ok = (dense_one_group || masked_fused) && SCHUR_LIN_OK<T> && !getenv("SBA_NO_FUSED");
-    if (fused_masked || (lin_pts_ok && !dense_one_group)) vis_mask.upload(vmask, stream);
+    if (fused_masked || (lin_pts_ok && !dense_one_group) || (fused_wide && C <= GROUP_CAMS && !dense)) vis_mask.upload(vmask, stream);
     if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * (fused_wide ? WIDE_ROWS : GROUP_ROWS));
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1)); gmax_alt.alloc(std::max(std::max(nblk, ksplit), 1));
     trial_part.alloc((size_t)4 * std::max(nblk, 1));
@@ -576,10 +577,12 @@ struct Engine : EngineBase {
   bool lin_pts() const { return lin_pts_ok && h_state && h_state->free_cams; }   // f64: points linearised inside k_schur_sym
   int n_lin_parts() const { return (fused() || lin_pts()) ? ksplit : nblk; }       // entries of cost_part / gmax_part
   void launch_schur() {
+    if constexpr (sizeof(T) == 4) {
+      if (fused() && fused_wide) { launch_schur_wide(); return; }
+    }
 #if SBA_NCP == 11
     if constexpr (sizeof(T) == 4) {
       if (fused()) {
-        if (fused_wide) { launch_schur_wide(); return; }
         if (fused_bf3) {
           FusedDecide fd{};
           fd.st_in = fd.st_out = d_state.p;
@@ -647,7 +650,6 @@ struct Engine : EngineBase {
     }
     launch_schur_kernels<false>();
   }
-#if SBA_NCP == 11
   FusedDecide make_fused_decide(double*& gm_out) {
     FusedDecide fd{};
     fd.st_in = fd.st_out = d_state.p;
@@ -667,18 +669,22 @@ struct Engine : EngineBase {
     if constexpr (sizeof(T) == 4) {
       double* gm_out = nullptr;
       const FusedDecide fd = make_fused_decide(gm_out);
+      // sparse rigs: per (16-camera group, point) visibility mask + index of the point's first observation in the group -- the
+      // k_group_index tables with several groups, the one-group mask and the point's start otherwise
       const bool tables = !dense;
+      const uint16_t* tmask = !tables ? nullptr : C > GROUP_CAMS ? grp_mask.p : vis_mask.p;
+      const int32_t* tstart = !tables ? nullptr : C > GROUP_CAMS ? grp_start.p : pt_start.p;
       auto go = [&](auto ntw_c, auto pw_c) {
         constexpr int NTW = decltype(ntw_c)::value, PW = decltype(pw_c)::value;
         constexpr size_t lds = SchurWideCfg<NTW, PW>::LDS_BYTES;
         hipLaunchKernelGGL((k_schur_fused_wide<NTW, PW>), dim3(ksplit), dim3(SCHUR_THREADS), lds, stream,
-                           ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, tables ? grp_mask.p : (const uint16_t*)nullptr,
-                           tables ? grp_start.p : (const int32_t*)nullptr, N, ksplit, D2p.p, gp.p, pfac.p, slabs.p, bpart.p, gdpart.p,
+                           ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, tmask, tstart, N, ksplit, D2p.p, gp.p, pfac.p, slabs.p, bpart.p, gdpart.p,
                            cost_part.p, gm_out, (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr);
       };
       using P2 = std::integral_constant<int, 2>;
       using P3 = std::integral_constant<int, 3>;
       switch (wide_ntw(C)) {
+        case 8: if (wide_pw == 3) go(std::integral_constant<int, 8>{}, P3{}); else go(std::integral_constant<int, 8>{}, P2{}); break;
         case 12: if (wide_pw == 3) go(std::integral_constant<int, 12>{}, P3{}); else go(std::integral_constant<int, 12>{}, P2{}); break;
         case 13: if (wide_pw == 3) go(std::integral_constant<int, 13>{}, P3{}); else go(std::integral_constant<int, 13>{}, P2{}); break;
         case 14: go(std::integral_constant<int, 14>{}, P2{}); break;
@@ -701,9 +707,6 @@ struct Engine : EngineBase {
       }
     }
   }
-#else
-  void launch_schur_wide() {}
-#endif
   template <bool PARTIAL> void launch_schur_kernels() {
     using CfgD = SchurSel<T, true>;
     using CfgO = SchurSel<T, false>;
@@ -1255,13 +1258,7 @@ struct Engine : EngineBase {
   // several camera groups, fp32, indexed producers: the group pairs run on the bf16 pipe (k_schur_diag_bf3 / k_schur_offdiag_bf3)
   bool diag_pairs_bf3() const { return sizeof(T) == 4 && ngroups > 1 && grp_indexed && !fused() && !no_bf3_pairs; }
   bool offdiag_pairs_bf3() const { return diag_pairs_bf3() && !no_bf3_offdiag; }
-  bool bf3_path() const {
-#if SBA_NCP == 11
-    return sizeof(T) == 4 && fused() && fused_bf3 && !sq_mode();
-#else
-    return false;
-#endif
-  }
+  bool bf3_path() const { return sizeof(T) == 4 && fused() && fused_bf3 && !sq_mode(); }
   const double* gmax_rd() const { return (bf3_path() && gmax_cur) ? gmax_cur : gmax_part.p; }
   void launch_decide(const double* scal_all, int n_ranks) {
     hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(DECIDE_THREADS), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,

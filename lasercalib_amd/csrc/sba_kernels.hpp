@@ -37,7 +37,8 @@ constexpr int NSCAL = 8;
 constexpr int WIDE_ROWS = 256;
 constexpr int WIDE_MAX_NTW = 16;
 constexpr int WIDE_SLOTS = WIDE_MAX_NTW * (WIDE_MAX_NTW + 1) / 2;
-__host__ __device__ constexpr int wide_ntw(int C) { return (C * NCP + 15) / 16; }
+// (tile counts the kernel is instantiated for: 8, 12, 13, 14, 15, 16 -- a smaller rig runs the next larger one, its surplus tiles stay zero)
+__host__ __device__ constexpr int wide_ntw(int C) { const int t = (C * NCP + 15) / 16; return t <= 8 ? 8 : t <= 12 ? 12 : t; }
 __host__ __device__ inline void wide_tile_rc(int ntw, int t, int& R, int& Tc) {      // row-major enumeration of the upper tile triangle
   int r = 0, rem = t;
   while (rem >= ntw - r) { rem -= ntw - r; ++r; }
@@ -1418,6 +1419,25 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
+constexpr int UPK = NCP * (NCP + 1) / 2 + NCP;                 // per-lane U_c (upper triangle) + g_c accumulators of the fused kernels: 77 (104)
+// The accept/reject decision of the PREVIOUS trial step can ride in this kernel's prologue (do_decide): every workgroup reads
+// the untouched record st_in and the trial partials, runs decide_core on its own LDS copy -- same inputs, same summation
+// order, same decision everywhere -- and workgroup 0 publishes the updated record to st_out (the other slot of a two-entry
+// buffer: nothing a late workgroup still has to read is overwritten; for the same reason the gradient maxima this kernel
+// writes go to a different array than the one the decision reads) and appends the log row.  That takes the k_decide launch
+// (6.6 us of mostly launch and memory latency) out of the iteration for one more dependent read in front of the camera load.
+struct FusedDecide {
+  const LMState* st_in;          // record before the decision (never written by this kernel)
+  LMState* st_out;               // where workgroup 0 publishes it afterwards (== st_in when do_decide == 0: nothing is written)
+  int do_decide;
+  const double* scal_all;        // multi-rank: gathered scalars [n_ranks][NSCAL], else NULL
+  int n_ranks;
+  const double* trial_part;      // [4][n_trial] partials of the trial kernel
+  const double* gmax_in;         // [n_gmax] gradient maxima of the previous linearisation
+  int n_trial, n_gmax;
+  LMLogRow* log;
+  int log_cap;
+};
 #if SBA_NCP == 11
 // ------------------------------------------------------------------ K3+K4 fused (dense visibility, <= 16 cameras, f32)
 // When every point is seen by every camera and there is one camera group, the producer lane (q, c) = (point of the
@@ -1431,7 +1451,6 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 //     (Upart2[wg][c][77]); k_build_exchange sums the partials in the same fixed-order loop as the slabs.
 // The two roles are split at the top level (same number of barriers on both sides), so the producers' 77 accumulators
 // and the consumers' 68 MFMA accumulator registers share the register file instead of adding up.
-constexpr int UPK = NCP * (NCP + 1) / 2 + NCP;                 // 77
 template <typename T> struct SchurFusedCfg : SchurCfg<T, true> {
   static constexpr size_t LDS_BYTES = SchurCfg<T, true>::LDS_BYTES + (size_t)SchurCfg<T, true>::NPROD * UPK * sizeof(T);
 };
@@ -1720,24 +1739,6 @@ struct SchurBf3Cfg {
   static_assert(2 * (size_t)BUF_BYTES >= (size_t)(NPROD + GROUP_CAMS) * UPKS * sizeof(float), "the accumulator hand-over reuses the panel buffers");
 };
 
-// The accept/reject decision of the PREVIOUS trial step can ride in this kernel's prologue (do_decide): every workgroup reads
-// the untouched record st_in and the trial partials, runs decide_core on its own LDS copy -- same inputs, same summation
-// order, same decision everywhere -- and workgroup 0 publishes the updated record to st_out (the other slot of a two-entry
-// buffer: nothing a late workgroup still has to read is overwritten; for the same reason the gradient maxima this kernel
-// writes go to a different array than the one the decision reads) and appends the log row.  That takes the k_decide launch
-// (6.6 us of mostly launch and memory latency) out of the iteration for one more dependent read in front of the camera load.
-struct FusedDecide {
-  const LMState* st_in;          // record before the decision (never written by this kernel)
-  LMState* st_out;               // where workgroup 0 publishes it afterwards (== st_in when do_decide == 0: nothing is written)
-  int do_decide;
-  const double* scal_all;        // multi-rank: gathered scalars [n_ranks][NSCAL], else NULL
-  int n_ranks;
-  const double* trial_part;      // [4][n_trial] partials of the trial kernel
-  const double* gmax_in;         // [n_gmax] gradient maxima of the previous linearisation
-  int n_trial, n_gmax;
-  LMLogRow* log;
-  int log_cap;
-};
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
     const ParamSets<float> ps, const FusedDecide fd, int C,
     const float2* __restrict__ uv, const float* __restrict__ w, const int32_t* __restrict__ pt_start,

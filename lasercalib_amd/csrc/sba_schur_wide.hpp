@@ -1,4 +1,5 @@
-// sba_schur_wide.hpp -- fused linearise + Schur kernel for 17 .. 23 cameras (f32 engine, 11-parameter model).
+// sba_schur_wide.hpp -- fused linearise + Schur kernel for up to 256 reduced-system rows (f32 engine): 17 .. 23 cameras of the
+// 11-parameter model, and every rig of up to 19 cameras of the 13-parameter model (which has no one-group kernel of its own).
 //
 // k_schur_fused_bf3 stops at one camera group (16 cameras = 176 rows = 11 MFMA tiles).  Right above it the rig used to fall back to
 // the three-pass path with group PAIRS (two linearisation kernels + k_point_factor + a diagonal and an off-diagonal pair kernel):
@@ -26,7 +27,6 @@
 #pragma once
 #include "sba_kernels.hpp"
 
-#if SBA_NCP == 11
 namespace SBA_NS {
 
 template <int NTW, int PW = 2> struct SchurWideCfg {
@@ -490,4 +490,3 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
 }
 
 }  // namespace SBA_NS
-#endif  // SBA_NCP == 11

@@ -20,7 +20,7 @@ from lasercalib_amd.synth import make_rig  # noqa: E402
 from oracle import sba_oracle as orc  # noqa: E402
 
 
-def _system(rig, uv, ci, pi, wts, monkeypatch, no_wide, lam=1e-4):
+def _system(rig, uv, ci, pi, wts, monkeypatch, no_wide, lam=1e-4, P=11):
     if no_wide:
         monkeypatch.setenv("SBA_NO_WIDE", "1")
     else:
@@ -51,7 +51,10 @@ def test_wide_kernel_builds_the_three_pass_system(monkeypatch, C, N, vis):
     wts = rng.uniform(0.5, 1.5, ci.size)
     Ea, sa, da = _system(rig, uv, ci, pi, wts, monkeypatch, no_wide=False)
     Eb, sb, db = _system(rig, uv, ci, pi, wts, monkeypatch, no_wide=True)
-    n = 11 * C
+    _compare_systems(Ea, sa, da, Eb, sb, db, 11 * C)
+
+
+def _compare_systems(Ea, sa, da, Eb, sb, db, n):
     S_a, S_b = Ea[: n * n].reshape(n, n), Eb[: n * n].reshape(n, n)
     assert np.array_equal(S_a, S_a.T)
     scale = np.sqrt(np.outer(np.abs(np.diag(S_b)), np.abs(np.diag(S_b))))
@@ -62,6 +65,21 @@ def test_wide_kernel_builds_the_three_pass_system(monkeypatch, C, N, vis):
     assert abs(Ea[-1] - Eb[-1]) <= 1e-6 * Eb[-1]                  # cost
     assert np.max(np.abs(sa[:4] - sb[:4]) / (np.abs(sb[:4]) + 1e-30)) <= 1e-3        # trial cost, predicted reduction, step norms
     assert np.max(np.abs(da - db)) <= 2e-3 * np.max(np.abs(db))   # camera step: the damped solve amplifies the 1e-5 of S
+
+
+@pytest.mark.parametrize("C,N,vis", [(4, 300, 1.0), (9, 250, 0.7), (16, 333, 1.0), (16, 400, 0.5), (17, 210, 1.0), (19, 180, 0.8)])
+def test_wide_kernel_serves_the_13_parameter_model(monkeypatch, C, N, vis):
+    """The 13-parameter (radial + tangential) model has no one-group kernel of its own: every rig of up to 19 cameras (<= 256
+    rows of 13) takes the wide kernel -- 8, 12, 13 tiles with three points per wave up to 16 cameras, 14 .. 16 tiles with two."""
+    rig = make_rig(C, N, seed=77 + C, visibility=vis, tangential=True)
+    rig["cams0"][:, 9:11] = rig["cams_true"][:, 9:11] * 0.6          # linearise where p1, p2 are not zero
+    rng = np.random.default_rng(6)
+    perm = rng.permutation(rig["camera_ind"].size)
+    uv, ci, pi = rig["points_2d"][perm], rig["camera_ind"][perm], rig["point_ind"][perm]
+    wts = rng.uniform(0.5, 1.5, ci.size)
+    Ea, sa, da = _system(rig, uv, ci, pi, wts, monkeypatch, no_wide=False)
+    Eb, sb, db = _system(rig, uv, ci, pi, wts, monkeypatch, no_wide=True)
+    _compare_systems(Ea, sa, da, Eb, sb, db, 13 * C)
 
 
 @pytest.mark.parametrize("C,N,vis", [(17, 400, 1.0), (17, 600, 0.45), (20, 300, 0.7), (23, 250, 1.0)])
