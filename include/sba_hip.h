@@ -233,6 +233,17 @@ int sba_set_robust_loss(sba_handle* h, int32_t loss /*sba_loss*/, double f_scale
 #define SBA_COMM_ID_BYTES 128
 int sba_comm_get_unique_id(uint8_t* id_out /*SBA_COMM_ID_BYTES*/);
 int sba_comm_init(sba_handle* h, const uint8_t* id /*SBA_COMM_ID_BYTES*/, int32_t rank, int32_t n_ranks);
+/* The same sharded loop without RCCL on its critical path: a one-shot exchange through peer-mapped device buffers.  Every rank
+ * exports one "area" (sba_ipc_export: hipIpcGetMemHandle of uncached device memory sized for n_ranks), the caller carries the
+ * 64-byte handles between the processes (any channel: the Python host uses torch.distributed / gloo), and every rank maps all
+ * of them (sba_ipc_attach).  Per LM trial a rank writes its packed reduced system, later its 8 trial scalars, into its own area,
+ * raises a flag, waits in a one-wave kernel (bounded: 2 s, then the solve returns SBA_ERR_STATE on that rank) for the peers'
+ * flags and adds the n_ranks copies in rank order: the same bits on every rank, two or three small launches per exchange
+ * instead of an RCCL collective.  Works between processes sharing ONE device (how tests/test_gpu_ipc.py runs the in-library
+ * sharded loop on a one-GPU box) and between peer GPUs of one node.  Exclusive with sba_comm_init. */
+#define SBA_IPC_HANDLE_BYTES 64
+int sba_ipc_export(sba_handle* h, int32_t n_ranks, uint8_t* handle_out /*SBA_IPC_HANDLE_BYTES*/);
+int sba_ipc_attach(sba_handle* h, int32_t rank, int32_t n_ranks, const uint8_t* handles_all /*n_ranks * SBA_IPC_HANDLE_BYTES, rank order*/);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * Runs `reps` launches of one named kernel on the current parameters and returns the mean launch

@@ -24,7 +24,7 @@ NSCALARS = 8
 EXPORTED_SYMBOLS = (
     "sba_abi_version", "sba_device_count", "sba_last_error", "sba_rotate", "sba_project", "sba_project_model",
     "sba_create", "sba_upload", "sba_set_params", "sba_get_params", "sba_destroy",
-    "sba_get_gradient", "sba_get_transform", "sba_lm_get_step", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
+    "sba_get_gradient", "sba_get_transform", "sba_lm_get_step", "sba_ipc_export", "sba_ipc_attach", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
     "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_finish", "sba_lm_get_log", "sba_time_kernel", "sba_get_kernel_profile",
     "sba_comm_get_unique_id", "sba_comm_init", "sba_set_fixed_points", "sba_set_robust_loss",
@@ -135,6 +135,8 @@ def load():
         "sba_get_kernel_profile": (C.c_int, [H, dp, ip]),
         "sba_comm_get_unique_id": (C.c_int, [C.c_char_p]),
         "sba_comm_init": (C.c_int, [H, C.c_char_p, C.c_int32, C.c_int32]),
+        "sba_ipc_export": (C.c_int, [H, C.c_int32, C.c_char_p]),
+        "sba_ipc_attach": (C.c_int, [H, C.c_int32, C.c_int32, C.c_char_p]),
         "sba_set_fixed_points": (C.c_int, [H, C.c_void_p]),
         "sba_set_robust_loss": (C.c_int, [H, C.c_int32, C.c_double]),
     }
@@ -184,6 +186,7 @@ def device_count():
 
 
 COMM_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 
 
 def comm_unique_id():
@@ -267,6 +270,20 @@ class Problem:
             raise ValueError("unique_id must be the 128 bytes comm_unique_id() returned on rank 0")
         _check(self._lib.sba_comm_init(self._h, bytes(unique_id), int(rank), int(n_ranks)), self._h)
         self.comm_rank, self.comm_n = int(rank), int(n_ranks)
+
+    # -- the same sharded loop over peer-mapped buffers instead of RCCL (sba_ipc_export / sba_ipc_attach, include/sba_hip.h)
+    def ipc_export(self, n_ranks):
+        """This rank's exchange area for a job of n_ranks: returns the 64-byte handle every peer needs."""
+        buf = C.create_string_buffer(IPC_HANDLE_BYTES)
+        _check(self._lib.sba_ipc_export(self._h, int(n_ranks), buf), self._h)
+        return bytes(buf.raw)
+
+    def ipc_attach(self, rank, handles):
+        """handles: the n_ranks handles in rank order (this rank's own included); after this, solve_lm runs the sharded loop."""
+        if any(len(h) != IPC_HANDLE_BYTES for h in handles):
+            raise ValueError("every handle must be the 64 bytes ipc_export() returned on its rank")
+        _check(self._lib.sba_ipc_attach(self._h, int(rank), len(handles), b"".join(bytes(h) for h in handles)), self._h)
+        self.comm_rank, self.comm_n = int(rank), len(handles)
 
     # -- opt-in extensions (off by default: the reference ignores points3Dfixed and uses the linear loss)
     def set_fixed_points(self, mask):

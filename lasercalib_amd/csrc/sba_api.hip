@@ -235,6 +235,16 @@ int sba_comm_init(sba_handle* h, const uint8_t* id, int32_t rank, int32_t n_rank
   return guarded(h, [&] { return h->eng->comm_init(id, rank, n_ranks); });
 }
 
+int sba_ipc_export(sba_handle* h, int32_t n_ranks, uint8_t* handle_out) {
+  if (!h || !handle_out) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return h->eng->ipc_export(n_ranks, handle_out); });
+}
+
+int sba_ipc_attach(sba_handle* h, int32_t rank, int32_t n_ranks, const uint8_t* handles_all) {
+  if (!h || !handles_all) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return h->eng->ipc_attach(rank, n_ranks, handles_all); });
+}
+
 int sba_set_fixed_points(sba_handle* h, const uint8_t* fixed_mask) {
   if (!h) return SBA_ERR_INVALID;
   return guarded(h, [&] { return h->eng->set_fixed_points(fixed_mask); });

@@ -254,6 +254,8 @@ struct EngineBase {
   virtual int get_kernel_profile(double* total_us, int64_t* count) = 0;
   virtual int time_kernel(const char* name, int reps, double* mean_us) = 0;
   virtual int comm_init(const uint8_t* id, int rank, int n_ranks) = 0;
+  virtual int ipc_export(int n_ranks, uint8_t* handle_out) = 0;
+  virtual int ipc_attach(int rank, int n_ranks, const uint8_t* handles) = 0;
   virtual int set_fixed_points(const uint8_t* mask) = 0;
   virtual int set_robust_loss(int loss, double f_scale) = 0;
 };

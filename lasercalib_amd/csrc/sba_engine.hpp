@@ -9,6 +9,7 @@
 #include "sba_chol_big.hpp"
 #include "sba_sq_kernels.hpp"
 #include "sba_schur_wide.hpp"
+#include "sba_ipc.hpp"
 
 namespace SBA_NS {
 using namespace sba_host;
@@ -104,6 +105,16 @@ struct Engine : EngineBase {
   int comm_rank = 0, comm_n = 1;
   DevBuf<double> xpack, sc_loc, sc_all, comm_tmp;
   double* h_comm = nullptr;             // pinned staging of the few scalars all-reduced at begin / finish
+  // one-shot exchange through peer-mapped buffers instead of RCCL (sba_ipc.hpp; sba_ipc_export / sba_ipc_attach)
+  bool ipc_on = false;
+  int ipc_planned = 0;                  // n_ranks the area was exported for
+  double* ipc_mine = nullptr;           // this rank's area (uncached device memory)
+  std::vector<double*> ipc_area;        // every rank's area as mapped into this process (own entry = ipc_mine)
+  DevBuf<double*> ipc_ptrs;             // ... the same table on the device
+  DevBuf<int> ipc_fail;                 // set by a gate that ran out of time outside the LM loop
+  IpcLayout ipc_L{};
+  unsigned long long ipc_seq[IPC_KINDS] = {0, 0, 0};     // exchanges enqueued so far, per kind (the value the flags carry)
+  bool multi() const { return comm != nullptr || ipc_on; }
   long long N_global = 0;
   DevBuf<long long> schur_dbg;
   DevBuf<long long> chol_dbg;
@@ -140,6 +151,10 @@ struct Engine : EngineBase {
   int n_decides = 0;                  // accept/reject kernels enqueued since lm_begin (upper bound of the log rows on the device)
   ~Engine() override {
     if (comm) (void)Rccl::get().comm_destroy(comm);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (size_t r = 0; r < ipc_area.size(); ++r)
+      if (ipc_area[r] && ipc_area[r] != ipc_mine) (void)hipIpcCloseMemHandle(ipc_area[r]);
+    if (ipc_mine) (void)hipFree(ipc_mine);
     if (h_comm) (void)hipHostFree(h_comm);
     if (have_hres) {
       if (stream) (void)hipStreamSynchronize(stream);     // nothing of this handle may still be in flight when its buffers are recycled
@@ -504,7 +519,9 @@ struct Engine : EngineBase {
     if (fused_masked || (lin_pts_ok && !dense_one_group) || (fused_wide && C <= GROUP_CAMS && !dense)) vis_mask.upload(vmask, stream);
     if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * (fused_wide ? WIDE_ROWS : GROUP_ROWS));
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1)); gmax_alt.alloc(std::max(std::max(nblk, ksplit), 1));
-    trial_part.alloc((size_t)4 * std::max(nblk, 1));
+    // (k_backsub_dense writes one partial row per WORKGROUP: nbs_dense of them, which exceeds the number of point-aligned blocks on
+    //  dense rigs with few cameras -- 8 x 1000: 63 vs 32; sized for nblk alone the rows used to run over into the next buffer)
+    trial_part.alloc((size_t)4 * std::max(std::max(nblk, nbs_dense), 1));
     up_lap("allocations + H2D enqueue");
     sync();   // the staging vectors go out of scope now
     up_lap("H2D completion");
@@ -946,8 +963,76 @@ struct Engine : EngineBase {
     return SBA_OK;
   }
   // in-place all-reduce of a few host doubles (begin / finish only: the LM loop itself never leaves the device)
+  // ------------------------------------------------------------------ one-shot exchange (sba_ipc.hpp)
+  int ipc_export(int n_ranks, uint8_t* handle_out) override {
+    if (n_ranks < 1 || !handle_out) { err = "bad arguments"; return SBA_ERR_INVALID; }
+    if (ipc_on || ipc_mine) { err = "the handle already has an exchange area"; return SBA_ERR_STATE; }
+    HIPCHK(hipSetDevice(device));
+    ipc_L = IpcLayout::make(n);
+    void* pmem = nullptr;
+    // uncached: the peers read what this rank's kernels wrote without a kernel boundary of THEIR stream in between
+    if (hipExtMallocWithFlags(&pmem, ipc_L.total * sizeof(double), hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      HIPCHK(hipMalloc(&pmem, ipc_L.total * sizeof(double)));
+    }
+    ipc_mine = static_cast<double*>(pmem);
+    HIPCHK(hipMemsetAsync(ipc_mine, 0, ipc_L.total * sizeof(double), stream));
+    sync();
+    hipIpcMemHandle_t hm;
+    HIPCHK(hipIpcGetMemHandle(&hm, ipc_mine));
+    static_assert(sizeof(hm) == SBA_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    memcpy(handle_out, &hm, sizeof hm);
+    ipc_planned = n_ranks;
+    return SBA_OK;
+  }
+  int ipc_attach(int rank, int n_ranks, const uint8_t* handles) override {
+    if (!ipc_mine || n_ranks != ipc_planned || rank < 0 || rank >= n_ranks || !handles) { err = "sba_ipc_export first, with the same n_ranks"; return SBA_ERR_STATE; }
+    if (comm) { err = "the handle already has an RCCL communicator"; return SBA_ERR_STATE; }
+    HIPCHK(hipSetDevice(device));
+    ipc_area.assign(n_ranks, nullptr);
+    for (int r = 0; r < n_ranks; ++r) {
+      if (r == rank) { ipc_area[r] = ipc_mine; continue; }
+      hipIpcMemHandle_t hp;
+      memcpy(&hp, handles + (size_t)r * SBA_IPC_HANDLE_BYTES, sizeof hp);
+      void* q = nullptr;
+      HIPCHK(hipIpcOpenMemHandle(&q, hp, hipIpcMemLazyEnablePeerAccess));
+      ipc_area[r] = static_cast<double*>(q);
+    }
+    ipc_ptrs.upload(ipc_area, stream);
+    if (ipc_fail.n == 0) ipc_fail.alloc(1);
+    ipc_fail.zero(stream);
+    comm_rank = rank; comm_n = n_ranks;
+    if (sc_all.n < (size_t)NSCAL * n_ranks) sc_all.alloc((size_t)NSCAL * n_ranks);
+    if (comm_tmp.n < (size_t)std::max(n, 1) + 8) comm_tmp.alloc(std::max(n, 1) + 8);
+    if (!h_comm) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_comm), sizeof(double) * (std::max(n, 1) + 8), hipHostMallocDefault));
+    sync();
+    ipc_on = true;
+    return SBA_OK;
+  }
+  void ipc_publish(int kind, unsigned long long seq, const LMState* st) {
+    hipLaunchKernelGGL(k_ipc_publish, dim3(1), dim3(1), 0, stream, ipc_mine, ipc_L.flag_of(kind, (int)(seq & 1)), seq, st);
+  }
+  void ipc_gate(int kind, unsigned long long seq, LMState* st, size_t copy_off, int ncopy, double* dst) {
+    hipLaunchKernelGGL(k_ipc_gate, dim3(1), dim3(64), 0, stream, ipc_ptrs.p, comm_n, ipc_L.flag_of(kind, (int)(seq & 1)), seq, st,
+                       st ? (int*)nullptr : ipc_fail.p, copy_off, ncopy, dst);
+  }
   void comm_reduce(double* v, int count, int op) {
     for (int i = 0; i < count; ++i) h_comm[i] = v[i];
+    if (ipc_on) {
+      const unsigned long long s = ++ipc_seq[2];
+      const size_t slot = ipc_L.vec_slot((int)(s & 1));
+      HIPCHK(hipMemcpyAsync(ipc_mine + slot, h_comm, sizeof(double) * count, hipMemcpyHostToDevice, stream));
+      ipc_publish(2, s, nullptr);
+      ipc_gate(2, s, nullptr, 0, 0, nullptr);
+      hipLaunchKernelGGL(k_ipc_reduce_vec, dim3(1), dim3(256), 0, stream, ipc_ptrs.p, comm_n, slot, count, op == Rccl::kMax ? 1 : 0, comm_tmp.p);
+      int failed = 0;
+      HIPCHK(hipMemcpyAsync(h_comm, comm_tmp.p, sizeof(double) * count, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(&failed, ipc_fail.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      sync();
+      if (failed) throw HipError{hipErrorNotReady, "a peer rank did not reach the exchange within 2 s (sba_ipc)", __FILE__, __LINE__};
+      for (int i = 0; i < count; ++i) v[i] = h_comm[i];
+      return;
+    }
     HIPCHK(hipMemcpyAsync(comm_tmp.p, h_comm, sizeof(double) * count, hipMemcpyHostToDevice, stream));
     RCCLCHK(Rccl::get().all_reduce(comm_tmp.p, comm_tmp.p, count, Rccl::kFloat64, op, comm, stream));
     HIPCHK(hipMemcpyAsync(h_comm, comm_tmp.p, sizeof(double) * count, hipMemcpyDeviceToHost, stream));
@@ -973,18 +1058,18 @@ struct Engine : EngineBase {
     // initial cost; scipy raises ValueError when it is not finite (least_squares.py:844-845)
     double c0 = 0;
     int rc = SBA_OK;
-    if (comm && sq_mode() && comm_n > 1) { err = "the squared-error variants (camonly, transform_points_3d) run on one GPU only"; return SBA_ERR_UNSUPPORTED; }  // (same on every rank)
+    if (multi() && sq_mode() && comm_n > 1) { err = "the squared-error variants (camonly, transform_points_3d) run on one GPU only"; return SBA_ERR_UNSUPPORTED; }  // (same on every rank)
     // With a communicator a failure on THIS rank must not keep it out of the collective its peers are about to enter: the
     // failure travels as a flag inside that all-reduce and every rank returns an error together.
     try { rc = residual(nullptr, nullptr, &c0); }
     catch (const HipError& e) {
-      if (!comm) throw;
+      if (!multi()) throw;
       err = std::string("HIP error in lm_begin: ") + hipGetErrorString(e.e) + " (" + e.what + ")";
       rc = SBA_ERR_HIP;
     }
-    if (rc && !comm) return rc;
+    if (rc && !multi()) return rc;
     N_global = N;
-    if (comm) {
+    if (multi()) {
       // every rank must see the same initial cost (a non-finite one on ANY rank fails the solve on ALL of them, before the
       // first collective of the loop) and the same default evaluation budget, 100 x the GLOBAL number of parameters
       double v[3] = {rc ? 0.0 : c0, (double)N, rc ? 1.0 : 0.0};
@@ -1286,6 +1371,7 @@ struct Engine : EngineBase {
     HIPCHK(hipGetLastError());
     prof_collect();
     const LMState& s = *h_state;
+    if (s.pad) { err = "a peer rank did not reach the exchange within 2 s (sba_ipc): the sharded solve was stopped"; lm_active = false; return SBA_ERR_STATE; }
     cur = cur_at_begin ^ (s.cur & 1);
     const int have = std::min(s.iter, LOG_CAP);
     if (have > log_read) {
@@ -1378,7 +1464,7 @@ struct Engine : EngineBase {
     if (cams_out) std::memcpy(cams_out, cams_l, sizeof(double) * n);
     double cost = 0;
     for (int i = 0; i < nblk; ++i) { gmax = std::max(gmax, gm[i]); cost += cp[i]; }
-    if (comm) {       // whole-job figures: cost and camera gradient are sums over the ranks, the point-gradient maximum a max
+    if (multi()) {       // whole-job figures: cost and camera gradient are sums over the ranks, the point-gradient maximum a max
       std::vector<double> v(n + 1);
       for (int i = 0; i < n; ++i) v[i] = gch[i];
       v[n] = cost;
@@ -1422,15 +1508,33 @@ struct Engine : EngineBase {
       // With a communicator the number of iterations (= collectives) enqueued per poll must not depend on anything rank-local
       // (bf3_path() follows the shard's own visibility density): a rank that enqueues one more all-reduce than its peers after
       // the device-side termination waits for it forever.
-      const int pbatch = comm ? 2 : (bf3_path() && defer_decide ? 2 : 1);
+      const int pbatch = multi() ? 2 : (bf3_path() && defer_decide ? 2 : 1);
       int batch = prof_on ? pbatch : BATCH;
       if (o->max_iter > 0) batch = std::min(std::max(1, o->max_iter - iters), prof_on ? pbatch : 64);
       for (int b = 0; b < batch; ++b) {
         lm_linearize();
-        if (!comm) {
+        if (!multi()) {
           lm_form_reduced(E_own.p);
           lm_solve_trial(E_own.p, nullptr);
           lm_decide_async(nullptr, 1);
+        } else if (ipc_on) {
+          // the same two exchange points through the peer-mapped areas (sba_ipc.hpp): every rank writes its packed system /
+          // its 8 trial scalars into its own area, raises a flag, waits (one wave, bounded) for the peers' flags and adds the
+          // n_ranks copies in rank order -- no RCCL launch on the iteration's critical path
+          const bool fc = h_state->free_cams != 0;
+          const unsigned long long s0 = ++ipc_seq[0];
+          const size_t sys_off = ipc_L.sys_slot(n, (int)(s0 & 1));
+          form_reduced(E_own.p, ipc_mine + sys_off);
+          ipc_publish(0, s0, d_state.p);
+          ipc_gate(0, s0, d_state.p, 0, 0, nullptr);
+          hipLaunchKernelGGL(k_ipc_sum_system, dim3(fc ? std::min(1024, (n * n + 255) / 256) : 1), dim3(256), 0, stream, ipc_ptrs.p, comm_n,
+                             sys_off, n, (int)fc, E_own.p, d_state.p);
+          const unsigned long long s1 = ++ipc_seq[1];
+          const size_t sc_off = ipc_L.scal_slot((int)(s1 & 1));
+          lm_solve_trial(E_own.p, ipc_mine + sc_off);
+          ipc_publish(1, s1, d_state.p);
+          ipc_gate(1, s1, d_state.p, sc_off, NSCAL, sc_all.p);
+          lm_decide_async(sc_all.p, comm_n);
         } else {
           // one all-reduce of the packed reduced camera system, one all-gather of 8 scalars per rank; every rank then solves
           // the same system and takes the same decision.  A finished solve turns the kernels into no-ops on the device; the

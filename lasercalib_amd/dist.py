@@ -266,18 +266,23 @@ def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device,
     max_nfev = int(max_nfev) if max_nfev else 100 * _n_params(mode, cams.shape[1], cams.shape[0], pts.shape[0])
     kw = dict(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, mode=mode, verbose=0, max_iter=max_iter,
               always_relinearize=always_relinearize)
-    use_rccl = os.environ.get("LASERCALIB_SBA_COMM", "rccl" if comm.d.get_backend() == "nccl" else "torch") == "rccl"
+    # who carries the per-trial exchanges: "rccl" (the library binds RCCL: default on the nccl backend), "ipc" (the library's
+    # one-shot exchange through peer-mapped buffers, csrc/sba_ipc.hpp: no RCCL launch per trial; also works with several ranks
+    # on ONE device), "torch" (the phase C ABI with torch.distributed collectives: default elsewhere)
+    mode_comm = os.environ.get("LASERCALIB_SBA_COMM", "rccl" if comm.d.get_backend() == "nccl" else "torch")
+    use_rccl = mode_comm in ("rccl", "ipc")
     if use_rccl:
-        # the library owns the collectives: hand it a communicator and make ONE call
+        # the library owns the exchanges: hand it a communicator (or the peers' areas) and make ONE call
         ids = [None]
-        if comm.r == 0:
-            try:
-                ids = [_native.comm_unique_id()]
-            except Exception as e:      # noqa: BLE001  (RCCL missing / wrong version: the peers are waiting for the broadcast)
-                ids = [("error", f"{type(e).__name__}: {e}")]
-        comm.d.broadcast_object_list(ids, src=0)
-        if isinstance(ids[0], tuple):
-            raise ValueError(f"sba_comm_get_unique_id failed on rank 0: {ids[0][1]}")
+        if mode_comm == "rccl":
+            if comm.r == 0:
+                try:
+                    ids = [_native.comm_unique_id()]
+                except Exception as e:      # noqa: BLE001  (RCCL missing / wrong version: the peers are waiting for the broadcast)
+                    ids = [("error", f"{type(e).__name__}: {e}")]
+            comm.d.broadcast_object_list(ids, src=0)
+            if isinstance(ids[0], tuple):
+                raise ValueError(f"sba_comm_get_unique_id failed on rank 0: {ids[0][1]}")
         # Everything that can fail on ONE rank (allocation, upload, a bad mask) happens before the first collective the
         # library enters (ncclCommInitRank), and the outcome is agreed over the torch group first: a rank that raised would
         # otherwise leave its peers blocked inside RCCL.  What this cannot cover is a failure inside ncclCommInitRank itself
@@ -297,7 +302,22 @@ def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device,
                 prob.close()
             raise
         try:
-            prob.comm_init(ids[0], comm.r, comm.n)
+            if mode_comm == "rccl":
+                prob.comm_init(ids[0], comm.r, comm.n)
+            else:
+                # every rank exports its area; a failure anywhere is agreed before anybody maps anything
+                handle, ipc_err = None, None
+                try:
+                    handle = prob.ipc_export(comm.n)
+                except Exception as e:      # noqa: BLE001
+                    ipc_err = f"{type(e).__name__}: {e}"
+                raise_everywhere(comm, ipc_err)
+                handles = comm.all_gather_var(handle)
+                try:
+                    prob.ipc_attach(comm.r, handles)
+                except Exception as e:      # noqa: BLE001
+                    ipc_err = f"{type(e).__name__}: {e}"
+                raise_everywhere(comm, ipc_err)
             bad = None
             try:
                 cams_opt, pts_loc, rep, log = prob.solve_lm(prob.make_opts(**kw))
@@ -306,6 +326,8 @@ def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device,
             if bad is not None:
                 raise bad
             fvec_loc, _ = prob.residual()
+            if mode_comm == "ipc":
+                comm.d.barrier()          # nobody unmaps or frees an area a peer's last kernels may still be reading
         finally:
             prob.close()
         status, cost, opt, cost0 = rep.status, rep.cost, rep.optimality, rep.initial_cost     # whole-job figures already
