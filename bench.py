@@ -224,10 +224,17 @@ def main():
     prob = _native.Problem(rig["cams0"], shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], dtype=a.dtype,
                            device=local, stream=stream)
     x0 = np.hstack((rig["cams0"].ravel(), shard["pts"].ravel()))
-    rehearsal = world > 1 and os.environ.get("SBA_BENCH_BACKEND", "nccl") != "nccl"     # gloo on one card: phase API + torch collectives
+    # SBA_BENCH_COMM=ipc: the library's one-shot exchange through peer-mapped buffers (csrc/sba_ipc.hpp) instead of RCCL; it also
+    # works with every rank on ONE card (SBA_BENCH_BACKEND=gloo), which is how the in-library sharded loop is timed on a one-GPU box
+    use_ipc = world > 1 and os.environ.get("SBA_BENCH_COMM", "") == "ipc"
+    rehearsal = world > 1 and os.environ.get("SBA_BENCH_BACKEND", "nccl") != "nccl" and not use_ipc     # gloo on one card: phase API + torch collectives
     phase_api = rehearsal or bool(os.environ.get("SBA_BENCH_PHASE_API"))
     comm_note = None
-    if world > 1 and not rehearsal:
+    if use_ipc:
+        handles = [None] * world
+        dist.all_gather_object(handles, prob.ipc_export(world))
+        prob.ipc_attach(rank, handles)
+    elif world > 1 and not rehearsal:
         # the library's own RCCL communicator; should binding or initialising it fail on EVERY rank alike (library missing,
         # version mismatch: symmetric failures), every rank falls back to the phase-API loop with torch.distributed collectives
         # (slower, but the run still measures the sharded solve) and says so.  A ONE-SIDED failure inside sba_comm_init cannot
@@ -294,7 +301,7 @@ def main():
         run(a.warmup)
     dt, costs = run(a.steps)
     run(min(a.steps, 20), profile=True)      # separate pass with one HIP event pair per kernel class per step
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -330,6 +337,7 @@ def main():
                        "observations_total": int(M_total), "parallelism": f"points sharded x{world}, cameras replicated",
                        "collectives_fallback_reason": comm_note,
                        "collectives": ("none" if world == 1 else "torch.distributed through the phase C ABI (rehearsal / fallback)" if phase_api else
+                                       "one-shot exchange through peer-mapped buffers inside libsba_hip.so (sba_ipc): per step n(n+1)/2+3n+1 doubles + 8 doubles written once per rank, read by every rank" if use_ipc else
                                        "RCCL inside libsba_hip.so: per step 1 all-reduce of n(n+1)/2+3n+1 doubles + 1 all-gather of 8 doubles per rank"),
                        "exchange_doubles_per_step": (0 if world == 1 else n * n + 3 * n + 1 if phase_api else n * (n + 1) // 2 + 3 * n + 1)},
             "lm_iters_per_s": a.steps / dt,
@@ -365,6 +373,8 @@ def main():
             if cpu_pts == Np:      # same configuration on both sides: the ratio of LM iterations per second is meaningful
                 out["speedup_vs_cpu_lm_iters_per_s"] = out["lm_iters_per_s"] / cb["lm_iters_per_s"]
         print(json.dumps(out))
+    if world > 1:
+        dist.barrier()          # (sba_ipc: nobody frees an area a peer may still be reading)
     prob.close()
     if world > 1:
         dist.destroy_process_group()
