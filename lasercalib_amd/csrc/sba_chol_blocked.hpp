@@ -67,8 +67,10 @@ __device__ __forceinline__ bool chol16_wave(double* __restrict__ blk) {
   // critical path.
   auto pivot = [](double x) { return NEWTON ? rsqrt_nr(x) : __builtin_amdgcn_rsq(x); };
   double akk = readlane_f64(dg, 0);
-  bool ok = (akk > 0.0) && isfinite(akk);
+  // positivity: a pivot a_kk <= 0 (or non-finite) makes 1/sqrt(a_kk) NaN or infinite; the pivots are summed beside the chain (one
+  // add per link instead of two compares and two ANDs -- the chain is issue-bound) and the sum is tested once at the end
   double piv = pivot(akk);
+  double chk = piv;
 #pragma unroll
   for (int k = 0; k < CB; ++k) {
     const double lik = a[k] * piv;
@@ -76,8 +78,8 @@ __device__ __forceinline__ bool chol16_wave(double* __restrict__ blk) {
     if (k + 1 < CB) {
       dg = __builtin_fma(-lik, lik, dg);
       akk = readlane_f64(dg, k + 1);
-      ok = ok && (akk > 0.0) && isfinite(akk);
       piv = pivot(akk);
+      chk += piv;
     }
 #pragma unroll
     for (int j = k + 1; j < CB; ++j) a[j] -= lik * readlane_f64(lik, j);
@@ -86,7 +88,7 @@ __device__ __forceinline__ bool chol16_wave(double* __restrict__ blk) {
 #pragma unroll
     for (int j = 0; j < CB; ++j) blk[i * CLD + j] = a[j];     // row i of Linv^T (zero left of the diagonal)
   }
-  return ok;
+  return isfinite(chk) && chk > 0.0;
 }
 
 // one 16x16 block of L21 = A21 * Linv^T, in place, by the calling wave (4 chained f64 MFMAs)

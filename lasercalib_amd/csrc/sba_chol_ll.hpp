@@ -49,8 +49,10 @@ __device__ __forceinline__ bool chol16_wave_to(const double* __restrict__ src, d
   __builtin_amdgcn_wave_barrier();
   auto pivot = [](double x) { return NEWTON ? rsqrt_nr(x) : __builtin_amdgcn_rsq(x); };
   double akk = readlane_f64(dg, 0);
-  bool ok = (akk > 0.0) && isfinite(akk);
+  // positivity: a pivot a_kk <= 0 (or non-finite) makes 1/sqrt(a_kk) NaN or infinite; the pivots are summed beside the chain (one
+  // add per link instead of two compares and two ANDs -- the chain is issue-bound) and the sum is tested once at the end
   double piv = pivot(akk);
+  double chk = piv;
 #pragma unroll
   for (int k = 0; k < CB; ++k) {
     const double lik = a[k] * piv;
@@ -58,8 +60,8 @@ __device__ __forceinline__ bool chol16_wave_to(const double* __restrict__ src, d
     if (k + 1 < CB) {
       dg = __builtin_fma(-lik, lik, dg);
       akk = readlane_f64(dg, k + 1);
-      ok = ok && (akk > 0.0) && isfinite(akk);
       piv = pivot(akk);
+      chk += piv;
     }
 #pragma unroll
     for (int j = k + 1; j < CB; ++j) a[j] -= lik * readlane_f64(lik, j);
@@ -68,7 +70,7 @@ __device__ __forceinline__ bool chol16_wave_to(const double* __restrict__ src, d
 #pragma unroll
     for (int j = 0; j < CB; ++j) dst[i * CLD + j] = a[j];     // row i of Linv^T (zero left of the diagonal)
   }
-  return ok;
+  return isfinite(chk) && chk > 0.0;
 }
 
 template <typename T>
@@ -104,16 +106,16 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
       if (I >= n || J >= n) a[rg] = (I == J) ? 1.0 : 0.0;
     }
   };
-  // Roles.  Wave 0 runs the pivot chain.  A workgroup's waves go to the SIMDs in cyclic order, so wave 4 shares wave 0's SIMD:
-  // it is the helper -- forward substitution, right-hand-side tail, slot allocator, copies to the workspace -- and gets MFMA work
-  // (f64 MFMAs of a neighbour slow the chain's f64 VALU instructions down) only when there are more than 14 block rows.
-  // Waves 1,2,3,5,6,7 are the six workers; worker x owns block rows 2 + x and 8 + x, the helper rows 14 and 15.
+  // Roles.  Wave 0 runs the pivot chain.  Waves 1..7 are the workers: worker x = wave - 1 owns block rows 2 + x and 9 + x (rows retire
+  // from the top, so a worker's two rows are rarely active together once the first seven are done).  Wave 4 -- it shares wave 0's SIMD,
+  // a workgroup's waves go to the SIMDs in cyclic order -- is also the helper: forward substitution, right-hand-side tail, slot
+  // allocator, copies to the workspace.
   constexpr int NR = 2, HELPER = 4;
   const bool helper = wid == HELPER;
-  const int widx = (wid >= 1 && wid != HELPER) ? (wid < HELPER ? wid - 1 : wid - 2) : -1;
+  const int widx = wid - 1;
   int rowi[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) rowi[r] = (widx >= 0) ? 2 + widx + 6 * r : helper ? 14 + r : CLL_MAX_NB + 1;
+  for (int r = 0; r < NR; ++r) rowi[r] = (widx >= 0) ? 2 + widx + 7 * r : CLL_MAX_NB + 1;
   acc_t cur[NR], nxt[NR], nx2[NR], Lr[NR];    // block columns j, j+1 (j+1, j+2 after the panel solve), the one requested two steps ahead, L(i,j)
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
