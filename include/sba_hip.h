@@ -237,7 +237,7 @@ int sba_comm_init(sba_handle* h, const uint8_t* id /*SBA_COMM_ID_BYTES*/, int32_
  * exports one "area" (sba_ipc_export: hipIpcGetMemHandle of uncached device memory sized for n_ranks), the caller carries the
  * 64-byte handles between the processes (any channel: the Python host uses torch.distributed / gloo), and every rank maps all
  * of them (sba_ipc_attach).  Per LM trial a rank writes its packed reduced system, later its 8 trial scalars, into its own area,
- * raises a flag, waits in a one-wave kernel (bounded: 2 s, then the solve returns SBA_ERR_STATE on that rank) for the peers'
+ * raises a flag, waits in a one-wave kernel (bounded: 5 s, then the solve returns SBA_ERR_STATE on that rank) for the peers'
  * flags and adds the n_ranks copies in rank order: the same bits on every rank, two or three small launches per exchange
  * instead of an RCCL collective.  Works between processes sharing ONE device (how tests/test_gpu_ipc.py runs the in-library
  * sharded loop on a one-GPU box) and between peer GPUs of one node.  Exclusive with sba_comm_init. */

@@ -1029,7 +1029,7 @@ struct Engine : EngineBase {
       HIPCHK(hipMemcpyAsync(h_comm, comm_tmp.p, sizeof(double) * count, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipMemcpyAsync(&failed, ipc_fail.p, sizeof(int), hipMemcpyDeviceToHost, stream));
       sync();
-      if (failed) throw HipError{hipErrorNotReady, "a peer rank did not reach the exchange within 2 s (sba_ipc)", __FILE__, __LINE__};
+      if (failed) throw HipError{hipErrorNotReady, "a peer rank did not reach the exchange within 5 s (sba_ipc)", __FILE__, __LINE__};
       for (int i = 0; i < count; ++i) v[i] = h_comm[i];
       return;
     }
@@ -1371,7 +1371,7 @@ struct Engine : EngineBase {
     HIPCHK(hipGetLastError());
     prof_collect();
     const LMState& s = *h_state;
-    if (s.pad) { err = "a peer rank did not reach the exchange within 2 s (sba_ipc): the sharded solve was stopped"; lm_active = false; return SBA_ERR_STATE; }
+    if (s.pad) { err = "a peer rank did not reach the exchange within 5 s (sba_ipc): the sharded solve was stopped"; lm_active = false; return SBA_ERR_STATE; }
     cur = cur_at_begin ^ (s.cur & 1);
     const int have = std::min(s.iter, LOG_CAP);
     if (have > log_read) {

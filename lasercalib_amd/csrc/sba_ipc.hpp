@@ -4,7 +4,7 @@
 // hipIpcOpenMemHandle: other processes on the same GPU, or peer GPUs over xGMI).  Per LM trial:
 //     k_build_exchange writes the rank's packed reduced system straight into its own area      (slot = exchange count & 1)
 //     k_ipc_publish    release-stores the exchange count into the rank's flag
-//     k_ipc_gate       ONE wave waits until every peer's flag has reached the count (bounded: 2 s, then the solve fails)
+//     k_ipc_gate       ONE wave waits until every peer's flag has reached the count (bounded: 5 s, then the solve fails)
 //     k_ipc_sum_system every rank adds the n_ranks copies in rank order -> the same bits everywhere, no broadcast
 // and the 8 trial scalars per rank the same way (k_trial_scalars writes them into the area, the gate kernel copies all ranks'
 // rows into the local array k_decide reads).  A trial has two exchange points (the decision needs the trial cost of the step the
@@ -20,6 +20,7 @@ namespace SBA_NS {
 
 constexpr int IPC_KINDS = 3;                 // 0: reduced system, 1: trial scalars, 2: small host-side vectors (begin / finish)
 constexpr int IPC_FLAG_STRIDE = 16;          // doubles (128 bytes) between flags
+constexpr long long IPC_TIMEOUT_TICKS = 500000000LL;      // 5 s of the 100 MHz wall clock: a gate never waits longer for a peer
 struct IpcLayout {                           // offsets in doubles from the start of an area
   size_t flag, sys, scal, vec, total;
   int nvec;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(64) void k_ipc_gate(double* const* __restrict__ are
     const unsigned long long* f = reinterpret_cast<const unsigned long long*>(areas[r] + flag_off);
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
-      if (wall_clock64() - t0 > 200000000LL) { late = true; break; }          // 2 s at 100 MHz
+      if (wall_clock64() - t0 > IPC_TIMEOUT_TICKS) { late = true; break; }
       __builtin_amdgcn_s_sleep(4);
     }
   }

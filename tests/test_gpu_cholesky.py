@@ -97,3 +97,29 @@ def test_ill_conditioned_and_indefinite(monkeypatch, C, mode):
     S2[k, k] = -1.0
     step = _solve_on_device(C, S2, rhs, dU, "f64", lam=1e-6)
     assert np.all(step == 0.0)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_shared_intrinsics_system_through_the_left_looking_kernel(monkeypatch, dtype):
+    """bundleAdjust_sharedcam ties f, k1, k2 of all cameras: 24 cameras give 3 + 8 * 24 = 195 tied unknowns, which the left-looking
+    kernel factors (with its tie / first maps in the epilogue); SBA_CHOL=blocked sends the same system through the streamed kernel."""
+    rig = make_rig(24, 220, seed=12, visibility=0.6)
+    args = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+
+    def run(mode):
+        if mode:
+            monkeypatch.setenv("SBA_CHOL", mode)
+        else:
+            monkeypatch.delenv("SBA_CHOL", raising=False)
+        with _native.Problem(*args, dtype=dtype) as prob:
+            return prob.solve_lm(prob.make_opts(ftol=1e-6, mode=_native.MODE_SHARED_INTR, max_iter=8))
+
+    ca, pa, ra, la = run(None)
+    cb, pb, rb, lb = run("blocked")
+    assert ra.iterations == rb.iterations == 8 or ra.status == rb.status
+    tol = 1e-9 if dtype == "f64" else 1e-4
+    assert abs(ra.cost - rb.cost) <= tol * rb.cost
+    # the tied parameters received the same step in every camera, in both runs
+    d = ca[:, 6:9] - rig["cams0"][:, 6:9]
+    assert np.max(np.abs(d - d[0])) <= 1e-9 * max(1.0, np.max(np.abs(d)))
+    assert np.max(np.abs(ca - cb)) <= (1e-6 if dtype == "f64" else 1e-2) * max(1.0, np.max(np.abs(cb)))
