@@ -1371,7 +1371,7 @@ struct Engine : EngineBase {
     HIPCHK(hipGetLastError());
     prof_collect();
     const LMState& s = *h_state;
-    if (s.pad) { err = "a peer rank did not reach the exchange within 5 s (sba_ipc): the sharded solve was stopped"; lm_active = false; return SBA_ERR_STATE; }
+    if (s.comm_fail) { err = "a peer rank did not reach the exchange within 5 s (sba_ipc): the sharded solve was stopped"; lm_active = false; return SBA_ERR_STATE; }
     cur = cur_at_begin ^ (s.cur & 1);
     const int have = std::min(s.iter, LOG_CAP);
     if (have > log_read) {

@@ -47,7 +47,7 @@ __global__ void k_ipc_publish(double* __restrict__ mine, size_t flag_off, unsign
 }
 
 // One wave.  Lane r waits for rank r's flag; afterwards (optional) rows of `ncopy` doubles are copied from every rank's area into
-// dst[r * ncopy + i].  On a timeout the solve is stopped: status 0 with the failure flag LMState::pad set.
+// dst[r * ncopy + i].  On a timeout the solve is stopped: status 0 with the failure flag LMState::comm_fail set.
 __global__ __launch_bounds__(64) void k_ipc_gate(double* const* __restrict__ areas, int n_ranks, size_t flag_off, unsigned long long value,
                                                  LMState* __restrict__ st, int* __restrict__ fail /* outside the LM loop (st == NULL) */,
                                                  size_t copy_off, int ncopy, double* __restrict__ dst) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void k_ipc_gate(double* const* __restrict__ are
   }
   const bool any_late = __any(late);
   if (any_late) {
-    if (lane == 0 && st) { st->pad = 1; st->status = 0; }
+    if (lane == 0 && st) { st->comm_fail = 1; st->status = 0; }
     if (lane == 0 && fail) *fail = 1;
     return;
   }
