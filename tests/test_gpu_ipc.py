@@ -13,6 +13,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _rig17():
+    from lasercalib_amd.synth import make_rig
+    rig = make_rig(17, 900, seed=3, visibility=0.6, min_cams_per_point=4)
+    return rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"]
+
+
 def _worker(rank, world, port, tag, q, dtype):
     sys.path.insert(0, ROOT)
     os.environ["LASERCALIB_SBA_DTYPE"] = dtype
@@ -23,8 +29,12 @@ def _worker(rank, world, port, tag, q, dtype):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lasercalib_amd.pySBA import PySBA
-        g = np.load(os.path.join(ROOT, "tests", "golden", "f4_solves.npz"))
-        sba = PySBA(g[f"{tag}_cams0"].copy(), g[f"{tag}_pts0"].copy(), g[f"{tag}_uv"], g[f"{tag}_ci"], g[f"{tag}_pi"])
+        if tag == "rig17":
+            a = _rig17()
+            sba = PySBA(a[0].copy(), a[1].copy(), a[2], a[3], a[4])
+        else:
+            g = np.load(os.path.join(ROOT, "tests", "golden", "f4_solves.npz"))
+            sba = PySBA(g[f"{tag}_cams0"].copy(), g[f"{tag}_pts0"].copy(), g[f"{tag}_uv"], g[f"{tag}_ci"], g[f"{tag}_pi"])
         res = sba.bundleAdjust(1e-4)
         q.put((rank, res.status, res.cost, res.nfev, sba.cameraArray.copy(), sba.points3D.copy(), res.fun.copy(), res.optimality))
     except BaseException as e:          # never leave the parent waiting on the queue
@@ -86,3 +96,21 @@ def test_in_library_sharded_loop_three_ranks_f32_fused_path():
     assert abs(rep.cost - r0[2]) <= 1e-4 * rep.cost          # fp32: the shards sum in a different order
     ref = float(g[f"{tag}_loose_cost"])
     assert abs(r0[2] - ref) <= 1e-4 * ref                     # fp32 bar of SURVEY 8(d)
+
+
+def test_in_library_sharded_loop_17_cameras_f32_wide_kernel():
+    """The reference's rig shape, sharded: every rank's shard runs k_schur_fused_wide (decision in its prologue), the exchanged
+    187 x 187 system goes through k_cholesky_ll on every rank -- two ranks on the card over the one-shot exchange."""
+    sys.path.insert(0, ROOT)
+    from lasercalib_amd import _native
+    from oracle import sba_oracle as orc
+    res = _run("rig17", "f32", world=2)
+    r0, r1 = res
+    assert r0[1] == r1[1] and r0[1] in (2, 3, 4) and r0[3] == r1[3] and r0[2] == r1[2]
+    assert np.array_equal(r0[4], r1[4]) and np.array_equal(r0[5], r1[5])
+    a = _rig17()
+    with _native.Problem(*a, dtype="f32") as prob:
+        _, _, rep, _ = prob.solve_lm(prob.make_opts(ftol=1e-4))
+    assert abs(rep.cost - r0[2]) <= 1e-4 * rep.cost
+    ref, _, _ = orc.bundle_adjust(*a, ftol=1e-4)
+    assert abs(r0[2] - ref.cost) <= 1e-4 * ref.cost
