@@ -110,13 +110,15 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ Dt, const 
   const int lane = threadIdx.x & 63;
   const double* Pa = Pa_blk + (lane & 15) * CLD + (lane >> 4);
   const double* Pb = Pb_blk + (lane & 15) * CLD + (lane >> 4);
-  Mfma<double>::acc_t acc;
+  // (the product is accumulated with its own sign and subtracted at the end: negating the operand is a VALU instruction per
+  //  k-step on the f64 lanes the MFMAs are waiting for)
+  Mfma<double>::acc_t acc, prod = {0, 0, 0, 0};
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) acc[rg] = Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) acc = Mfma<double>::mma(-Pa[4 * ks], Pb[4 * ks], acc);
+  for (int ks = 0; ks < 4; ++ks) prod = Mfma<double>::mma(Pa[4 * ks], Pb[4 * ks], prod);
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg];
+  for (int rg = 0; rg < 4; ++rg) Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg] - prod[rg];
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -136,8 +138,11 @@ __device__ __forceinline__ void chol_panel_update_diag(double* __restrict__ Pblk
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) pt = Mfma<double>::mma(Pl[4 * ks * CLD], Pa[4 * ks], pt);
   __builtin_amdgcn_wave_barrier();
+  Mfma<double>::acc_t pp = {0, 0, 0, 0};
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) d = Mfma<double>::mma(-pt[ks], pt[ks], d);
+  for (int ks = 0; ks < 4; ++ks) pp = Mfma<double>::mma(pt[ks], pt[ks], pp);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) d[rg] -= pp[rg];
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) Pblk[(lane & 15) * CLD + (lane >> 4) + 4 * rg] = pt[rg];
 #pragma unroll

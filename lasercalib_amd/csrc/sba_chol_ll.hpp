@@ -233,11 +233,10 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
           for (int ks = 0; ks < 4; ++ks) h[ks] = Mfma<double>::mma(Pl[4 * ks * CLD], Pa[4 * ks], acc_t{0, 0, 0, 0});
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) pt[rg] = (h[0][rg] + h[1][rg]) + (h[2][rg] + h[3][rg]);
-          h[0] = d; h[1] = acc_t{0, 0, 0, 0}; h[2] = h[1]; h[3] = h[1];
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) h[ks] = Mfma<double>::mma(-pt[ks], pt[ks], h[ks]);
+          for (int ks = 0; ks < 4; ++ks) h[ks] = Mfma<double>::mma(pt[ks], pt[ks], acc_t{0, 0, 0, 0});
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) d[rg] = (h[0][rg] + h[1][rg]) + (h[2][rg] + h[3][rg]);
+          for (int rg = 0; rg < 4; ++rg) d[rg] -= (h[0][rg] + h[1][rg]) + (h[2][rg] + h[3][rg]);
         }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) Dt[(lq + 4 * rg) * CLD + l15] = d[rg];
@@ -343,11 +342,11 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) a4[ks] = Pa[4 * ks];
             {
-              acc_t h[4] = {cur[r], acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}};
+              acc_t h[4];
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks) h[ks] = Mfma<double>::mma(-a4[ks], Lr[r][ks], h[ks]);
+              for (int ks = 0; ks < 4; ++ks) h[ks] = Mfma<double>::mma(a4[ks], Lr[r][ks], acc_t{0, 0, 0, 0});
 #pragma unroll
-              for (int rg = 0; rg < 4; ++rg) cur[r][rg] = (h[0][rg] + h[1][rg]) + (h[2][rg] + h[3][rg]);
+              for (int rg = 0; rg < 4; ++rg) cur[r][rg] -= (h[0][rg] + h[1][rg]) + (h[2][rg] + h[3][rg]);
             }
             // rhs tail of this block row: y_i -= L(i,j) y_j  (the lane holds L(i,j)[l15][lq + 4 rg])
             double s = 0;
@@ -379,7 +378,9 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
                 if (lq + 4 * rg == l15 && I < n) nxt[r][rg] += s_d[I];
               }
             }
-            acc_t g[4] = {nxt[r], acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}};
+            // (the products are accumulated with their own sign and subtracted once at the end: negating an operand is four VALU
+            //  instructions per product on the f64 lanes the MFMAs of the SIMD's two waves are waiting for)
+            acc_t g[4] = {acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}};
             // the slots of the operand blocks: lane l looks up column l once, the loop takes them through v_readlane (scalar
             // address arithmetic instead of a dependent LDS read per step); the operands of step k+1 are requested before the
             // MFMAs of step k issue (two register sets, loop unrolled by two)
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
             };
             auto mm = [&](const double (&a)[4], const double (&b)[4]) {
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks) g[ks] = Mfma<double>::mma(-a[ks], b[ks], g[ks]);
+              for (int ks = 0; ks < 4; ++ks) g[ks] = Mfma<double>::mma(a[ks], b[ks], g[ks]);
             };
             double aX[4], bX[4], aY[4], bY[4];
             ld(0, aX, bX);
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
               }
             }
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) nxt[r][rg] = (g[0][rg] + g[1][rg]) + (g[2][rg] + g[3][rg]);
+            for (int rg = 0; rg < 4; ++rg) nxt[r][rg] -= (g[0][rg] + g[1][rg]) + (g[2][rg] + g[3][rg]);
             if (i == j + 2) {
               double* Dt = s_stD + ((j + 2) & 1) * CBS;
 #pragma unroll
