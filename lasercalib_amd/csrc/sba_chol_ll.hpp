@@ -283,12 +283,6 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) { cur[r] = nxt[r]; nxt[r] = nx2[r]; }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const int i = rowi[r];
-        if (j + 3 < nb && i >= j + 3 && i < nb) load_acc(j + 3, i, nx2[r]);      // block column j+3 (the diagonal block when i == j+3)
-      }
     }
     if (dbg && lane == 0 && j == 3) dbg[64 + wid] = clock64();
     lds_barrier();                                                                   // B1
@@ -328,6 +322,13 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
       }
     }
     if (wid != 0) {
+      // block column j+3 is requested here, behind the barrier: its address arithmetic does not lengthen the panel phase every wave
+      // waits for (the register sets moved up in that phase, two intervals after their loads were issued)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int i = rowi[r];
+        if (j + 3 < nb && i >= j + 3 && i < nb) load_acc(j + 3, i, nx2[r]);      // (the diagonal block when i == j+3)
+      }
       double yv[4];                                             // y_j[lq + 4 ks]
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) yv[ks] = s_y[j * CB + lq + 4 * ks];
