@@ -141,3 +141,31 @@ def test_wide_path_with_huber_loss_and_fixed_points(monkeypatch):
     cb, pb, rb = run(True)
     assert np.array_equal(pa[:6], rig["pts0"][:6]) and np.array_equal(pb[:6], rig["pts0"][:6])
     assert abs(ra.cost - rb.cost) <= 1e-4 * rb.cost
+
+
+@pytest.mark.parametrize("mode", ["shared", "nocam"])
+def test_wide_rig_in_the_variant_solvers(monkeypatch, mode):
+    """17 cameras, fp32: bundleAdjust_sharedcam ties f, k1, k2 (the wide kernel builds the system, k_tie_system collapses it to
+    3 + 8 * 17 = 139 unknowns); bundleAdjust_nocam freezes the cameras (no reduced system: the three-pass point kernels).  Both
+    against the three-pass path (SBA_NO_WIDE=1)."""
+    rig = make_rig(17, 350, seed=23, visibility=0.7, min_cams_per_point=4)
+    args = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    m = _native.MODE_SHARED_INTR if mode == "shared" else _native.MODE_POINTS_ONLY
+
+    def run(no_wide):
+        if no_wide:
+            monkeypatch.setenv("SBA_NO_WIDE", "1")
+        else:
+            monkeypatch.delenv("SBA_NO_WIDE", raising=False)
+        with _native.Problem(*args, dtype="f32") as prob:
+            return prob.solve_lm(prob.make_opts(ftol=1e-5, mode=m))
+
+    ca, pa, ra, _ = run(False)
+    cb, pb, rb, _ = run(True)
+    assert ra.status in (2, 3, 4) and rb.status in (2, 3, 4)
+    assert abs(ra.cost - rb.cost) <= 1e-4 * rb.cost
+    if mode == "nocam":
+        assert np.array_equal(ca, rig["cams0"]) and np.array_equal(cb, rig["cams0"])
+    else:
+        d = ca[:, 6:9] - rig["cams0"][:, 6:9]
+        assert np.max(np.abs(d - d[0])) <= 1e-9 * max(1.0, np.max(np.abs(d)))
