@@ -365,6 +365,30 @@ def main():
                       "cost_first_last": [costs64[0], costs64[-1]] if costs64 else None,
                       "roofline": roofline_of_step(kt64, "f64", P, C, Nloc, M_local, (C, Np, "f64", a.tangential, a.visibility)),
                       "note": "the drop-in class's default engine (LASERCALIB_SBA_DTYPE unset): same workload and step as the headline"}
+    # SBA_BENCH_COMPARE_IPC=1 (N > 1, opt-in): the same steps once more over the one-shot exchange through peer-mapped buffers
+    # (csrc/sba_ipc.hpp) on a second handle, reported beside the headline as `ipc_exchange` -- the comparison of the two exchange
+    # mechanisms on whatever node this runs on.  Off by default: the headline is the RCCL path BASELINE.json names.
+    if world > 1 and not use_ipc and os.environ.get("SBA_BENCH_COMPARE_IPC"):
+        saved_phase = phase_api
+        prob2 = _native.Problem(rig["cams0"], shard["pts"], shard["uv"], shard["ci"], shard["pi_local"], dtype=a.dtype,
+                                device=local, stream=stream)
+        handles = [None] * world
+        dist.all_gather_object(handles, prob2.ipc_export(world))
+        prob2.ipc_attach(rank, handles)
+        phase_api = False                      # the library's own loop
+        run2 = make_runner(prob2)
+        run2(max(a.warmup, 1))
+        dt2, costs2 = run2(a.steps)
+        t2 = torch.tensor([dt2], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        dt2 = float(t2.item())
+        phase_api = saved_phase
+        dist.barrier()
+        prob2.close()
+        if rank == 0:
+            out["ipc_exchange"] = {"ms_per_step": dt2 / a.steps * 1e3, "lm_iters_per_s": a.steps / dt2, "value": M_total * a.steps / dt2 / 1e6,
+                                   "cost_first_last": [costs2[0], costs2[-1]] if costs2 else None,
+                                   "note": "same workload and steps through sba_ipc_export / sba_ipc_attach instead of the headline's collectives"}
     if rank == 0:
         if a.cpu_baseline != "off" and world == 1:
             cpu_pts = a.cpu_points if a.cpu_points > 0 else Np
