@@ -516,7 +516,10 @@ struct Engine : EngineBase {
     fused_ok = (NCP == 11 && (dense_one_group || masked_fused) && sizeof(T) == 4 && !getenv("SBA_NO_FUSED")) || fused_wide;
     fused_masked = fused_ok && !dense_one_group && !fused_wide;
     lin_pts_ok = (dense_one_group || masked_fused) && SCHUR_LIN_OK<T> && !getenv("SBA_NO_FUSED");
-    if (fused_masked || (lin_pts_ok && !dense_one_group) || (fused_wide && C <= GROUP_CAMS && !dense)) vis_mask.upload(vmask, stream);
+    // (the lane = (point, camera) back substitution serves sparse one-group rigs through the same mask, down to the visibility
+    //  where the point-aligned kernel, whose cost follows the observation count, wins)
+    backsub_masked = masked_ok && C <= GROUP_CAMS && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
+    if (fused_masked || (lin_pts_ok && !dense_one_group) || (fused_wide && C <= GROUP_CAMS && !dense) || backsub_masked) vis_mask.upload(vmask, stream);
     if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * (fused_wide ? WIDE_ROWS : GROUP_ROWS));
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1)); gmax_alt.alloc(std::max(std::max(nblk, ksplit), 1));
     // (k_backsub_dense writes one partial row per WORKGROUP: nbs_dense of them, which exceeds the number of point-aligned blocks on
@@ -784,13 +787,15 @@ struct Engine : EngineBase {
     }
   }
   // dense visibility with one camera group: the row-reduction kernel (any dtype); its partial rows are per workgroup
-  bool backsub_dense() const { return dense_one_group; }
+  bool backsub_masked = false;       // sparse one-group rig dense enough for the lane = (point, camera) back substitution (visibility mask)
+  bool backsub_dense() const { return dense_one_group || backsub_masked; }
   int n_trial_parts() const { return backsub_dense() ? nbs_dense : nblk; }
   void launch_backsub_trial() {
     if (nblk == 0) return;
     if (backsub_dense()) {
       hipLaunchKernelGGL(k_backsub_dense<T>, dim3(nbs_dense), dim3(PM_BLOCK), 0, stream, ps_lm(), C, uv_pm.p,
-                         has_w ? w_pm.p : nullptr, N, pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nbs_dense);
+                         has_w ? w_pm.p : nullptr, N, pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nbs_dense,
+                         dense_one_group ? (const uint16_t*)nullptr : vis_mask.p, dense_one_group ? (const int32_t*)nullptr : pt_start.p);
       return;
     }
     const size_t lds = (size_t)PM_BLOCK * 6 * sizeof(double) + (2 * (size_t)C * CAMPRE + (size_t)C * NCP) * sizeof(T);

@@ -562,7 +562,10 @@ template <typename T>
 __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
     const ParamSets<T> ps, int C, const typename Vec2<T>::type* __restrict__ uv /* observation (p, c) at p*C + c */,
     const T* __restrict__ w, int N, const T* __restrict__ pf, const double* __restrict__ gp, const double* __restrict__ D2p,
-    const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ trial_part, int nparts) {
+    const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ trial_part, int nparts,
+    const uint16_t* __restrict__ vis = nullptr /* sparse one-group rigs (round 3): per-point visibility mask; observation (p, c) then sits at
+                                                  pt_start[p] + popcount(mask below bit c), a lane without one idles through the row sums */,
+    const int32_t* __restrict__ pt_start = nullptr) {
   __shared__ T s_cam01[2][GROUP_CAMS * CAMPRE], s_dc[GROUP_CAMS * NCP];
   __shared__ double s_scr[PM_BLOCK / 64];
   // both camera tables are needed whichever is current: they and the camera step are requested before the state record's round trip
@@ -592,11 +595,14 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
   for (int ch = blockIdx.x; ch < nch; ch += gridDim.x) {
     const int p = ch * 16 + q;
     const bool pt_ok = p < N;
-    const bool valid = pt_ok && cam_ok;
     const size_t pp = (size_t)(pt_ok ? p : 0);
+    unsigned mask = 0xffffu;
+    size_t o = pp * C + c;
+    if (vis) { mask = vis[pp]; o = (size_t)pt_start[pp] + __builtin_popcount(mask & ((1u << c) - 1u)); }
+    const bool valid = pt_ok && cam_ok && ((mask >> c) & 1u);
     typename Vec2<T>::type m; m.x = 0; m.y = 0;
     T ww = (T)1;
-    if (valid) { m = uv[pp * C + c]; if (w) ww = w[pp * C + c]; }
+    if (valid) { m = uv[o]; if (w) ww = w[o]; }
     // every lane of the row reads the point's data (same addresses: one transaction) and solves for its step
     // redundantly.  (Requesting the next chunk's operands one chunk ahead was measured: no gain, the kernel is
     // issue-bound at three workgroups per CU and the extra registers cost one of them.)
