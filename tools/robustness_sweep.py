@@ -1,5 +1,6 @@
 """Device LM vs the scipy oracle from increasingly bad starts (seeds x perturbation scale, with outliers):
-final cost ratio, status, iteration counts.  Run on the GPU box: python tools/robustness_sweep.py"""
+final cost ratio, status, iteration counts.  Run on the GPU box: python tools/robustness_sweep.py [CAMS [POINTS [VISIBILITY]]]
+(default 6 x 250 at 0.8: the one-group kernels; 17 x 300 at 0.6: the wide kernel + the left-looking Cholesky)"""
 import sys, os, io, contextlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,10 +8,13 @@ from lasercalib_amd import _native
 from lasercalib_amd.synth import make_rig
 from oracle import sba_oracle as orc
 
+CAMS = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+POINTS = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+VIS = float(sys.argv[3]) if len(sys.argv) > 3 else 0.8
 rows = []
 for scale in (1.0, 4.0, 12.0):
     for seed in range(4):
-        rig = make_rig(6, 250, seed=100 + seed, visibility=0.8)
+        rig = make_rig(CAMS, POINTS, seed=100 + seed, visibility=VIS, min_cams_per_point=min(4, CAMS))
         rng = np.random.default_rng(seed)
         cams0 = rig["cams_true"] + (rig["cams0"] - rig["cams_true"]) * scale
         pts0 = rig["pts_true"] + (rig["pts0"] - rig["pts_true"]) * scale
