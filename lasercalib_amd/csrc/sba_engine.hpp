@@ -9,6 +9,7 @@
 #include "sba_chol_big.hpp"
 #include "sba_sq_kernels.hpp"
 #include "sba_schur_wide.hpp"
+#include "sba_schur_f64.hpp"
 #include "sba_ipc.hpp"
 
 namespace SBA_NS {
@@ -40,6 +41,7 @@ struct Engine : EngineBase {
   bool no_bf3_offdiag = false;       // SBA_NO_BF3_OFFDIAG=1: ... for the off-diagonal pairs only
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
   bool fused_bf3 = true;             // ... with the Schur products on the bf16 matrix pipe (k_schur_fused_bf3)
+  bool fused_f64 = false;            // fp64, one group, 11 parameters: k_schur_fused_f64 (sba_schur_f64.hpp)
   bool fused_wide = false;           // 17 .. 23 cameras: k_schur_fused_wide (compact rows, one launch; implies fused_ok)
   int wide_pw = 2;                   // ... points per producer wave: 3 (packed lanes, 12-point rounds) for 17 and 18 cameras, else 2
   DevBuf<double> gdpart;
@@ -210,6 +212,9 @@ struct Engine : EngineBase {
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, true>)));
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, false, true>)));
       if constexpr (SCHUR_LIN_OK<T>) HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, false, true>)));
+#if SBA_NCP == 11
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurF64Cfg::LDS_BYTES));
+#endif
     } else {
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, true, false>)));
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, false, false>)));
@@ -513,9 +518,11 @@ struct Engine : EngineBase {
     // does not shrink with the number of observations, so below ~35 % visibility the three-pass path is used
     const bool masked_fused = masked_ok && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
     // (the fused kernel is built for the 11-parameter model only: 77 register accumulators per lane; 13 parameters need 104)
-    fused_ok = (NCP == 11 && (dense_one_group || masked_fused) && sizeof(T) == 4 && !getenv("SBA_NO_FUSED")) || fused_wide;
+    // (fp64, round 3: k_schur_fused_f64, same structure on the f64 matrix pipe; SBA_NO_FUSED64=1 keeps the three-launch path)
+    fused_f64 = NCP == 11 && sizeof(T) == 8 && (dense_one_group || masked_fused) && !getenv("SBA_NO_FUSED") && !getenv("SBA_NO_FUSED64");
+    fused_ok = (NCP == 11 && (dense_one_group || masked_fused) && sizeof(T) == 4 && !getenv("SBA_NO_FUSED")) || fused_wide || fused_f64;
     fused_masked = fused_ok && !dense_one_group && !fused_wide;
-    lin_pts_ok = (dense_one_group || masked_fused) && SCHUR_LIN_OK<T> && !getenv("SBA_NO_FUSED");
+    lin_pts_ok = (dense_one_group || masked_fused) && SCHUR_LIN_OK<T> && !getenv("SBA_NO_FUSED") && !fused_f64;
     // (the lane = (point, camera) back substitution serves sparse one-group rigs through the same mask, down to the visibility
     //  where the point-aligned kernel, whose cost follows the observation count, wins)
     backsub_masked = masked_ok && C <= GROUP_CAMS && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
@@ -600,6 +607,33 @@ struct Engine : EngineBase {
     if constexpr (sizeof(T) == 4) {
       if (fused() && fused_wide) { launch_schur_wide(); return; }
     }
+#if SBA_NCP == 11
+    if constexpr (sizeof(T) == 8) {
+      if (fused() && fused_f64) {
+        double* gm_out = nullptr;
+        const FusedDecide fd = make_fused_decide(gm_out);
+        hipLaunchKernelGGL(k_schur_fused_f64, dim3(ksplit), dim3(SCHUR_THREADS), SchurF64Cfg::LDS_BYTES, stream,
+                           ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
+                           N, ksplit, D2p.p, gp.p, pfac.p, slabs.p, bpart.p, gdpart.p, cost_part.p, gm_out,
+                           (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr);
+        d_state.p = fd.st_out;
+        pending_decide = false;
+        gmax_cur = gm_out;
+        if (schur_debug && schur_debug_skip > 0) { --schur_debug_skip; return; }
+        if (schur_debug) {
+          std::vector<long long> st(64);
+          HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+          sync();
+          fprintf(stderr, "[schur_fused_f64 stamps, cycles since the first producer stamp; per chunk: producer-done consumer-done]\n");
+          for (int i = 0; i < 14; ++i) fprintf(stderr, "  it %2d: P %7lld  C %7lld\n", i, st[2 * i] - st[0], st[2 * i + 1] - st[0]);
+          fprintf(stderr, "  phases (cycles): prologue %lld | main loop %lld | fold U %lld | slab stores %lld | tail %lld | whole kernel %lld\n",
+                  st[49] - st[48], st[50] - st[49], st[51] - st[50], st[52] - st[51], st[53] - st[52], st[53] - st[48]);
+          schur_debug = false;
+        }
+        return;
+      }
+    }
+#endif
 #if SBA_NCP == 11
     if constexpr (sizeof(T) == 4) {
       if (fused()) {
@@ -1186,7 +1220,7 @@ struct Engine : EngineBase {
       const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * np_arg + (n + 15) / 16 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, np_arg, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_wide) ? 3 : (fused() && fused_bf3) ? 1 : (diag_pairs_bf3() ? (offdiag_pairs_bf3() ? 1 : 2) : 0));
+                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_wide) ? 3 : (fused() && fused_bf3 && sizeof(T) == 4) ? 1 : (diag_pairs_bf3() ? (offdiag_pairs_bf3() ? 1 : 2) : 0));
     }
     prof_end(KP_REDUCE);
     return SBA_OK;
@@ -1348,7 +1382,9 @@ struct Engine : EngineBase {
   // several camera groups, fp32, indexed producers: the group pairs run on the bf16 pipe (k_schur_diag_bf3 / k_schur_offdiag_bf3)
   bool diag_pairs_bf3() const { return sizeof(T) == 4 && ngroups > 1 && grp_indexed && !fused() && !no_bf3_pairs; }
   bool offdiag_pairs_bf3() const { return diag_pairs_bf3() && !no_bf3_offdiag; }
-  bool bf3_path() const { return sizeof(T) == 4 && fused() && fused_bf3 && !sq_mode(); }
+  // (the name is historical: every Schur kernel that takes the previous step's decision in its prologue -- k_schur_fused_bf3,
+  //  k_schur_fused_wide, k_schur_fused_f64)
+  bool bf3_path() const { return fused() && (sizeof(T) == 4 ? fused_bf3 : fused_f64) && !sq_mode(); }
   const double* gmax_rd() const { return (bf3_path() && gmax_cur) ? gmax_cur : gmax_part.p; }
   void launch_decide(const double* scal_all, int n_ranks) {
     hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(DECIDE_THREADS), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,

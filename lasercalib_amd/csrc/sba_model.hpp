@@ -151,6 +151,9 @@ __device__ inline void obs_resjac(const T* __restrict__ cp, T X0, T X1, T X2, T 
   Jp[1][0] = A10 * R0 + A11 * R3 + A12 * R6;
   Jp[1][1] = A10 * R1 + A11 * R4 + A12 * R7;
   Jp[1][2] = A10 * R2 + A11 * R5 + A12 * R8;
+#ifdef SBA_F64_SCHED
+  if constexpr (sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);
+#endif
 
   // rotation block: A * dP/drho,  dP/drho = q rho^T - a [X]x + b rho X^T + b (rho.X) I
   const T h0 = cp[CP_RHO + 0], h1 = cp[CP_RHO + 1], h2 = cp[CP_RHO + 2];
