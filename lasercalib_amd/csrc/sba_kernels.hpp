@@ -1760,8 +1760,11 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
   T* s_Ured = s_U + NPROD * UPKS;                                        // [C][UPKB]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool producer = threadIdx.x < NPROD;
+  // the slice of this workgroup: a multiple of 8 points (one 32-deep k-step), NOT of the 16-point chunk -- at 50 000 points and 256
+  // workgroups that is 200 points = 12 chunks + 8 points on 250 workgroups instead of 13 chunks on 240; the half chunk at the end
+  // costs half (producer waves 0 and 1 work, the consumers take one k-step)
   int per = (N + ksplit - 1) / ksplit;
-  per = ((per + PTS - 1) / PTS) * PTS;
+  per = ((per + 7) / 8) * 8;
   const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
   const int nchunk = (pend - pbeg + PTS - 1) / PTS;
   // ---- prologue.  (Requesting the camera table and the first chunk for BOTH parameter sets next to the record, so that the
@@ -1858,7 +1861,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
     // byte offset of this lane's 8-byte slot inside a plane: half (q >> 2) & 1, row 16 e + c, slot sigma(q) ^ (c >> 1)
     const int lane_slot = ((q >> 2) & 1) * Cfg::HALF_BYTES + c * 64 + ((((q & 3) | ((q >> 3) << 2)) ^ (c >> 1)) << 3);
     for (int it = 0; it <= nchunk; ++it) {
-      if (it < nchunk) {
+      if (it < nchunk && (wid < 2 || pbeg + it * PTS + 8 < pend)) {      // (points 8 .. 15 of a chunk = the second k-step: waves 2, 3)
         unsigned char* pbuf = smem + (it & 1) * Cfg::BUF_BYTES;
         const bool valid = n_valid, have_pt = n_pt;
         const float2 m = n_uv;
@@ -1982,6 +1985,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
     for (int it = 0; it <= nchunk; ++it) {
       if (it >= 1) {
         const unsigned char* pbuf = smem + ((it - 1) & 1) * Cfg::BUF_BYTES;
+        const int nstep = (pend - (pbeg + (it - 1) * PTS) > 8) ? 2 : 1;     // k-steps the producers have written (last chunk: maybe one)
         static_for<0, Cfg::NV>([&](auto vc) {
           constexpr int V = decltype(vc)::value;
           if (cw == V) {
@@ -1989,6 +1993,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
             constexpr int RMIN = schur_tile_R(true, LO);
 #pragma unroll
             for (int s = 0; s < Cfg::K / 32; ++s) {
+              if (s >= nstep) break;
               // all three planes of this k-step are requested before the first MFMA (the scheduling barrier keeps the
               // compiler from sinking the reads next to their uses, which exposed one LDS round trip per few MFMAs)
               bf16x8_t fh[GROUP_TILES], fm[GROUP_TILES], fl[GROUP_TILES];
