@@ -39,7 +39,7 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # f32-in MFMA = vector rate 157
 # HBM bytes per launch come from the rocprofv3 PMC summaries committed under profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE
 # passes folded by tools/pmc_summary.py; traffic = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).
 # They are read at run time, newest round first, and only for the shape they were measured on; any other shape reports null.
-PMC_KERNEL_OF_SLOT = {"schur_fused": ("k_schur_fused_bf3", "k_schur_fused"), "schur": ("k_schur<", "k_schur_sym<"),
+PMC_KERNEL_OF_SLOT = {"schur_fused": ("k_schur_fused_bf3", "k_schur_fused_f64", "k_schur_fused"), "schur": ("k_schur<", "k_schur_sym<"),
                       "resjac": ("k_resjac<",), "linearize_points": ("k_linearize_points<",), "linearize_cams": ("k_linearize_cams<",),
                       "backsub": ("k_backsub_dense<", "k_backsub_trial<"), "residual": ("k_residual<",)}
 
@@ -153,7 +153,8 @@ def roofline_of_step(kt, dtype, P, C, Nloc, M_local, shape):
         bf3 = fused and dtype == "f32" and os.environ.get("SBA_FUSED_MFMA", "bf3") != "f32"
         if fused:
             wide = C > 16 or P == 13        # csrc/sba_schur_wide.hpp: 17 .. 23 cameras, and every one-launch rig of the 13-parameter model
-            kname = "k_schur_fused_wide" if (wide and bf3) else "k_schur_fused_bf3" if bf3 else "k_schur_fused"
+            kname = ("k_schur_fused_f64" if dtype == "f64" else      # csrc/sba_schur_f64.hpp: the fp64 one-group kernel
+                     "k_schur_fused_wide" if (wide and bf3) else "k_schur_fused_bf3" if bf3 else "k_schur_fused")
         elif dtype == "f64":
             kname = "k_schur_sym<double>"
         else:
@@ -264,6 +265,8 @@ def main():
         prob.comm_init(_native.comm_unique_id(), 0, 1)
     comm = sdist.TorchComm() if (world > 1 and phase_api) else sdist.SoloComm()
 
+    per_solve = {}
+
     def make_runner(pr):
         E = torch.empty(pr.exchange_size(), dtype=torch.float64, device="cuda")
         sc = torch.empty(sdist.NSCALARS, dtype=torch.float64, device="cuda")
@@ -272,34 +275,57 @@ def main():
             """`iters` LM iterations from the initial guess; returns (seconds, costs)."""
             pr.set_params(x0)
             opts = pr.make_opts(ftol=0.0, xtol=0.0, gtol=0.0, max_iter=iters, always_relinearize=True, profile=profile)
-            barrier()
-            t0 = time.perf_counter()
             if not phase_api:
-                cams, pts, rep, log = pr.solve_lm(opts)          # N > 1: the library runs the sharded loop and its collectives
-                costs = [r.cost for r in log]
-            else:
+                # the library's own loop (N > 1: the sharded loop and its collectives).  A step is one LM iteration: the timed
+                # region is sba_lm_run, exactly `iters` iterations; the per-solve work either side of it -- sba_lm_begin (reset +
+                # cost of the initial point) and sba_lm_finish (gradient at the returned point, download of cameras and points into
+                # pageable host arrays) -- is timed separately and reported as `per_solve_us`
+                barrier()
+                tb = time.perf_counter()
                 pr.lm_begin(opts)
-                done = 0
-                while done < iters:
-                    for _ in range(min(32, iters - done)):      # 32 steps enqueued between two host polls
-                        pr.lm_linearize()
-                        pr.lm_form_reduced(E.data_ptr())
-                        if world > 1:
-                            dist.all_reduce(E)
-                        pr.lm_solve_trial(E.data_ptr(), sc.data_ptr())
-                        sc_all = comm.all_gather_rows(sc)
-                        pr.lm_decide_async(sc_all.data_ptr(), world)
-                    status, done = pr.lm_poll()
+                barrier()
+                t0 = time.perf_counter()
+                pr.lm_run()
+                barrier()
+                t1 = time.perf_counter()
                 costs = [r.cost for r in pr.iteration_log()]
                 pr.lm_finish()
+                barrier()
+                per_solve["lm_begin"] = (t0 - tb) * 1e6
+                per_solve["lm_finish"] = (time.perf_counter() - t1) * 1e6
+                return t1 - t0, costs
+            # phase API (torch.distributed carries the exchanges): same timed region, the iterations alone
             barrier()
-            return time.perf_counter() - t0, costs
+            tb = time.perf_counter()
+            pr.lm_begin(opts)
+            barrier()
+            t0 = time.perf_counter()
+            done = 0
+            while done < iters:
+                for _ in range(min(32, iters - done)):      # 32 steps enqueued between two host polls
+                    pr.lm_linearize()
+                    pr.lm_form_reduced(E.data_ptr())
+                    if world > 1:
+                        dist.all_reduce(E)
+                    pr.lm_solve_trial(E.data_ptr(), sc.data_ptr())
+                    sc_all = comm.all_gather_rows(sc)
+                    pr.lm_decide_async(sc_all.data_ptr(), world)
+                status, done = pr.lm_poll()
+            barrier()
+            t1 = time.perf_counter()
+            costs = [r.cost for r in pr.iteration_log()]
+            pr.lm_finish()
+            barrier()
+            per_solve["lm_begin"] = (t0 - tb) * 1e6
+            per_solve["lm_finish"] = (time.perf_counter() - t1) * 1e6
+            return t1 - t0, costs
         return run
 
     run = make_runner(prob)
     if a.warmup > 0:
         run(a.warmup)
     dt, costs = run(a.steps)
+    per_solve_main = dict(per_solve)
     run(min(a.steps, 20), profile=True)      # separate pass with one HIP event pair per kernel class per step
     t = torch.tensor([dt], dtype=torch.float64, device="cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu")
     if world > 1:
@@ -345,6 +371,11 @@ def main():
             "fused_linearize_mobs_per_s": M_local / (kt["schur"] if fused else (kt["linearize_points"] + kt["linearize_cams"])),
             "linearize_fused_into_schur": bool(fused),
             "kernel_us": kt, "step_us": step_us,
+            # the timed region is the K iterations (sba_lm_run); once per solve, outside it: sba_lm_begin (reset + cost of the initial
+            # point) and sba_lm_finish (gradient at the returned point + download of cameras and points to pageable host memory)
+            "timed_region": "K LM iterations (sba_lm_run) between sba_lm_begin and sba_lm_finish",
+            "per_solve_us": per_solve_main,
+            "ms_per_step_with_begin_and_finish": (dt + (per_solve_main.get("lm_begin", 0.0) + per_solve_main.get("lm_finish", 0.0)) * 1e-6) / a.steps * 1e3,
             "cost_first_last": [costs[0], costs[-1]] if costs else None,
             "roofline": roof, "roofline_resjac": rj,
         }

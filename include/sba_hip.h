@@ -196,6 +196,12 @@ int sba_lm_decide(sba_handle* h, const double* scalars_all_dev /*n_ranks*8*/, in
 int sba_lm_decide_async(sba_handle* h, const double* scalars_all_dev /* NULL when n_ranks == 1 */, int32_t n_ranks);
 int sba_lm_poll(sba_handle* h, int32_t* status_out, int32_t* iterations_out);
 int sba_lm_finish(sba_handle* h, double* cams_out, double* points_out, sba_lm_report* report);
+/* The iteration loop of sba_solve_lm alone, on a solve begun with sba_lm_begin: iterations are enqueued in batches and polled
+ * until the device-side state terminates (tolerances or max_iter of the options given to sba_lm_begin); single-rank handles run
+ * linearise -> reduced system -> solve + trial -> decide, handles with a communicator the sharded loop with its exchanges.
+ * sba_solve_lm = sba_lm_begin + sba_lm_run + sba_lm_finish.  (bench.py times exactly the K iterations with it: the initial
+ * cost evaluation of sba_lm_begin and the gradient + result download of sba_lm_finish are per-solve work, not per-step.) */
+int sba_lm_run(sba_handle* h, int32_t* status_out, int32_t* iterations_out);
 /* Camera step delta_c (n_cams * params doubles) of the last sba_lm_solve_trial: the solution of the damped reduced camera
  * system the exchange buffer described.  A test hook -- the reduced system may be ANY symmetric positive definite matrix the
  * caller wrote into the exchange buffer, which is how tests/test_gpu_cholesky.py checks every factorisation kernel on its own. */

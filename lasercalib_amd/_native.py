@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "sba_create", "sba_upload", "sba_set_params", "sba_get_params", "sba_destroy",
     "sba_get_gradient", "sba_get_transform", "sba_lm_get_step", "sba_ipc_export", "sba_ipc_attach", "sba_residual", "sba_residual_jacobian", "sba_solve_lm",
     "sba_lm_exchange_size", "sba_lm_begin", "sba_lm_linearize", "sba_lm_form_reduced",
-    "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_finish", "sba_lm_get_log", "sba_time_kernel", "sba_get_kernel_profile",
+    "sba_lm_solve_trial", "sba_lm_decide", "sba_lm_decide_async", "sba_lm_poll", "sba_lm_run", "sba_lm_finish", "sba_lm_get_log", "sba_time_kernel", "sba_get_kernel_profile",
     "sba_comm_get_unique_id", "sba_comm_init", "sba_set_fixed_points", "sba_set_robust_loss",
 )
 
@@ -129,6 +129,7 @@ def load():
                                     C.POINTER(C.c_int32), C.POINTER(LmIterLog)]),
         "sba_lm_decide_async": (C.c_int, [H, C.c_void_p, C.c_int32]),
         "sba_lm_poll": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "sba_lm_run": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "sba_lm_finish": (C.c_int, [H, dp, dp, C.POINTER(LmReport)]),
         "sba_lm_get_log": (C.c_int, [H, C.POINTER(LmIterLog), C.c_int32, C.POINTER(C.c_int32)]),
         "sba_time_kernel": (C.c_int, [H, C.c_char_p, C.c_int32, dp]),
@@ -413,6 +414,12 @@ class Problem:
     def lm_poll(self):
         status, iters = C.c_int32(), C.c_int32()
         _check(self._lib.sba_lm_poll(self._h, C.byref(status), C.byref(iters)), self._h)
+        return status.value, iters.value
+
+    def lm_run(self):
+        """The iteration loop of solve_lm alone (between lm_begin and lm_finish); returns (status, iterations)."""
+        status, iters = C.c_int32(), C.c_int32()
+        _check(self._lib.sba_lm_run(self._h, C.byref(status), C.byref(iters)), self._h)
         return status.value, iters.value
 
     def lm_finish(self):

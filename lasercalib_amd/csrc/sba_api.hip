@@ -205,6 +205,11 @@ int sba_lm_poll(sba_handle* h, int32_t* status_out, int32_t* iterations_out) {
   if (!h) return SBA_ERR_INVALID;
   return guarded(h, [&] { return h->eng->lm_poll(status_out, iterations_out); });
 }
+
+int sba_lm_run(sba_handle* h, int32_t* status_out, int32_t* iterations_out) {
+  if (!h) return SBA_ERR_INVALID;
+  return guarded(h, [&] { return h->eng->lm_run(status_out, iterations_out); });
+}
 int sba_lm_get_log(sba_handle* h, sba_lm_iter_log* log, int32_t log_capacity, int32_t* log_rows) {
   if (!h || !log_rows) return SBA_ERR_INVALID;
   return h->eng->get_log(log, log_capacity, log_rows);

@@ -249,6 +249,7 @@ struct EngineBase {
   virtual int lm_decide(const double* scal_all, int n_ranks, int32_t* status_out, int32_t* accepted_out, sba_lm_iter_log* row) = 0;
   virtual int lm_decide_async(const double* scal_all, int n_ranks) = 0;
   virtual int lm_poll(int32_t* status_out, int32_t* iterations_out) = 0;
+  virtual int lm_run(int32_t* status_out, int32_t* iterations_out) = 0;
   virtual int lm_finish(double* cams_out, double* pts_out, sba_lm_report* rep) = 0;
   virtual int get_log(sba_lm_iter_log* log, int32_t cap, int32_t* rows) = 0;
   virtual int get_kernel_profile(double* total_us, int64_t* count) = 0;

@@ -1213,14 +1213,16 @@ struct Engine : EngineBase {
     {
       const int fc = (int)h_state->free_cams;
       const bool wide = fused() && fused_wide;
-      // (wide: one slab per workgroup with ntw (ntw + 1) / 2 tiles; the kernel counts its tile blocks as 4 * 121 * npairs, so one
-      //  "pair" of 121 tile slots per 121 tiles is passed)
-      const int ntw = wide_ntw(C), wide_pairs = (ntw * (ntw + 1) / 2 + GROUP_TILES * GROUP_TILES - 1) / (GROUP_TILES * GROUP_TILES);
-      const int np_arg = wide ? wide_pairs : npairs;
-      const int nblocks = (fc ? 4 * GROUP_TILES * GROUP_TILES * np_arg + (n + 15) / 16 : 0) + 1;
+      // (wide: one slab per workgroup with ntw (ntw + 1) / 2 tiles, passed as one "pair")
+      // tile slots per pair the grid covers: one pair -> its own tile count (no workgroups that return at once)
+      const int ntw = wide_ntw(C);
+      const int nt_launch = wide ? ntw * (ntw + 1) / 2 : npairs == 1 ? GROUP_TILES * (GROUP_TILES + 1) / 2 : GROUP_TILES * GROUP_TILES;
+      const int np_arg = wide ? 1 : npairs;
+      const int nblocks = (fc ? 4 * nt_launch * np_arg + (n + 15) / 16 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, np_arg, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_wide) ? 3 : (fused() && fused_bf3 && sizeof(T) == 4) ? 1 : (diag_pairs_bf3() ? (offdiag_pairs_bf3() ? 1 : 2) : 0));
+                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_wide) ? 3 : (fused() && fused_bf3 && sizeof(T) == 4) ? 1 : (diag_pairs_bf3() ? (offdiag_pairs_bf3() ? 1 : 2) : 0),
+                         nt_launch);
     }
     prof_end(KP_REDUCE);
     return SBA_OK;
@@ -1531,16 +1533,9 @@ struct Engine : EngineBase {
     return SBA_OK;
   }
 
-  int solve(const sba_lm_opts* o, double* cams_out, double* pts_out, sba_lm_report* rep, sba_lm_iter_log* lg, int cap,
-            int32_t* rows) override {
-    const auto t0 = std::chrono::steady_clock::now();
-    static const bool solve_debug = getenv("SBA_SOLVE_DEBUG") != nullptr;      // host-side phase times of one solve on stderr
-    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6; };
-    int rc = lm_begin(o);
-    if (rc) return rc;
-    const double t_begin = since();
-    HIPCHK(hipEventRecord(ev0, stream));
-    int32_t status = -1, iters = 0;
+  // the iteration loop of a solve between lm_begin and lm_finish: batches of iterations enqueued back to back, one poll per batch
+  int run_loop(const sba_lm_opts* o, int32_t& status, int32_t& iters) {
+    int rc = SBA_OK;
     while (status < 0) {
       // a batch of iterations is enqueued back to back; the kernels turn into no-ops once the device-side state says the
       // solve has terminated, and a rejected step skips its re-linearization on the device, not on the host
@@ -1595,6 +1590,32 @@ struct Engine : EngineBase {
       rc = lm_poll(&status, &iters);
       if (rc) return rc;
     }
+    return SBA_OK;
+  }
+
+  // sba_lm_run: the loop alone on a solve begun with sba_lm_begin (bench.py times exactly the iterations with it)
+  int lm_run(int32_t* status_out, int32_t* iterations_out) override {
+    if (!lm_active) { err = "sba_lm_begin has not been called"; return SBA_ERR_STATE; }
+    int32_t status = -1, iters = 0;
+    const int rc = run_loop(&opts, status, iters);
+    if (rc) return rc;
+    if (status_out) *status_out = status;
+    if (iterations_out) *iterations_out = iters;
+    return SBA_OK;
+  }
+
+  int solve(const sba_lm_opts* o, double* cams_out, double* pts_out, sba_lm_report* rep, sba_lm_iter_log* lg, int cap,
+            int32_t* rows) override {
+    const auto t0 = std::chrono::steady_clock::now();
+    static const bool solve_debug = getenv("SBA_SOLVE_DEBUG") != nullptr;      // host-side phase times of one solve on stderr
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6; };
+    int rc = lm_begin(o);
+    if (rc) return rc;
+    const double t_begin = since();
+    HIPCHK(hipEventRecord(ev0, stream));
+    int32_t status = -1, iters = 0;
+    rc = run_loop(o, status, iters);
+    if (rc) return rc;
     const double t_loop = since();
     HIPCHK(hipEventRecord(ev1, stream));
     HIPCHK(hipEventSynchronize(ev1));

@@ -36,7 +36,10 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     int emajor_mode = 0 /* parameter-major tiles (tile (R, Tc) holds parameters (R, Tc) of the camera pairs, row 16 e + c):
                            1 = every pair (k_schur_fused_bf3), 2 = the diagonal pairs (k_schur_diag_bf3),
                            3 = k_schur_fused_wide: one slab per workgroup, compact rows e*C + c in ceil(11 C / 16) tiles, row partials
-                               (bpart / gdpart) in the exchange buffer's own order with a stride of WIDE_ROWS */) {
+                               (bpart / gdpart) in the exchange buffer's own order with a stride of WIDE_ROWS */,
+    int nt_launch = GROUP_TILES * GROUP_TILES /* tile slots per pair the grid covers: 121 with several pairs (an off-diagonal pair has
+                           that many), the pair's own count -- 66, or the wide kernel's ntw (ntw + 1) / 2 -- when there is one pair: the
+                           220 workgroups of 16 waves that returned at once cost a third of the launch */) {
   using M_ = Mfma<T>;
   // tiles: 64 entries x 16 k-split groups per block (256-byte segments per group load; 16 entries x 64 groups was
   // measured slower: 64-byte segments, four times the blocks).  Rows: 16 rows x 64 groups, see below.
@@ -47,14 +50,14 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
   __shared__ double scr[16];
   constexpr int NT = GROUP_TILES * GROUP_TILES;
   const int n = C * NCP;
-  const int tile_blocks = free_cams ? BPT * NT * npairs : 0;
+  const int tile_blocks = free_cams ? BPT * nt_launch * npairs : 0;
   const int row_blocks = free_cams ? (n + 15) / 16 : 0;
   const int g = threadIdx.x / EPB, l16 = threadIdx.x & (EPB - 1);
   int bid = blockIdx.x;
   if (bid < tile_blocks) {
     const bool wide = emajor_mode == 3;
-    const int pair = wide ? 0 : bid / (BPT * NT);
-    const int rem = bid - pair * BPT * NT;
+    const int pair = wide ? 0 : bid / (BPT * nt_launch);
+    const int rem = bid - pair * BPT * nt_launch;
     const int t = rem / BPT, part = rem - t * BPT;
     const int ga = pair_ga[pair], gb = pair_gb[pair];
     const bool diag = wide || (ga == gb);
@@ -80,14 +83,24 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
     const size_t stride = wide ? (size_t)WIDE_SLOTS * 256 : (size_t)NT * 256;
     const T* src = slabs + (size_t)pair * ksplit * stride + (size_t)t * 256 + e;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int k = g;
-    for (; k + 3 * NG < ksplit; k += 4 * NG) {
-      s0 += (double)src[(size_t)k * stride];
-      s1 += (double)src[(size_t)(k + NG) * stride];
-      s2 += (double)src[(size_t)(k + 2 * NG) * stride];
-      s3 += (double)src[(size_t)(k + 3 * NG) * stride];
+    if (ksplit == 16 * NG) {
+      // one workgroup per CU (256 slabs): every group adds exactly 16 of them -- all 16 loads are in flight at once instead of four
+      // rounds of four (the kernel is a chain of memory round trips, not a bandwidth problem); same summation order as the loop below
+      T v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(g + u * NG) * stride];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) { s0 += (double)v[u]; s1 += (double)v[u + 1]; s2 += (double)v[u + 2]; s3 += (double)v[u + 3]; }
+    } else {
+      int k = g;
+      for (; k + 3 * NG < ksplit; k += 4 * NG) {
+        s0 += (double)src[(size_t)k * stride];
+        s1 += (double)src[(size_t)(k + NG) * stride];
+        s2 += (double)src[(size_t)(k + 2 * NG) * stride];
+        s3 += (double)src[(size_t)(k + 3 * NG) * stride];
+      }
+      for (; k < ksplit; k += NG) s0 += (double)src[(size_t)k * stride];
     }
-    for (; k < ksplit; k += NG) s0 += (double)src[(size_t)k * stride];
     const int ci_ = i / NCP, cj_ = j / NCP;
     s_p[g][l16] = (s0 + s1) + (s2 + s3);
     __syncthreads();

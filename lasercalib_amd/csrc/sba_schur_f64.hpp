@@ -37,13 +37,43 @@ struct SchurF64Cfg {
   // producer wave and camera, added to with ds_add_f64 (the four points of a wave meet in the same slot; with all 77 in registers
   // the producers ran 180 bytes of scratch per lane, ten accumulators read-modify-written in memory every chunk)
   static constexpr int KREG = 52, NL = UPK - KREG;
+  static constexpr int KS = KREG + 1;                        // hand-over stride of a lane (53 doubles = 106 words: 64 lanes, 32 even bank pairs, no conflict)
   static constexpr size_t CAM_OFF = (size_t)2 * BUF * sizeof(double);
   static constexpr size_t URED_OFF = CAM_OFF + (size_t)GROUP_CAMS * CAMPRE * sizeof(double);
   static constexpr size_t ACC_OFF = URED_OFF + (size_t)GROUP_CAMS * UPK * sizeof(double);
   static constexpr size_t LDS_BYTES = ACC_OFF + (size_t)(NPROD / 64) * GROUP_CAMS * NL * sizeof(double);
 };
-static_assert((size_t)SchurF64Cfg::NPROD * SchurF64Cfg::KREG * sizeof(double) <= SchurF64Cfg::CAM_OFF, "the hand-over area is the two panel buffers");
+static_assert((size_t)SchurF64Cfg::NPROD * SchurF64Cfg::KS * sizeof(double) <= SchurF64Cfg::CAM_OFF, "the hand-over area is the two panel buffers");
 static_assert(SchurF64Cfg::LDS_BYTES + 1024 <= 160 * 1024, "LDS budget of a CU (static record, log row and scratch on top)");
+
+// L^-1 of the 3x3 SPD matrix (v00,v01,v02,v11,v12,v22) in double without sqrt / divide sequences: v_rsq_f64 (5e-8, tools/micro/
+// rsq_acc.hip) + two Newton steps (4e-15, then rounding level); straight-line like chol3_inv_fast(float): a failing pivot is
+// replaced by 1 and the verdict is one flag at the end
+__device__ __forceinline__ double rsqrt_nr2(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+  y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+  return y;
+}
+__device__ __forceinline__ bool chol3_inv_fast(const double v[6], double li[6]) {
+  const bool ok0 = v[0] > 0.0;
+  const double i00 = rsqrt_nr2(ok0 ? v[0] : 1.0);
+  const double l10 = v[1] * i00, l20 = v[2] * i00;
+  const double d11 = v[3] - l10 * l10;
+  const bool ok1 = d11 > 0.0;
+  const double i11 = rsqrt_nr2(ok1 ? d11 : 1.0);
+  const double l21 = (v[4] - l20 * l10) * i11;
+  const double d22 = v[5] - l20 * l20 - l21 * l21;
+  const bool ok2 = d22 > 0.0;
+  const double i22 = rsqrt_nr2(ok2 ? d22 : 1.0);
+  li[0] = i00;
+  li[1] = -l10 * i00 * i11;
+  li[2] = i11;
+  li[3] = (-l20 * i00 - l21 * li[1]) * i22;
+  li[4] = -l21 * i11 * i22;
+  li[5] = i22;
+  return ok0 && ok1 && ok2 && isfinite(i22) && isfinite(i11) && isfinite(i00);
+}
 
 // schur_consume (sba_kernels.hpp) with a runtime number of k-steps, for the last chunk of a workgroup's slice: it may hold fewer than
 // 16 points, and only the producer waves that have a point write their 12 panel rows (3 k-steps each)
@@ -85,7 +115,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
   extern __shared__ __align__(16) unsigned char smem[];
   using T = double;
   using Cfg = SchurF64Cfg;
-  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF, KREG = Cfg::KREG, NL = Cfg::NL;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF, KREG = Cfg::KREG, NL = Cfg::NL, KS = Cfg::KS;
   const bool stamp_wg = dbg && blockIdx.x == 0;
   if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();
   __shared__ LMState s_st;
@@ -96,7 +126,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
   T* s_cam = reinterpret_cast<T*>(smem + Cfg::CAM_OFF);           // [16][CAMPRE]
   T* s_Ured = reinterpret_cast<T*>(smem + Cfg::URED_OFF);         // [C][UPK]
   T* s_acc = reinterpret_cast<T*>(smem + Cfg::ACC_OFF);           // [4 producer waves][16][NL]
-  T* s_U = s_buf;                                                 // [256][KREG] once the panels are done with
+  T* s_U = s_buf;                                                 // [256][KS] once the panels are done with
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool producer = threadIdx.x < NPROD;
   // the slice of this workgroup: a multiple of 4 points (one producer wave's share of a chunk), NOT of the 16-point chunk -- at
@@ -152,7 +182,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
       T sum = 0;
       if (k < KREG) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) sum += s_U[(q * 16 + c) * KREG + k];
+        for (int q = 0; q < 16; ++q) sum += s_U[(q * 16 + c) * KS + k];
       } else {
 #pragma unroll
         for (int wv = 0; wv < NPROD / 64; ++wv) sum += s_acc[(wv * GROUP_CAMS + c) * NL + (k - KREG)];
@@ -210,7 +240,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
         T f[PF];
         T li[6];
         const T vd[6] = {v6[0] + lam * fmax_pos(E0), v6[1], v6[2], v6[3] + lam * fmax_pos(E1), v6[4], v6[5] + lam * fmax_pos(E2)};
-        const bool okp = have_pt && !fixedp && chol3_inv<T>(vd, li);
+        const bool okp = have_pt && !fixedp && chol3_inv_fast(vd, li);
 #pragma unroll
         for (int k = 0; k < PF; ++k) f[k] = (T)0;
         if (okp) {
@@ -284,7 +314,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
     }
     if (stamp_wg && threadIdx.x == 0) dbg[50] = clock64();
     // hand the register accumulators over (the panel buffers are free now)
-    static_for<0, KREG>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * KREG + k] = Uacc[k]; });
+    static_for<0, KREG>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * KS + k] = Uacc[k]; });
     const double cs = wave_sum(sq), gm = wave_max(gmx);
     if (lane == 0) { s_scr[0][wid] = cs; s_scr[1][wid] = gm; }
     __syncthreads();
