@@ -155,3 +155,26 @@ def test_decision_in_the_fused_prologue_equals_the_separate_kernel(kw, monkeypat
                 assert getattr(ra, f) == getattr(rb, f), f
     assert rep_a.cost == rep_b.cost and rep_a.optimality == rep_b.optimality
     assert np.array_equal(cams_a, cams_b) and np.array_equal(pts_a, pts_b)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_lm_run_is_the_loop_of_solve_lm(dtype):
+    """sba_solve_lm = sba_lm_begin + sba_lm_run + sba_lm_finish (include/sba_hip.h): the three calls give the log, the report and
+    the parameters of the one call, bit for bit.  bench.py times sba_lm_run alone."""
+    rig = make_rig(16, 2500, seed=5, visibility=0.9)
+    args = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    kw = dict(ftol=1e-6)
+    with _native.Problem(*args, dtype=dtype) as prob:
+        cams_a, pts_a, rep_a, log_a = prob.solve_lm(prob.make_opts(**kw))
+    with _native.Problem(*args, dtype=dtype) as prob:
+        prob.lm_begin(prob.make_opts(**kw))
+        status, iters = prob.lm_run()
+        log_b = prob.iteration_log()
+        cams_b, pts_b, rep_b = prob.lm_finish()
+    assert status == rep_a.status and iters == rep_a.iterations == rep_b.iterations
+    assert [r.cost for r in log_a] == [r.cost for r in log_b] and [r.accepted for r in log_a] == [r.accepted for r in log_b]
+    assert rep_a.cost == rep_b.cost and rep_a.optimality == rep_b.optimality and rep_a.nfev == rep_b.nfev
+    assert np.array_equal(cams_a, cams_b) and np.array_equal(pts_a, pts_b)
+    with _native.Problem(*args, dtype=dtype) as prob:                # without a solve in progress the call is refused
+        with pytest.raises(RuntimeError):
+            prob.lm_run()
