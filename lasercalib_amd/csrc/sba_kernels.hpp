@@ -1919,9 +1919,12 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
         if (cam_ok) {
           static_for<0, NCP>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
+            // (Jc[1][cx] = Jc[0][cy] = 0 structurally -- obs_resjac, and the robust scaling keeps zeros: those products are left out,
+            //  here and in U_c / g_c below; the results are the same bit for bit)
             T y[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) y[d] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
+            for (int d = 0; d < 3; ++d)
+              y[d] = e == CP_CX ? Jc[0][e] * Jt[0][d] : e == CP_CY ? Jc[1][e] * Jt[1][d] : Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
             Uacc[UPK + e] = __builtin_fmaf(y[2], f[8], __builtin_fmaf(y[1], f[7], __builtin_fmaf(y[0], f[6], Uacc[UPK + e])));
             // three-way split by round-to-nearest (v_cvt_pk_bf16_f32 converts and packs two values in one instruction): the
             // remainders y - h and (y - h) - m are exact in f32 and the last one has at most 8 significant bits
@@ -1954,9 +1957,15 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
           static_for<a, NCP>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             constexpr int k = a * NCP - (a * (a - 1)) / 2 + (b - a);
-            Uacc[k] = __builtin_fmaf(Jc[1][a], Jc[1][b], __builtin_fmaf(Jc[0][a], Jc[0][b], Uacc[k]));
+            constexpr bool t0 = a != CP_CY && b != CP_CY, t1 = a != CP_CX && b != CP_CX;      // row 0 (u) / row 1 (v) can be non-zero
+            if constexpr (t0 && t1) Uacc[k] = __builtin_fmaf(Jc[1][a], Jc[1][b], __builtin_fmaf(Jc[0][a], Jc[0][b], Uacc[k]));
+            else if constexpr (t0) Uacc[k] = __builtin_fmaf(Jc[0][a], Jc[0][b], Uacc[k]);
+            else if constexpr (t1) Uacc[k] = __builtin_fmaf(Jc[1][a], Jc[1][b], Uacc[k]);
           });
-          Uacc[NCP * (NCP + 1) / 2 + a] = __builtin_fmaf(Jc[1][a], r[1], __builtin_fmaf(Jc[0][a], r[0], Uacc[NCP * (NCP + 1) / 2 + a]));
+          constexpr int kg = NCP * (NCP + 1) / 2 + a;
+          if constexpr (a == CP_CX) Uacc[kg] = __builtin_fmaf(Jc[0][a], r[0], Uacc[kg]);
+          else if constexpr (a == CP_CY) Uacc[kg] = __builtin_fmaf(Jc[1][a], r[1], Uacc[kg]);
+          else Uacc[kg] = __builtin_fmaf(Jc[1][a], r[1], __builtin_fmaf(Jc[0][a], r[0], Uacc[kg]));
         });
       }
       if (stamp_wg && threadIdx.x == 0 && it < 20) dbg[2 * it] = clock64();

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
             constexpr int e = decltype(ec)::value;
             T y[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) y[d] = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
+            for (int d = 0; d < 3; ++d)      // (Jc[1][cx] = Jc[0][cy] = 0 structurally: those products are left out, same bits)
+              y[d] = e == CP_CX ? Jc[0][e] * Jt[0][d] : e == CP_CY ? Jc[1][e] * Jt[1][d] : Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
             Uacc[UPK + e] = __builtin_fmaf(y[2], f[8], __builtin_fmaf(y[1], f[7], __builtin_fmaf(y[0], f[6], Uacc[UPK + e])));
             auto pk = [](float lo, float hi) -> unsigned {
               unsigned v;
@@ -331,9 +332,15 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
           static_for<a, NCP>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             constexpr int k = a * NCP - (a * (a - 1)) / 2 + (b - a);
-            Uacc[k] = __builtin_fmaf(Jc[1][a], Jc[1][b], __builtin_fmaf(Jc[0][a], Jc[0][b], Uacc[k]));
+            constexpr bool t0 = a != CP_CY && b != CP_CY, t1 = a != CP_CX && b != CP_CX;      // row 0 (u) / row 1 (v) can be non-zero
+            if constexpr (t0 && t1) Uacc[k] = __builtin_fmaf(Jc[1][a], Jc[1][b], __builtin_fmaf(Jc[0][a], Jc[0][b], Uacc[k]));
+            else if constexpr (t0) Uacc[k] = __builtin_fmaf(Jc[0][a], Jc[0][b], Uacc[k]);
+            else if constexpr (t1) Uacc[k] = __builtin_fmaf(Jc[1][a], Jc[1][b], Uacc[k]);
           });
-          Uacc[NCP * (NCP + 1) / 2 + a] = __builtin_fmaf(Jc[1][a], r[1], __builtin_fmaf(Jc[0][a], r[0], Uacc[NCP * (NCP + 1) / 2 + a]));
+          constexpr int kg = NCP * (NCP + 1) / 2 + a;
+          if constexpr (a == CP_CX) Uacc[kg] = __builtin_fmaf(Jc[0][a], r[0], Uacc[kg]);
+          else if constexpr (a == CP_CY) Uacc[kg] = __builtin_fmaf(Jc[1][a], r[1], Uacc[kg]);
+          else Uacc[kg] = __builtin_fmaf(Jc[1][a], r[1], __builtin_fmaf(Jc[0][a], r[0], Uacc[kg]));
         });
       }
       if (stamp_wg && threadIdx.x == 0 && it < 20) dbg[2 * it] = clock64();
