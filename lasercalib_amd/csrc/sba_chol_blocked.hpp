@@ -26,7 +26,7 @@ constexpr int CB = 16;                 // block edge
 constexpr int CLD = 17;                // row stride inside a block (doubles)
 constexpr int CBS = CB * CLD;          // doubles per block
 constexpr int CHOLB_THREADS = 512;          // k_cholesky_stream
-constexpr int CHOLB_LDS_THREADS = 512;      // k_cholesky_blocked (1024 was measured: same 116k cycles, the pivot chain and the load set the time)
+constexpr int CHOLB_LDS_THREADS = 512;      // k_cholesky_blocked (1024 threads were measured twice: same time, the look-ahead phase is bound per SIMD, not per wave)
 constexpr int CHOLB_MAX_NB = 11;       // 176 rows
 
 __device__ inline int cb_off(int r, int c) { return (r * (r + 1) / 2 + c) * CBS; }
@@ -119,6 +119,29 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ Dt, const 
   for (int ks = 0; ks < 4; ++ks) prod = Mfma<double>::mma(Pa[4 * ks], Pb[4 * ks], prod);
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) Dt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg] - prod[rg];
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Two tiles at once: a wave's block product is 4 dependent MFMAs (256 cycles of issue, ~130 of latency each) behind an LDS round trip,
+// ~850 cycles during which the matrix pipe of its SIMD is busy 256 -- two independent products interleaved keep it busy.
+__device__ __forceinline__ void chol_update_tile2(double* __restrict__ Dt0, const double* __restrict__ Pa0_blk, const double* __restrict__ Pb0_blk,
+                                                  double* __restrict__ Dt1, const double* __restrict__ Pa1_blk, const double* __restrict__ Pb1_blk) {
+  const int lane = threadIdx.x & 63;
+  const int po = (lane & 15) * CLD + (lane >> 4);
+  double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { a0[ks] = Pa0_blk[po + 4 * ks]; b0[ks] = Pb0_blk[po + 4 * ks]; }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { a1[ks] = Pa1_blk[po + 4 * ks]; b1[ks] = Pb1_blk[po + 4 * ks]; }
+  Mfma<double>::acc_t acc0, acc1, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) { acc0[rg] = Dt0[((lane >> 4) + 4 * rg) * CLD + (lane & 15)]; acc1[rg] = Dt1[((lane >> 4) + 4 * rg) * CLD + (lane & 15)]; }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { p0 = Mfma<double>::mma(a0[ks], b0[ks], p0); p1 = Mfma<double>::mma(a1[ks], b1[ks], p1); }
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Dt0[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc0[rg] - p0[rg];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Dt1[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc1[rg] - p1[rg];
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -360,7 +383,10 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
         if (!chol16_wave<PIV_NEWTON>(Lb + cb_off(jb + 1, jb + 1))) { if (lane == 0) s_fail = 1; }
       }
     } else {
-      if (wid == 1) {
+      // The wave that shares its SIMD with wave 0 (wave 4: waves go round the four SIMDs, tools/micro/hw_id.hip) takes the light
+      // part, the right-hand side's tail, and stays out of the update: an f64 MFMA holds the SIMD's issue for 64 cycles and the pivot
+      // chain (~30 dependent f64 VALU instructions per pivot) gets three instructions in per MFMA (tools/micro/rate_f64.hip).
+      if (wid == 4) {
         // rhs tail: y_i -= sum_k L21[i][k] y_blk[k]
         for (int t = lane; t < m; t += 64) {
           const double* row = Lb + cb_off(jb + 1 + (t >> 4), jb) + (t & 15) * CLD;
@@ -369,16 +395,31 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
           for (int k = 0; k < CB; k += 2) { s0 += row[k] * s_y[jb * CB + k]; s1 += row[k + 1] * s_y[jb * CB + k + 1]; }
           s_y[(jb + 1) * CB + t] -= s0 + s1;
         }
-      }
-      // tiles (r,c), jb < c <= r < nb, except (jb+1,jb+1): enumerate the trailing block triangle from index 1
-      const int q = nb - jb - 1;
-      const int ntile = q * (q + 1) / 2;
-      for (int t = 1 + (wid - 1); t < ntile; t += (NW - 1)) {
-        const int rc = s_rc[t];
-        const int r = jb + 1 + (rc >> 8), c = jb + 1 + (rc & 255);
-        chol_update_tile(Lb + cb_off(r, c), Lb + cb_off(r, jb), Lb + cb_off(c, jb));
+      } else {
+        // tiles (r,c), jb < c <= r < nb, except (jb+1,jb+1): the trailing block triangle from index 1, dealt to the six workers two
+        // at a time
+        constexpr int NWORK = NW - 2;
+        const int wk = wid - 1 - (wid > 4 ? 1 : 0);
+        const int q = nb - jb - 1;
+        const int ntile = q * (q + 1) / 2;
+        auto tile_ptrs = [&](int t, double*& D, const double*& Pa, const double*& Pb) {
+          const int rc = s_rc[t];
+          const int r = jb + 1 + (rc >> 8), c = jb + 1 + (rc & 255);
+          D = Lb + cb_off(r, c); Pa = Lb + cb_off(r, jb); Pb = Lb + cb_off(c, jb);
+        };
+        for (int t = 1 + wk; t < ntile; t += 2 * NWORK) {
+          double *D0, *D1; const double *A0, *B0, *A1, *B1;
+          tile_ptrs(t, D0, A0, B0);
+          if (t + NWORK < ntile) {
+            tile_ptrs(t + NWORK, D1, A1, B1);
+            chol_update_tile2(D0, A0, B0, D1, A1, B1);
+          } else {
+            chol_update_tile(D0, A0, B0);
+          }
+        }
       }
     }
+    if (dbg && jb == 0 && lane == 0) dbg[40 + wid] = clock64();      // diagnostic: when each wave finished its share of C0
     __syncthreads();
     CHOL_STAMP();
   }

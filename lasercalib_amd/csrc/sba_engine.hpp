@@ -1313,6 +1313,9 @@ struct Engine : EngineBase {
           fprintf(stderr, "[chol stamps, cycles] load %lld  chol0 %lld |", st[1] - st[0], st[2] - st[1]);
           for (int j = 0; j < nb; ++j) fprintf(stderr, " B%d %lld C%d %lld |", j, st[3 + 2 * j] - st[2 + 2 * j], j, st[4 + 2 * j] - st[3 + 2 * j]);
           fprintf(stderr, " backsub %lld  epilogue %lld  total %lld\n", st[3 + 2 * nb] - st[2 + 2 * nb], st[4 + 2 * nb] - st[3 + 2 * nb], st[4 + 2 * nb] - st[0]);
+          fprintf(stderr, "[chol C0, cycles after B0's barrier, per wave]");
+          for (int w = 0; w < CHOLB_LDS_THREADS / 64; ++w) fprintf(stderr, " %lld", st[40 + w] - st[3]);
+          fprintf(stderr, "\n");
           chol_debug = false;
         }
       } else if (n_sys <= CHOL_LDS_MAX_N) {
