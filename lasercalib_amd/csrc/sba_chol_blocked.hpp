@@ -396,26 +396,50 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
           s_y[(jb + 1) * CB + t] -= s0 + s1;
         }
       } else {
-        // tiles (r,c), jb < c <= r < nb, except (jb+1,jb+1): the trailing block triangle from index 1, dealt to the six workers two
-        // at a time
+        // tiles (r,c), jb < c <= r < nb, except (jb+1,jb+1): the trailing block triangle in row-major order from index 1, a CONTIGUOUS
+        // run per worker: consecutive tiles share their row, so the row block's fragment (r, jb) stays in registers, the target and
+        // the column block's fragment advance by constant strides, and a tile costs 8 LDS reads, 4 MFMAs, 4 subtractions and 4 LDS
+        // writes.  (Measured, n = 176, sum of the ten look-ahead phases: table-driven tiles dealt round robin to seven workers 49.0k
+        //  cycles; six workers taking two tiles at a time with interleaved MFMA chains 49.7k; these strips 48.3k; sixteen waves 49k.
+        //  A tile costs a wave ~850 cycles in every variant and a SIMD ~450: neither the matrix pipe (256 per tile), the LDS (48)
+        //  nor the instruction count explains it alone -- DESIGN.md, what comes next.)
         constexpr int NWORK = NW - 2;
         const int wk = wid - 1 - (wid > 4 ? 1 : 0);
         const int q = nb - jb - 1;
         const int ntile = q * (q + 1) / 2;
-        auto tile_ptrs = [&](int t, double*& D, const double*& Pa, const double*& Pb) {
+        const int per = (ntile - 1 + NWORK - 1) / NWORK;
+        int t = 1 + wk * per;
+        const int t_hi = min(ntile, t + per);
+        if (t < t_hi) {
           const int rc = s_rc[t];
-          const int r = jb + 1 + (rc >> 8), c = jb + 1 + (rc & 255);
-          D = Lb + cb_off(r, c); Pa = Lb + cb_off(r, jb); Pb = Lb + cb_off(c, jb);
-        };
-        for (int t = 1 + wk; t < ntile; t += 2 * NWORK) {
-          double *D0, *D1; const double *A0, *B0, *A1, *B1;
-          tile_ptrs(t, D0, A0, B0);
-          if (t + NWORK < ntile) {
-            tile_ptrs(t + NWORK, D1, A1, B1);
-            chol_update_tile2(D0, A0, B0, D1, A1, B1);
-          } else {
-            chol_update_tile(D0, A0, B0);
+          int r = jb + 1 + (rc >> 8), c = jb + 1 + (rc & 255);
+          const int po = (lane & 15) * CLD + (lane >> 4);              // operand pattern: [row lane & 15][k = 4 ks + (lane >> 4)]
+          const int to = (lane >> 4) * CLD + (lane & 15);              // accumulator pattern: [row (lane >> 4) + 4 reg][col lane & 15]
+          while (t < t_hi) {
+            const double* Ap = Lb + cb_off(r, jb) + po;
+            double a[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a[ks] = Ap[4 * ks];
+            double* D = Lb + cb_off(r, c) + to;
+            const double* Bp = Lb + cb_off(c, jb) + po;
+            for (; c <= r && t < t_hi; ++c, ++t) {
+              double bq[4];
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) bq[ks] = Bp[4 * ks];
+              Mfma<double>::acc_t acc, prod = {0, 0, 0, 0};
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) acc[rg] = D[4 * rg * CLD];
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) prod = Mfma<double>::mma(a[ks], bq[ks], prod);
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) D[4 * rg * CLD] = acc[rg] - prod[rg];
+              D += CBS;
+              Bp += (c + 1) * CBS;                                      // cb_off(c + 1, jb) - cb_off(c, jb)
+            }
+            ++r;
+            c = jb + 1;
           }
+          __builtin_amdgcn_wave_barrier();
         }
       }
     }
