@@ -39,7 +39,7 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # f32-in MFMA = vector rate 157
 # HBM bytes per launch come from the rocprofv3 PMC summaries committed under profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE
 # passes folded by tools/pmc_summary.py; traffic = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).
 # They are read at run time, newest round first, and only for the shape they were measured on; any other shape reports null.
-PMC_KERNEL_OF_SLOT = {"schur_fused": ("k_schur_fused_bf3", "k_schur_fused_f64", "k_schur_fused"), "schur": ("k_schur<", "k_schur_sym<"),
+PMC_KERNEL_OF_SLOT = {"schur_fused": ("k_schur_fused_bf3", "k_schur_fused_f64", "k_schur_fused_wide", "k_schur_fused"), "schur": ("k_schur<", "k_schur_sym<"),
                       "resjac": ("k_resjac<",), "linearize_points": ("k_linearize_points<",), "linearize_cams": ("k_linearize_cams<",),
                       "backsub": ("k_backsub_dense<", "k_backsub_trial<"), "residual": ("k_residual<",)}
 
@@ -153,7 +153,7 @@ def roofline_of_step(kt, dtype, P, C, Nloc, M_local, shape):
         bf3 = fused and dtype == "f32" and os.environ.get("SBA_FUSED_MFMA", "bf3") != "f32"
         if fused:
             wide = C > 16 or P == 13        # csrc/sba_schur_wide.hpp: 17 .. 23 cameras, and every one-launch rig of the 13-parameter model
-            kname = ("k_schur_fused_f64" if dtype == "f64" else      # csrc/sba_schur_f64.hpp: the fp64 one-group kernel
+            kname = (("k_schur_fused_wide_f64" if C > 16 else "k_schur_fused_f64") if dtype == "f64" else      # csrc/sba_schur_f64.hpp
                      "k_schur_fused_wide" if (wide and bf3) else "k_schur_fused_bf3" if bf3 else "k_schur_fused")
         elif dtype == "f64":
             kname = "k_schur_sym<double>"

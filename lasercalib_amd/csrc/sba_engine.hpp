@@ -214,6 +214,8 @@ struct Engine : EngineBase {
       if constexpr (SCHUR_LIN_OK<T>) HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, false, true>)));
 #if SBA_NCP == 11
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurF64Cfg::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<12>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<13>::LDS_BYTES));
 #endif
     } else {
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, true, false>)));
@@ -500,6 +502,20 @@ struct Engine : EngineBase {
         ksplit = std::max(1, std::min(target, (N + 4 * wide_pw - 1) / (4 * wide_pw)));
       }
     }
+#if SBA_NCP == 11
+    // fp64, 17 and 18 cameras (12 / 13 row tiles): k_schur_fused_wide_f64 (sba_schur_f64.hpp), same eligibility; SBA_NO_FUSED64=1 or
+    // SBA_NO_WIDE=1 keep the pair kernels
+    if constexpr (sizeof(T) == 8) {
+      const bool dense_enough = (double)M >= 0.35 * (double)N * C;
+      fused_wide = C > GROUP_CAMS && C <= SchurWide64Cfg<13>::MAXC && (dense || (grp_indexed && dense_enough)) && N > 0 &&
+                   !getenv("SBA_NO_FUSED") && !getenv("SBA_NO_FUSED64") && !getenv("SBA_NO_WIDE");
+      if (fused_wide) {
+        int target = 256;
+        if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
+        ksplit = std::max(1, std::min(target, (N + 7) / 8));
+      }
+    }
+#endif
 
     for (int b = 0; b < 2; ++b) {
       cams[b].alloc((size_t)C * NCP); pts[b].alloc((size_t)N * 3);
@@ -609,6 +625,35 @@ struct Engine : EngineBase {
     }
 #if SBA_NCP == 11
     if constexpr (sizeof(T) == 8) {
+      if (fused() && fused_wide) {
+        double* gm_out = nullptr;
+        const FusedDecide fd = make_fused_decide(gm_out);
+        const bool tables = !dense;
+        const uint16_t* tmask = tables ? grp_mask.p : nullptr;
+        const int32_t* tstart = tables ? grp_start.p : nullptr;
+        auto go = [&](auto ntw_c) {
+          constexpr int NTW = decltype(ntw_c)::value;
+          hipLaunchKernelGGL((k_schur_fused_wide_f64<NTW>), dim3(ksplit), dim3(SCHUR_THREADS), SchurWide64Cfg<NTW>::LDS_BYTES, stream,
+                             ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, tmask, tstart, N, ksplit, D2p.p, gp.p, pfac.p, slabs.p, bpart.p,
+                             gdpart.p, cost_part.p, gm_out, (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr);
+        };
+        if (wide_ntw(C) == 12) go(std::integral_constant<int, 12>{}); else go(std::integral_constant<int, 13>{});
+        d_state.p = fd.st_out;
+        pending_decide = false;
+        gmax_cur = gm_out;
+        if (schur_debug && schur_debug_skip > 0) { --schur_debug_skip; return; }
+        if (schur_debug) {
+          std::vector<long long> st(64);
+          HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+          sync();
+          fprintf(stderr, "[schur_fused_wide_f64 stamps, cycles since the first producer stamp; per chunk of 8 points: producer-done consumer-done]\n");
+          for (int i = 0; i < 14; ++i) fprintf(stderr, "  it %2d: P %7lld  C %7lld\n", i, st[2 * i] - st[0], st[2 * i + 1] - st[0]);
+          fprintf(stderr, "  phases (cycles): prologue %lld | main loop %lld | fold U %lld | slab stores %lld | tail %lld | whole kernel %lld\n",
+                  st[49] - st[48], st[50] - st[49], st[51] - st[50], st[52] - st[51], st[53] - st[52], st[53] - st[48]);
+          schur_debug = false;
+        }
+        return;
+      }
       if (fused() && fused_f64) {
         double* gm_out = nullptr;
         const FusedDecide fd = make_fused_decide(gm_out);
@@ -1389,7 +1434,7 @@ struct Engine : EngineBase {
   bool offdiag_pairs_bf3() const { return diag_pairs_bf3() && !no_bf3_offdiag; }
   // (the name is historical: every Schur kernel that takes the previous step's decision in its prologue -- k_schur_fused_bf3,
   //  k_schur_fused_wide, k_schur_fused_f64)
-  bool bf3_path() const { return fused() && (sizeof(T) == 4 ? fused_bf3 : fused_f64) && !sq_mode(); }
+  bool bf3_path() const { return fused() && (sizeof(T) == 4 ? fused_bf3 : (fused_f64 || fused_wide)) && !sq_mode(); }
   const double* gmax_rd() const { return (bf3_path() && gmax_cur) ? gmax_cur : gmax_part.p; }
   void launch_decide(const double* scal_all, int n_ranks) {
     hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(DECIDE_THREADS), 0, stream, d_state.p, scal_all, n_ranks, trial_part.p,

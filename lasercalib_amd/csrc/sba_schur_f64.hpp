@@ -16,6 +16,7 @@
 //   Outputs are those of k_schur_fused in T = double: slab [121 tile slots][64 lanes][4] per workgroup, bpart, gdpart, pf, gp, D2p.
 #pragma once
 #include "sba_kernels.hpp"
+#include "sba_schur_wide.hpp"
 
 namespace SBA_NS {
 #if SBA_NCP == 11
@@ -400,6 +401,379 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
     for (int wv = 0; wv < NPROD / 64; ++wv) { cs += s_scr[0][wv]; gm = fmax(gm, s_scr[1][wv]); }
     cost_part[blockIdx.x] = 0.5 * cs;
     gmax_part[blockIdx.x] = gm;
+    if (stamp_wg) dbg[53] = clock64();
+  }
+}
+
+// ------------------------------------------------------------------ 17 and 18 cameras in fp64: the same kernel on compact rows
+// The reference's own example rig has 17 cameras (example/config.json:24-42) and PySBA computes in float64: above one camera group
+// the fp64 engine fell back to two linearisation launches + k_point_factor + three pair launches of k_schur_sym (541 us per step at
+// 17 x 50k against 196 at 16 x 50k).  k_schur_fused_wide's row scheme (sba_schur_wide.hpp) -- COMPACT parameter-major rows
+// row = e C + c, n = 11 C rows in NTW = ceil(n / 16) tiles: 12 tiles for 17 cameras, 13 for 18 -- with k_schur_fused_f64's arithmetic:
+//   producers  a wave holds TWO points, one per 32-lane half (lane -> half lane >> 5, camera lane & 31 < C); 8 points per chunk =
+//              24 panel rows = 6 k-steps of the f64 MFMA; per-point sums = DPP row sum + one v_permlane16_swap per dword;
+//              52 of the 77 U_c / g_c accumulators in registers, 25 in per-wave LDS sets (ds_add_f64), as above;
+//   panel      [24][16 NTW] doubles + z, double-buffered: a producer store is 32 consecutive doubles per row;
+//   consumers  4 waves, contiguous ranges of the NTW (NTW + 1) / 2 upper-triangular tiles (20 of 78, 23 of 91: 160 / 184
+//              accumulator VGPRs), the fragments of one k-step in registers;
+//   outputs    k_schur_fused_wide's: slab [WIDE_SLOTS][64 lanes][4] per workgroup (k_build_exchange, emajor_mode 3), bpart /
+//              gdpart rows in the exchange buffer's own order with a stride of WIDE_ROWS.
+// 19 cameras and more (14+ tiles: 27 tiles = 216 accumulator VGPRs per consumer wave) stay on the pair kernels.
+template <int NTW> struct SchurWide64Cfg {
+  using elem = double;
+  static constexpr int THREADS = SCHUR_THREADS, NPROD = 256, NV = 4;
+  static constexpr int ROWS = 16 * NTW;
+  static constexpr int NTILE = NTW * (NTW + 1) / 2;
+  static constexpr int TPW = (NTILE + NV - 1) / NV;
+  static constexpr int PTS = 8, K = 3 * PTS;
+  static constexpr int BUF = K * ROWS + K;                       // doubles: panel [K][ROWS] + z [K]
+  static constexpr int MAXC = 18;
+  static constexpr int KREG = SchurF64Cfg::KREG, NL = SchurF64Cfg::NL;
+  static constexpr int KH = KREG / 2, KS = KH + 1;               // register accumulators handed over per pass, lane stride (odd)
+  static constexpr size_t CAM_OFF = (size_t)2 * BUF * sizeof(double);
+  static constexpr size_t URED_OFF = CAM_OFF + (size_t)MAXC * CAMPRE * sizeof(double);
+  static constexpr size_t ACC_OFF = URED_OFF + (size_t)MAXC * UPK * sizeof(double);
+  static constexpr size_t LDS_BYTES = ACC_OFF + (size_t)(NPROD / 64) * MAXC * NL * sizeof(double);
+  static_assert(KREG % 2 == 0, "two hand-over passes");
+  static_assert((size_t)NPROD * KS * sizeof(double) <= CAM_OFF, "the hand-over area is the two panel buffers");
+  static_assert(CAM_OFF >= 5 * THREADS * sizeof(double), "the decision's scratch lives in the panel buffers");
+  static_assert(LDS_BYTES + 1024 <= 160 * 1024, "LDS budget of a CU");
+  static_assert(ROWS <= WIDE_ROWS && NTILE <= WIDE_SLOTS, "slab / row-partial strides of the wide path");
+};
+
+// sum over the 32 lanes of a wave half (two DPP rows) of a double, result in all 32
+__device__ __forceinline__ double half32_sum(double v) {
+  v = row16_sum(v);
+  unsigned lo0 = __double2loint(v), hi0 = __double2hiint(v), lo1 = lo0, hi1 = hi0;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
+               : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
+  return __hiloint2double(hi0, lo0) + __hiloint2double(hi1, lo1);
+}
+
+template <int NTW>
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
+    const ParamSets<double> ps, const FusedDecide fd, int C,
+    const double2* __restrict__ uv, const double* __restrict__ w,
+    const uint16_t* __restrict__ gmask /* [2][N] visibility masks of the two 16-camera groups, or NULL: dense */,
+    const int32_t* __restrict__ gstart /* [2][N] first observation of the point in the group */,
+    int N, int ksplit, double* __restrict__ D2p, double* __restrict__ gp, double* __restrict__ pf, double* __restrict__ slabs,
+    double* __restrict__ bpart, double* __restrict__ gdpart, double* __restrict__ cost_part, double* __restrict__ gmax_part,
+    long long* __restrict__ dbg) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using T = double;
+  using Cfg = SchurWide64Cfg<NTW>;
+  constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF, ROWS = Cfg::ROWS;
+  constexpr int KREG = Cfg::KREG, NL = Cfg::NL, KH = Cfg::KH, KS = Cfg::KS, MAXC = Cfg::MAXC;
+  const bool stamp_wg = dbg && blockIdx.x == 0;
+  if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();
+  __shared__ LMState s_st;
+  __shared__ LMLogRow s_row;
+  __shared__ int s_have_row;
+  __shared__ double s_scr[2][NPROD / 64];
+  T* s_buf = reinterpret_cast<T*>(smem);                          // [2][BUF]
+  T* s_cam = reinterpret_cast<T*>(smem + Cfg::CAM_OFF);           // [C][CAMPRE]
+  T* s_Ured = reinterpret_cast<T*>(smem + Cfg::URED_OFF);         // [C][UPK]
+  T* s_acc = reinterpret_cast<T*>(smem + Cfg::ACC_OFF);           // [4 producer waves][MAXC][NL]
+  T* s_U = s_buf;                                                 // [256][KS] once the panels are done with
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool producer = threadIdx.x < NPROD;
+  const int n = C * NCP;
+  int per = (N + ksplit - 1) / ksplit;
+  per = ((per + PTS - 1) / PTS) * PTS;
+  const int pbeg = min(N, (int)blockIdx.x * per), pend = min(N, pbeg + per);
+  const int nchunk = (pend - pbeg + PTS - 1) / PTS;
+  // ---- prologue: state record, the pending LM decision, zeroed panels (rows n .. ROWS - 1 are never written)
+  DecidePartials dp;
+  {
+    constexpr int NWORD = sizeof(LMState) / 4;
+    if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(fd.st_in)[threadIdx.x];
+    if (fd.do_decide) decide_gather(dp, fd.scal_all, fd.trial_part, fd.gmax_in, fd.n_trial, fd.n_gmax);
+    {
+      uint4* z4 = reinterpret_cast<uint4*>(smem);
+      for (int i = threadIdx.x; i < (int)(Cfg::CAM_OFF / 16); i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
+      for (int i = threadIdx.x; i < (NPROD / 64) * MAXC * NL; i += THREADS) s_acc[i] = 0.0;
+    }
+    asm volatile("" : "+v"(dp.a), "+v"(dp.b), "+v"(dp.c), "+v"(dp.d), "+v"(dp.g));
+    __syncthreads();
+    if (fd.do_decide) {
+      const bool running = s_st.status < 0;
+      bool have_row = false;
+      static_assert(THREADS == DECIDE_THREADS, "decide_fold is written for the thread count of this kernel");
+      if (running) have_row = decide_core(&s_st, dp, fd.scal_all, fd.n_ranks, &s_row, fd.log_cap, reinterpret_cast<double*>(smem), nullptr);
+      if (threadIdx.x == 0) s_have_row = have_row ? 1 : 0;
+      __syncthreads();
+      if (running && fd.scal_all == nullptr) {
+        uint4* z4 = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < 5 * THREADS * (int)sizeof(double) / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
+      }
+      if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(fd.st_out)[threadIdx.x] = reinterpret_cast<const int*>(&s_st)[threadIdx.x];
+        if (threadIdx.x == 0 && s_have_row && fd.log) fd.log[s_st.iter - 1] = s_row;
+      }
+    }
+  }
+  if (s_st.status >= 0) return;
+  const LMState* st = &s_st;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  for (int i = threadIdx.x; i < C * CAMPRE; i += THREADS) s_cam[i] = ps.campre[cur_][i];
+  const T lam = st->lam;
+  // fold the eight lanes that served camera c (4 waves x 2 halves) for the register accumulators [k0, k0 + KH) handed over through
+  // s_U, and -- in the second pass -- the four waves' LDS sets
+  auto fold_u = [&](int k0) {
+    for (int o = threadIdx.x; o < C * KH; o += THREADS) {
+      const int c = o / KH, k = o - c * KH;
+      T sum = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += s_U[(q * 32 + c) * KS + k];
+      s_Ured[c * UPK + k0 + k] = sum;
+    }
+    if (k0 != 0)
+      for (int o = threadIdx.x; o < C * NL; o += THREADS) {
+        const int c = o / NL, k = o - c * NL;
+        T sum = 0;
+#pragma unroll
+        for (int wv = 0; wv < NPROD / 64; ++wv) sum += s_acc[(wv * MAXC + c) * NL + k];
+        s_Ured[c * UPK + KREG + k] = sum;
+      }
+  };
+  if (stamp_wg && threadIdx.x == 0) dbg[49] = clock64();
+  __syncthreads();
+
+  if (producer) {
+    const int h = lane >> 5, c = lane & 31, q = 2 * wid + h;
+    const bool cam_ok = c < C;
+    const T* cp_safe = s_cam + (cam_ok ? c : 0) * CAMPRE;
+    const int grp = c >> 4, cc = c & 15;
+    const uint16_t* __restrict__ gm = gmask ? gmask + (size_t)grp * N : nullptr;
+    const int32_t* __restrict__ gs = gstart ? gstart + (size_t)grp * N : nullptr;
+    T Uacc[KREG];
+    static_for<0, KREG>([&](auto kc) { Uacc[decltype(kc)::value] = (T)0; });
+    T* acc_lane = s_acc + (wid * MAXC + (cam_ok ? c : 0)) * NL;
+    auto lds_add = [](T* slot, T v) { (void)__hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    T sq = 0, gmx = 0;
+    const int row0 = cam_ok ? c : 0, rstep = cam_ok ? C : 0;        // row of parameter e: e C + c
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it < nchunk) {
+        T* panel = s_buf + (it & 1) * BUF;
+        T* s_z = panel + K * ROWS;
+        const int p = pbeg + it * PTS + q;
+        const bool have_pt = p < pend;
+        const size_t pp = (size_t)(have_pt ? p : pbeg);
+        unsigned mask = 0xffffu;
+        size_t o = pp * C + c;
+        if (gm && cam_ok) { mask = gm[pp]; o = (size_t)gs[pp] + __builtin_popcount(mask & ((1u << cc) - 1u)); }
+        const bool valid = have_pt && cam_ok && ((mask >> cc) & 1u);
+        double2 m = make_double2(0., 0.);
+        T ww = 1;
+        if (valid) { m = uv[o]; if (w) ww = w[o]; }
+        const T X0 = ptsT[3 * pp], X1 = ptsT[3 * pp + 1], X2 = ptsT[3 * pp + 2];
+        T r[2], Jc[2][NCP], Jp[2][3];
+        obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
+        sq += robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+        T v6[6], g3[3];
+        v6[0] = half32_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
+        v6[1] = half32_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
+        v6[2] = half32_sum(Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2]);
+        v6[3] = half32_sum(Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1]);
+        v6[4] = half32_sum(Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2]);
+        v6[5] = half32_sum(Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2]);
+        g3[0] = half32_sum(Jp[0][0] * r[0] + Jp[1][0] * r[1]);
+        g3[1] = half32_sum(Jp[0][1] * r[0] + Jp[1][1] * r[1]);
+        g3[2] = half32_sum(Jp[0][2] * r[0] + Jp[1][2] * r[1]);
+        const bool fixedp = have_pt && pt_fixed(ps, (size_t)p);
+        if (!fixedp) gmx = fmax(gmx, fmax(fabs(g3[0]), fmax(fabs(g3[1]), fabs(g3[2]))));
+        const double E0 = fmax(D2p[3 * pp], v6[0]), E1 = fmax(D2p[3 * pp + 1], v6[3]), E2 = fmax(D2p[3 * pp + 2], v6[5]);
+        T f[PF];
+        T li[6];
+        const T vd[6] = {v6[0] + lam * fmax_pos(E0), v6[1], v6[2], v6[3] + lam * fmax_pos(E1), v6[4], v6[5] + lam * fmax_pos(E2)};
+        const bool okp = have_pt && !fixedp && chol3_inv_fast(vd, li);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) f[k] = (T)0;
+        if (okp) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) f[k] = li[k];
+          f[6] = li[0] * g3[0];
+          f[7] = li[1] * g3[0] + li[2] * g3[1];
+          f[8] = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
+          f[9] = (T)1;
+        }
+        if (have_pt && c == 0) {
+          D2p[3 * (size_t)p] = E0; D2p[3 * (size_t)p + 1] = E1; D2p[3 * (size_t)p + 2] = E2;
+          gp[3 * (size_t)p] = g3[0]; gp[3 * (size_t)p + 1] = g3[1]; gp[3 * (size_t)p + 2] = g3[2];
+          double2* o2 = reinterpret_cast<double2*>(pf + (size_t)p * PF);
+#pragma unroll
+          for (int k = 0; k < PF / 2; ++k) o2[k] = make_double2(f[2 * k], f[2 * k + 1]);
+        }
+        constexpr auto nz0 = [](int e) { return e != CP_CY; };      // row 0 (u) of column e can be non-zero
+        constexpr auto nz1 = [](int e) { return e != CP_CX; };
+        if (cam_ok) {
+          T Jt[2][3];
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            Jt[rr][0] = Jp[rr][0] * f[0];
+            Jt[rr][1] = Jp[rr][0] * f[1] + Jp[rr][1] * f[2];
+            Jt[rr][2] = Jp[rr][0] * f[3] + Jp[rr][1] * f[4] + Jp[rr][2] * f[5];
+          }
+          T* pan = panel + 3 * q * ROWS + row0;
+          const bool degenerate = f[9] == (T)0;
+          static_for<0, NCP>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              T y;
+              if constexpr (!nz1(e)) y = Jc[0][e] * Jt[0][d];
+              else if constexpr (!nz0(e)) y = Jc[1][e] * Jt[1][d];
+              else y = Jc[0][e] * Jt[0][d] + Jc[1][e] * Jt[1][d];
+              pan[d * ROWS + e * rstep] = degenerate ? (T)0 : y;
+            }
+          });
+          if (c == 0) { s_z[3 * q + 0] = f[6]; s_z[3 * q + 1] = f[7]; s_z[3 * q + 2] = f[8]; }
+          static_for<0, NCP>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            static_for<a, NCP>([&](auto bc) {
+              constexpr int b = decltype(bc)::value;
+              constexpr int k = a * NCP - (a * (a - 1)) / 2 + (b - a);
+              constexpr bool t0 = nz0(a) && nz0(b), t1 = nz1(a) && nz1(b);
+              if constexpr (k < KREG) {
+                if constexpr (t0 && t1) Uacc[k] = __builtin_fma(Jc[1][a], Jc[1][b], __builtin_fma(Jc[0][a], Jc[0][b], Uacc[k]));
+                else if constexpr (t0) Uacc[k] = __builtin_fma(Jc[0][a], Jc[0][b], Uacc[k]);
+                else if constexpr (t1) Uacc[k] = __builtin_fma(Jc[1][a], Jc[1][b], Uacc[k]);
+              } else {
+                if constexpr (t0 && t1) lds_add(acc_lane + (k - KREG), __builtin_fma(Jc[1][a], Jc[1][b], Jc[0][a] * Jc[0][b]));
+                else if constexpr (t0) lds_add(acc_lane + (k - KREG), Jc[0][a] * Jc[0][b]);
+                else if constexpr (t1) lds_add(acc_lane + (k - KREG), Jc[1][a] * Jc[1][b]);
+              }
+            });
+            constexpr int kg = NCP * (NCP + 1) / 2 + a;
+            static_assert(kg >= KREG, "g_c lives in LDS");
+            if constexpr (nz0(a) && nz1(a)) lds_add(acc_lane + (kg - KREG), __builtin_fma(Jc[1][a], r[1], Jc[0][a] * r[0]));
+            else if constexpr (nz0(a)) lds_add(acc_lane + (kg - KREG), Jc[0][a] * r[0]);
+            else lds_add(acc_lane + (kg - KREG), Jc[1][a] * r[1]);
+          });
+        }
+      }
+      if (stamp_wg && threadIdx.x == 0 && it < 20) dbg[2 * it] = clock64();
+      __syncthreads();
+    }
+    if (stamp_wg && threadIdx.x == 0) dbg[50] = clock64();
+    // hand the register accumulators over in two passes (the panel buffers are free now)
+    static_for<0, KH>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * KS + k] = Uacc[k]; });
+    const double cs = wave_sum(sq), gm_ = wave_max(gmx);
+    if (lane == 0) { s_scr[0][wid] = cs; s_scr[1][wid] = gm_; }
+    __syncthreads();
+    fold_u(0);
+    __syncthreads();
+    static_for<0, KH>([&](auto kc) { constexpr int k = decltype(kc)::value; s_U[threadIdx.x * KS + k] = Uacc[KH + k]; });
+    __syncthreads();
+    fold_u(KH);
+    __syncthreads();
+  } else {
+    const int cw = wid - NPROD / 64;
+    typename Mfma<T>::acc_t acc[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) acc[s] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+    const int ct = threadIdx.x - NPROD;
+    const int lane_off = (lane >> 4) * ROWS + (lane & 15);
+    double bacc = 0;
+    for (int it = 0; it <= nchunk; ++it) {
+      if (it >= 1) {
+        const T* panel = s_buf + ((it - 1) & 1) * BUF;
+        const T* s_z = panel + K * ROWS;
+        if (ct < ROWS) {                  // right-hand side: b_row += sum_k panel[k][row] z[k]
+          T s0 = 0, s1 = 0;
+#pragma unroll 4
+          for (int k = 0; k < K; k += 2) { s0 += panel[k * ROWS + ct] * s_z[k]; s1 += panel[(k + 1) * ROWS + ct] * s_z[k + 1]; }
+          bacc += s0 + s1;
+        }
+        const T* pl = panel + lane_off;
+        static_for<0, Cfg::NV>([&](auto vc) {
+          constexpr int V = decltype(vc)::value;
+          if (cw == V) {
+            constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
+            constexpr int RMIN = wide_tile_R<NTW>(LO);
+#pragma unroll
+            for (int ks = 0; ks < K / 4; ++ks) {
+              T fa[NTW];
+#pragma unroll
+              for (int b = RMIN; b < NTW; ++b) fa[b] = pl[ks * 4 * ROWS + 16 * b];
+              __builtin_amdgcn_sched_barrier(0);
+              static_for<LO, HI>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int R = wide_tile_R<NTW>(t), Tc = wide_tile_T<NTW>(t);
+                acc[t - LO] = Mfma<T>::mma(fa[R], fa[Tc], acc[t - LO]);
+              });
+            }
+          }
+        });
+      }
+      if (stamp_wg && threadIdx.x == NPROD && it < 20) dbg[2 * it + 1] = clock64();
+      __syncthreads();
+    }
+    __syncthreads();
+    fold_u(0);
+    __syncthreads();
+    __syncthreads();
+    fold_u(KH);
+    __syncthreads();
+    // the camera's own block U_c sits wherever row and column belong to the same camera (row = e C + c, column = e' C + c): of the
+    // lane's four rows rho0 + 4 reg at most one is congruent to its column modulo C (C > 12)
+    const float invC = 1.0f / (float)C;
+    static_for<0, Cfg::NV>([&](auto vc) {
+      constexpr int V = decltype(vc)::value;
+      if (cw == V) {
+        constexpr int T0 = schur_lo(Cfg::NTILE, Cfg::NV, V), T1 = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
+        static_for<T0, T1>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int R = wide_tile_R<NTW>(t), Tc = wide_tile_T<NTW>(t);
+          const int kap = 16 * Tc + (lane & 15), rho0 = 16 * R + (lane >> 4);
+          const int dif = kap - rho0 + 16 * C;                                    // > 0, same residue modulo C
+          const int dq = (int)(((float)dif + 0.5f) * invC), d = dif - dq * C;     // (kap - rho0) mod C
+          if ((d & 3) == 0 && d < 16 && kap < n && rho0 + d < n) {
+            const int rho = rho0 + d;
+            const int er = (int)(((float)rho + 0.5f) * invC), cr = rho - er * C;
+            const int ek = (int)(((float)kap + 0.5f) * invC);
+            const int a = min(er, ek), b = max(er, ek);
+            const T u = s_Ured[cr * UPK + (a * NCP - (a * (a - 1)) / 2 + (b - a))];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) acc[t - T0][rg] -= (4 * rg == d) ? u : (T)0;
+          }
+        });
+      }
+    });
+    if (stamp_wg && threadIdx.x == NPROD) dbg[51] = clock64();
+    T* slab = slabs + (size_t)blockIdx.x * (size_t)WIDE_SLOTS * 256;
+    static_for<0, Cfg::NV>([&](auto vc) {
+      constexpr int V = decltype(vc)::value;
+      if (cw == V) {
+        constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
+#pragma unroll
+        for (int t = LO; t < HI; ++t) {
+          double2* dst = reinterpret_cast<double2*>(slab + (size_t)t * 256 + lane * 4);       // [tile][lane][reg]
+          dst[0] = make_double2(acc[t - LO][0], acc[t - LO][1]);
+          dst[1] = make_double2(acc[t - LO][2], acc[t - LO][3]);
+        }
+      }
+    });
+    if (stamp_wg && threadIdx.x == NPROD) dbg[52] = clock64();
+    if (ct < ROWS) {
+      // this thread's compact row rho = e C + c goes out in the exchange buffer's order o = c * 11 + e
+      const int er = (int)(((float)ct + 0.5f) * invC), cr = ct - er * C;
+      if (ct < n) {
+        const int o = cr * NCP + er;
+        const double gpart = s_Ured[cr * UPK + NCP * (NCP + 1) / 2 + er];
+        const double dpart = s_Ured[cr * UPK + (er * NCP - (er * (er - 1)) / 2)];
+        bpart[(size_t)blockIdx.x * WIDE_ROWS + o] = bacc - gpart;             // rhs = sum (b - g_c) over the workgroups
+        gdpart[((size_t)blockIdx.x * 2 + 0) * WIDE_ROWS + o] = gpart;
+        gdpart[((size_t)blockIdx.x * 2 + 1) * WIDE_ROWS + o] = dpart;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    double cs = 0, gm_ = 0;
+    for (int wv = 0; wv < NPROD / 64; ++wv) { cs += s_scr[0][wv]; gm_ = fmax(gm_, s_scr[1][wv]); }
+    cost_part[blockIdx.x] = 0.5 * cs;
+    gmax_part[blockIdx.x] = gm_;
     if (stamp_wg) dbg[53] = clock64();
   }
 }

@@ -164,3 +164,63 @@ def test_fused_f64_full_size_16x50k_properties():
     assert all(b <= a for a, b in zip(costs, costs[1:]))
     rms = np.sqrt(np.mean(np.sum(r1.reshape(-1, 2) ** 2, axis=1)))
     assert 0.35 < rms < 0.45                                      # 0.3 px noise per axis
+
+
+# ---------------------------------------------------------------- 17 and 18 cameras: k_schur_fused_wide_f64 (compact rows)
+@pytest.mark.parametrize("C,N,vis", [(17, 333, 1.0), (17, 4099, 1.0), (17, 500, 0.5), (18, 260, 1.0), (18, 700, 0.6), (17, 50, 1.0)])
+def test_wide_f64_builds_the_pair_kernel_system(monkeypatch, C, N, vis):
+    """The reference's own rig shape (17 cameras, example/config.json:24-42) in PySBA's own dtype: the one-launch kernel against
+    the path it replaces (SBA_NO_FUSED64=1: k_linearize_* + k_point_factor + the k_schur_sym group pairs)."""
+    rig = make_rig(C, N, seed=41 + C, visibility=vis, min_cams_per_point=2)
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(rig["camera_ind"].size)
+    uv, ci, pi = rig["points_2d"][perm], rig["camera_ind"][perm], rig["point_ind"][perm]
+    wts = rng.uniform(0.5, 1.5, ci.size)
+    Ea, sa, da = _system(rig, uv, ci, pi, wts, monkeypatch, fused=True)
+    Eb, sb, db = _system(rig, uv, ci, pi, wts, monkeypatch, fused=False)
+    _compare(Ea, sa, da, Eb, sb, db, 11 * C)
+
+
+@pytest.mark.parametrize("C,N,vis", [(17, 600, 1.0), (18, 500, 0.55)])
+def test_wide_f64_solve_follows_the_pair_kernel_solve_and_the_oracle(monkeypatch, C, N, vis):
+    rig = make_rig(C, N, seed=5 + C, visibility=vis, min_cams_per_point=4)
+    args = (rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    logs = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("SBA_NO_FUSED64", raising=False)
+        else:
+            monkeypatch.setenv("SBA_NO_FUSED64", "1")
+        with _native.Problem(rig["cams0"], rig["pts0"], *args, dtype="f64") as prob:
+            logs.append(prob.solve_lm(prob.make_opts(ftol=1e-10)))
+    (ca, pa, ra, la), (cb, pb, rb, lb) = logs
+    assert ra.status == rb.status and [r.accepted for r in la] == [r.accepted for r in lb]
+    assert abs(ra.cost - rb.cost) <= 1e-11 * rb.cost and np.max(np.abs(ca - cb)) <= 1e-6 * np.max(np.abs(cb))
+    ref, _, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], *args, ftol=1e-10)
+    assert ra.cost <= ref.cost * (1 + 1e-9) and ra.cost >= 0.99 * ref.cost
+    again, _, _ = orc.bundle_adjust(ca, pa, *args, ftol=1e-10, max_nfev=20)
+    assert again.cost >= ra.cost * (1 - 1e-6)
+
+
+def test_wide_f64_with_huber_loss_and_fixed_points(monkeypatch):
+    rig = make_rig(17, 300, seed=4, visibility=0.8)
+    uv = rig["points_2d"].copy()
+    rng = np.random.default_rng(1)
+    bad = rng.choice(uv.shape[0], 30, replace=False)
+    uv[bad] += rng.normal(0, 40.0, (30, 2))
+    fixed = np.zeros(300, dtype=np.uint8)
+    fixed[:6] = 1
+    out = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("SBA_NO_FUSED64", raising=False)
+        else:
+            monkeypatch.setenv("SBA_NO_FUSED64", "1")
+        with _native.Problem(rig["cams0"], rig["pts0"], uv, rig["camera_ind"], rig["point_ind"], dtype="f64") as prob:
+            prob.set_fixed_points(fixed)
+            prob.set_robust_loss("huber", 1.0)
+            out.append(prob.solve_lm(prob.make_opts(ftol=1e-9)))
+    (ca, pa, ra, la), (cb, pb, rb, lb) = out
+    assert np.array_equal(pa[:6], rig["pts0"][:6]) and np.array_equal(pb[:6], rig["pts0"][:6])
+    assert [r.accepted for r in la] == [r.accepted for r in lb]
+    assert abs(ra.cost - rb.cost) <= 1e-10 * rb.cost
