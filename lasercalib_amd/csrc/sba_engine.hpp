@@ -214,8 +214,10 @@ struct Engine : EngineBase {
       if constexpr (SCHUR_LIN_OK<T>) HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, false, true>)));
 #if SBA_NCP == 11
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurF64Cfg::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<12>::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<13>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<12, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<12, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<13, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<13, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<12, 3>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<13, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<13, 3>::LDS_BYTES));
 #endif
     } else {
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, true, false>)));
@@ -512,7 +514,8 @@ struct Engine : EngineBase {
       if (fused_wide) {
         int target = 256;
         if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
-        ksplit = std::max(1, std::min(target, (N + 7) / 8));
+        wide_pw = getenv("SBA_WIDE_PW2") ? 2 : 3;          // three points per producer wave (3 C <= 54 lanes)
+        ksplit = std::max(1, std::min(target, (N + 4 * wide_pw - 1) / (4 * wide_pw)));
       }
     }
 #endif
@@ -631,13 +634,17 @@ struct Engine : EngineBase {
         const bool tables = !dense;
         const uint16_t* tmask = tables ? grp_mask.p : nullptr;
         const int32_t* tstart = tables ? grp_start.p : nullptr;
-        auto go = [&](auto ntw_c) {
-          constexpr int NTW = decltype(ntw_c)::value;
-          hipLaunchKernelGGL((k_schur_fused_wide_f64<NTW>), dim3(ksplit), dim3(SCHUR_THREADS), SchurWide64Cfg<NTW>::LDS_BYTES, stream,
+        auto go = [&](auto ntw_c, auto pw_c) {
+          constexpr int NTW = decltype(ntw_c)::value, PW = decltype(pw_c)::value;
+          constexpr size_t lds64 = SchurWide64Cfg<NTW, PW>::LDS_BYTES;
+          hipLaunchKernelGGL((k_schur_fused_wide_f64<NTW, PW>), dim3(ksplit), dim3(SCHUR_THREADS), lds64, stream,
                              ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, tmask, tstart, N, ksplit, D2p.p, gp.p, pfac.p, slabs.p, bpart.p,
                              gdpart.p, cost_part.p, gm_out, (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr);
         };
-        if (wide_ntw(C) == 12) go(std::integral_constant<int, 12>{}); else go(std::integral_constant<int, 13>{});
+        using P2 = std::integral_constant<int, 2>;
+        using P3 = std::integral_constant<int, 3>;
+        if (wide_ntw(C) == 12) { if (wide_pw == 3) go(std::integral_constant<int, 12>{}, P3{}); else go(std::integral_constant<int, 12>{}, P2{}); }
+        else { if (wide_pw == 3) go(std::integral_constant<int, 13>{}, P3{}); else go(std::integral_constant<int, 13>{}, P2{}); }
         d_state.p = fd.st_out;
         pending_decide = false;
         gmax_cur = gm_out;
@@ -646,7 +653,7 @@ struct Engine : EngineBase {
           std::vector<long long> st(64);
           HIPCHK(hipMemcpyAsync(st.data(), schur_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
           sync();
-          fprintf(stderr, "[schur_fused_wide_f64 stamps, cycles since the first producer stamp; per chunk of 8 points: producer-done consumer-done]\n");
+          fprintf(stderr, "[schur_fused_wide_f64 stamps, cycles since the first producer stamp; per chunk of 8 or 12 points: producer-done consumer-done]\n");
           for (int i = 0; i < 14; ++i) fprintf(stderr, "  it %2d: P %7lld  C %7lld\n", i, st[2 * i] - st[0], st[2 * i + 1] - st[0]);
           fprintf(stderr, "  phases (cycles): prologue %lld | main loop %lld | fold U %lld | slab stores %lld | tail %lld | whole kernel %lld\n",
                   st[49] - st[48], st[50] - st[49], st[51] - st[50], st[52] - st[51], st[53] - st[52], st[53] - st[48]);

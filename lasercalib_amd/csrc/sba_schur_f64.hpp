@@ -410,8 +410,10 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
 // the fp64 engine fell back to two linearisation launches + k_point_factor + three pair launches of k_schur_sym (541 us per step at
 // 17 x 50k against 196 at 16 x 50k).  k_schur_fused_wide's row scheme (sba_schur_wide.hpp) -- COMPACT parameter-major rows
 // row = e C + c, n = 11 C rows in NTW = ceil(n / 16) tiles: 12 tiles for 17 cameras, 13 for 18 -- with k_schur_fused_f64's arithmetic:
-//   producers  a wave holds TWO points, one per 32-lane half (lane -> half lane >> 5, camera lane & 31 < C); 8 points per chunk =
-//              24 panel rows = 6 k-steps of the f64 MFMA; per-point sums = DPP row sum + one v_permlane16_swap per dword;
+//   producers  PW = 3 (the default): a wave holds THREE points, packed -- lane l serves point l / C, camera l % C, 51 or 54 of the 64
+//              lanes work --, 12 points per chunk = 36 panel rows = 9 k-steps of the f64 MFMA; per-point sums = segment differences
+//              of a wave-wide DPP prefix scan read at the segment ends.  PW = 2 (SBA_WIDE_PW2=1): two points, one per 32-lane half,
+//              8 points per chunk = 6 k-steps, per-point sums = DPP row sum + one v_permlane16_swap per dword;
 //              52 of the 77 U_c / g_c accumulators in registers, 25 in per-wave LDS sets (ds_add_f64), as above;
 //   panel      [24][16 NTW] doubles + z, double-buffered: a producer store is 32 consecutive doubles per row;
 //   consumers  4 waves, contiguous ranges of the NTW (NTW + 1) / 2 upper-triangular tiles (20 of 78, 23 of 91: 160 / 184
@@ -419,13 +421,13 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
 //   outputs    k_schur_fused_wide's: slab [WIDE_SLOTS][64 lanes][4] per workgroup (k_build_exchange, emajor_mode 3), bpart /
 //              gdpart rows in the exchange buffer's own order with a stride of WIDE_ROWS.
 // 19 cameras and more (14+ tiles: 27 tiles = 216 accumulator VGPRs per consumer wave) stay on the pair kernels.
-template <int NTW> struct SchurWide64Cfg {
+template <int NTW, int PW = 2> struct SchurWide64Cfg {
   using elem = double;
   static constexpr int THREADS = SCHUR_THREADS, NPROD = 256, NV = 4;
   static constexpr int ROWS = 16 * NTW;
   static constexpr int NTILE = NTW * (NTW + 1) / 2;
   static constexpr int TPW = (NTILE + NV - 1) / NV;
-  static constexpr int PTS = 8, K = 3 * PTS;
+  static constexpr int PTS = 4 * PW, K = 3 * PTS;                // points per chunk: 8 (two per producer wave) or 12 (three, packed)
   static constexpr int BUF = K * ROWS + K;                       // doubles: panel [K][ROWS] + z [K]
   static constexpr int MAXC = 18;
   static constexpr int KREG = SchurF64Cfg::KREG, NL = SchurF64Cfg::NL;
@@ -439,6 +441,8 @@ template <int NTW> struct SchurWide64Cfg {
   static_assert(CAM_OFF >= 5 * THREADS * sizeof(double), "the decision's scratch lives in the panel buffers");
   static_assert(LDS_BYTES + 1024 <= 160 * 1024, "LDS budget of a CU");
   static_assert(ROWS <= WIDE_ROWS && NTILE <= WIDE_SLOTS, "slab / row-partial strides of the wide path");
+  static_assert(PW == 2 || PW == 3, "two points per wave (32-lane halves) or three (packed: lane l -> point l / C, camera l % C)");
+  static_assert(K % 4 == 0, "whole k-steps per chunk");
 };
 
 // sum over the 32 lanes of a wave half (two DPP rows) of a double, result in all 32
@@ -450,7 +454,26 @@ __device__ __forceinline__ double half32_sum(double v) {
   return __hiloint2double(hi0, lo0) + __hiloint2double(hi1, lo1);
 }
 
-template <int NTW>
+// inclusive prefix sum of a double over the 64 lanes of the wave (wave_scan of sba_schur_wide.hpp on both dwords): Hillis-Steele
+// inside every DPP row (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then the row totals travel on
+// (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
+__device__ __forceinline__ double wave_scan(double v) {
+  auto dpp = [](double x, auto ctrl, auto rmask) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  using I = std::integral_constant<int, 0xf>;
+  v += dpp(v, std::integral_constant<int, 0x111>{}, I{});      // row_shr:1
+  v += dpp(v, std::integral_constant<int, 0x112>{}, I{});      // row_shr:2
+  v += dpp(v, std::integral_constant<int, 0x114>{}, I{});      // row_shr:4
+  v += dpp(v, std::integral_constant<int, 0x118>{}, I{});      // row_shr:8
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});      // row_bcast:15 -> rows 1, 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});      // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+template <int NTW, int PW>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
     const ParamSets<double> ps, const FusedDecide fd, int C,
     const double2* __restrict__ uv, const double* __restrict__ w,
@@ -461,7 +484,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
     long long* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem[];
   using T = double;
-  using Cfg = SchurWide64Cfg<NTW>;
+  using Cfg = SchurWide64Cfg<NTW, PW>;
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF, ROWS = Cfg::ROWS;
   constexpr int KREG = Cfg::KREG, NL = Cfg::NL, KH = Cfg::KH, KS = Cfg::KS, MAXC = Cfg::MAXC;
   const bool stamp_wg = dbg && blockIdx.x == 0;
@@ -518,14 +541,21 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
   const T* __restrict__ ptsT = ps.ptsT[cur_];
   for (int i = threadIdx.x; i < C * CAMPRE; i += THREADS) s_cam[i] = ps.campre[cur_][i];
   const T lam = st->lam;
-  // fold the eight lanes that served camera c (4 waves x 2 halves) for the register accumulators [k0, k0 + KH) handed over through
+  // fold the 4 PW lanes that served camera c (4 waves x PW points) for the register accumulators [k0, k0 + KH) handed over through
   // s_U, and -- in the second pass -- the four waves' LDS sets
   auto fold_u = [&](int k0) {
     for (int o = threadIdx.x; o < C * KH; o += THREADS) {
       const int c = o / KH, k = o - c * KH;
       T sum = 0;
+      if constexpr (PW == 2) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) sum += s_U[(q * 32 + c) * KS + k];
+        for (int q = 0; q < 8; ++q) sum += s_U[(q * 32 + c) * KS + k];
+      } else {
+#pragma unroll
+        for (int wv = 0; wv < NPROD / 64; ++wv)
+#pragma unroll
+          for (int hs = 0; hs < 3; ++hs) sum += s_U[(wv * 64 + hs * C + c) * KS + k];
+      }
       s_Ured[c * UPK + k0 + k] = sum;
     }
     if (k0 != 0)
@@ -541,10 +571,23 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
   __syncthreads();
 
   if (producer) {
-    const int h = lane >> 5, c = lane & 31, q = 2 * wid + h;
-    const bool cam_ok = c < C;
+    // point of the chunk, camera slot.  PW = 2: one point per 32-lane half; PW = 3: lane l of the wave -> point l / C, camera l % C
+    const int hseg = PW == 2 ? (lane >> 5) : ((lane >= C) + (lane >= 2 * C) + (lane >= 3 * C));
+    const int q = PW * wid + min(hseg, PW - 1);
+    const int c = PW == 2 ? (lane & 31) : lane - hseg * C;
+    const bool cam_ok = PW == 2 ? c < C : hseg < 3;
+    auto point_sum = [&](T v) -> T {
+      if constexpr (PW == 2) return half32_sum(v);
+      else {
+        // segment sums = differences of the wave-wide prefix scan read at the segment ends
+        const T sc = wave_scan(v);
+        const T e0 = lane_f64(sc, C - 1), e1 = lane_f64(sc, 2 * C - 1), e2 = lane_f64(sc, 3 * C - 1);
+        return hseg == 0 ? e0 : hseg == 1 ? e1 - e0 : e2 - e1;
+      }
+    };
     const T* cp_safe = s_cam + (cam_ok ? c : 0) * CAMPRE;
-    const int grp = c >> 4, cc = c & 15;
+    const int cs_ = cam_ok ? c : 0;
+    const int grp = cs_ >> 4, cc = cs_ & 15;
     const uint16_t* __restrict__ gm = gmask ? gmask + (size_t)grp * N : nullptr;
     const int32_t* __restrict__ gs = gstart ? gstart + (size_t)grp * N : nullptr;
     T Uacc[KREG];
@@ -572,15 +615,15 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
         obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
         sq += robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
         T v6[6], g3[3];
-        v6[0] = half32_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
-        v6[1] = half32_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
-        v6[2] = half32_sum(Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2]);
-        v6[3] = half32_sum(Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1]);
-        v6[4] = half32_sum(Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2]);
-        v6[5] = half32_sum(Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2]);
-        g3[0] = half32_sum(Jp[0][0] * r[0] + Jp[1][0] * r[1]);
-        g3[1] = half32_sum(Jp[0][1] * r[0] + Jp[1][1] * r[1]);
-        g3[2] = half32_sum(Jp[0][2] * r[0] + Jp[1][2] * r[1]);
+        v6[0] = point_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
+        v6[1] = point_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
+        v6[2] = point_sum(Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2]);
+        v6[3] = point_sum(Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1]);
+        v6[4] = point_sum(Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2]);
+        v6[5] = point_sum(Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2]);
+        g3[0] = point_sum(Jp[0][0] * r[0] + Jp[1][0] * r[1]);
+        g3[1] = point_sum(Jp[0][1] * r[0] + Jp[1][1] * r[1]);
+        g3[2] = point_sum(Jp[0][2] * r[0] + Jp[1][2] * r[1]);
         const bool fixedp = have_pt && pt_fixed(ps, (size_t)p);
         if (!fixedp) gmx = fmax(gmx, fmax(fabs(g3[0]), fmax(fabs(g3[1]), fabs(g3[2]))));
         const double E0 = fmax(D2p[3 * pp], v6[0]), E1 = fmax(D2p[3 * pp + 1], v6[3]), E2 = fmax(D2p[3 * pp + 2], v6[5]);
@@ -598,7 +641,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
           f[8] = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
           f[9] = (T)1;
         }
-        if (have_pt && c == 0) {
+        if (have_pt && cam_ok && c == 0) {
           D2p[3 * (size_t)p] = E0; D2p[3 * (size_t)p + 1] = E1; D2p[3 * (size_t)p + 2] = E2;
           gp[3 * (size_t)p] = g3[0]; gp[3 * (size_t)p + 1] = g3[1]; gp[3 * (size_t)p + 2] = g3[2];
           double2* o2 = reinterpret_cast<double2*>(pf + (size_t)p * PF);

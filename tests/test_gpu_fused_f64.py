@@ -168,9 +168,13 @@ def test_fused_f64_full_size_16x50k_properties():
 
 # ---------------------------------------------------------------- 17 and 18 cameras: k_schur_fused_wide_f64 (compact rows)
 @pytest.mark.parametrize("C,N,vis", [(17, 333, 1.0), (17, 4099, 1.0), (17, 500, 0.5), (18, 260, 1.0), (18, 700, 0.6), (17, 50, 1.0)])
-def test_wide_f64_builds_the_pair_kernel_system(monkeypatch, C, N, vis):
+@pytest.mark.parametrize("pw2", [False, True])
+def test_wide_f64_builds_the_pair_kernel_system(monkeypatch, C, N, vis, pw2):
     """The reference's own rig shape (17 cameras, example/config.json:24-42) in PySBA's own dtype: the one-launch kernel against
-    the path it replaces (SBA_NO_FUSED64=1: k_linearize_* + k_point_factor + the k_schur_sym group pairs)."""
+    the path it replaces (SBA_NO_FUSED64=1: k_linearize_* + k_point_factor + the k_schur_sym group pairs); three points per
+    producer wave (the default) and two (SBA_WIDE_PW2=1)."""
+    if pw2:
+        monkeypatch.setenv("SBA_WIDE_PW2", "1")
     rig = make_rig(C, N, seed=41 + C, visibility=vis, min_cams_per_point=2)
     rng = np.random.default_rng(7)
     perm = rng.permutation(rig["camera_ind"].size)
