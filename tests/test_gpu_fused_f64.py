@@ -228,3 +228,15 @@ def test_wide_f64_with_huber_loss_and_fixed_points(monkeypatch):
     assert np.array_equal(pa[:6], rig["pts0"][:6]) and np.array_equal(pb[:6], rig["pts0"][:6])
     assert [r.accepted for r in la] == [r.accepted for r in lb]
     assert abs(ra.cost - rb.cost) <= 1e-10 * rb.cost
+
+
+@pytest.mark.parametrize("C,N", [(16, 3), (16, 17), (5, 1), (17, 2), (18, 13)])
+def test_fused_f64_kernels_on_tiny_rigs(monkeypatch, C, N):
+    """Fewer points than one chunk, slices of a single point, most workgroups without work."""
+    rig = make_rig(C, N, seed=100 + C + N)
+    rng = np.random.default_rng(2)
+    wts = rng.uniform(0.5, 1.5, rig["camera_ind"].size)
+    args = (rig, rig["points_2d"], rig["camera_ind"], rig["point_ind"], wts, monkeypatch)
+    Ea, sa, da = _system(*args, fused=True, lam=1e-2)
+    Eb, sb, db = _system(*args, fused=False, lam=1e-2)
+    _compare(Ea, sa, da, Eb, sb, db, 11 * C, tol=1e-10)
