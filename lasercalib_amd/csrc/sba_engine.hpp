@@ -42,6 +42,7 @@ struct Engine : EngineBase {
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
   bool fused_bf3 = true;             // ... with the Schur products on the bf16 matrix pipe (k_schur_fused_bf3)
   bool fused_f64 = false;            // fp64, one group, 11 parameters: k_schur_fused_f64 (sba_schur_f64.hpp)
+  int wide_ts = 1;                   // fp64 wide kernel: workgroups per slice (tile split, grid.y)
   bool fused_wide = false;           // 17 .. 23 cameras: k_schur_fused_wide (compact rows, one launch; implies fused_ok)
   int wide_pw = 2;                   // ... points per producer wave: 3 (packed lanes, 12-point rounds) for 17 and 18 cameras, else 2
   DevBuf<double> gdpart;
@@ -214,10 +215,13 @@ struct Engine : EngineBase {
       if constexpr (SCHUR_LIN_OK<T>) HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur_sym<T, true, false, true>)));
 #if SBA_NCP == 11
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurF64Cfg::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<12, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<12, 2>::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<13, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<13, 2>::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<12, 3>::LDS_BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<13, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<13, 3>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<12, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<12, 2, 1>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<13, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<13, 2, 1>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<12, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<12, 3, 1>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<13, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<13, 3, 1>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<14, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<14, 2, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<15, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<15, 2, 2>::LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_fused_wide_f64<16, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SchurWide64Cfg<16, 2, 2>::LDS_BYTES));
 #endif
     } else {
       HIPCHK(big_lds(reinterpret_cast<const void*>(&k_schur<T, true, false>)));
@@ -509,13 +513,16 @@ struct Engine : EngineBase {
     // SBA_NO_WIDE=1 keep the pair kernels
     if constexpr (sizeof(T) == 8) {
       const bool dense_enough = (double)M >= 0.35 * (double)N * C;
-      fused_wide = C > GROUP_CAMS && C <= SchurWide64Cfg<13>::MAXC && (dense || (grp_indexed && dense_enough)) && N > 0 &&
+      fused_wide = C > GROUP_CAMS && C * NCP <= 16 * WIDE_MAX_NTW && (dense || (grp_indexed && dense_enough)) && N > 0 &&
                    !getenv("SBA_NO_FUSED") && !getenv("SBA_NO_FUSED64") && !getenv("SBA_NO_WIDE");
       if (fused_wide) {
         int target = 256;
         if (const char* e = getenv("SBA_SCHUR_WGS")) target = std::max(1, atoi(e));
-        wide_pw = getenv("SBA_WIDE_PW2") ? 2 : 3;          // three points per producer wave (3 C <= 54 lanes)
-        ksplit = std::max(1, std::min(target, (N + 4 * wide_pw - 1) / (4 * wide_pw)));
+        // 17, 18 cameras (12, 13 row tiles): one workgroup per slice, three points per producer wave; 19 .. 23 (14 .. 16 tiles): two
+        // workgroups per slice share its tiles (a consumer wave holds at most ~23 f64 accumulator tiles), two points per wave
+        wide_ts = wide_ntw(C) > 13 ? 2 : 1;
+        wide_pw = (wide_ts == 1 && !getenv("SBA_WIDE_PW2")) ? 3 : 2;
+        ksplit = std::max(1, std::min(target / wide_ts, (N + 4 * wide_pw - 1) / (4 * wide_pw)));
       }
     }
 #endif
@@ -634,17 +641,24 @@ struct Engine : EngineBase {
         const bool tables = !dense;
         const uint16_t* tmask = tables ? grp_mask.p : nullptr;
         const int32_t* tstart = tables ? grp_start.p : nullptr;
-        auto go = [&](auto ntw_c, auto pw_c) {
-          constexpr int NTW = decltype(ntw_c)::value, PW = decltype(pw_c)::value;
-          constexpr size_t lds64 = SchurWide64Cfg<NTW, PW>::LDS_BYTES;
-          hipLaunchKernelGGL((k_schur_fused_wide_f64<NTW, PW>), dim3(ksplit), dim3(SCHUR_THREADS), lds64, stream,
+        auto go = [&](auto ntw_c, auto pw_c, auto ts_c) {
+          constexpr int NTW = decltype(ntw_c)::value, PW = decltype(pw_c)::value, TS = decltype(ts_c)::value;
+          constexpr size_t lds64 = SchurWide64Cfg<NTW, PW, TS>::LDS_BYTES;
+          hipLaunchKernelGGL((k_schur_fused_wide_f64<NTW, PW, TS>), dim3(ksplit, TS), dim3(SCHUR_THREADS), lds64, stream,
                              ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, tmask, tstart, N, ksplit, D2p.p, gp.p, pfac.p, slabs.p, bpart.p,
                              gdpart.p, cost_part.p, gm_out, (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr);
         };
         using P2 = std::integral_constant<int, 2>;
         using P3 = std::integral_constant<int, 3>;
-        if (wide_ntw(C) == 12) { if (wide_pw == 3) go(std::integral_constant<int, 12>{}, P3{}); else go(std::integral_constant<int, 12>{}, P2{}); }
-        else { if (wide_pw == 3) go(std::integral_constant<int, 13>{}, P3{}); else go(std::integral_constant<int, 13>{}, P2{}); }
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        switch (wide_ntw(C)) {
+          case 12: if (wide_pw == 3) go(std::integral_constant<int, 12>{}, P3{}, S1{}); else go(std::integral_constant<int, 12>{}, P2{}, S1{}); break;
+          case 13: if (wide_pw == 3) go(std::integral_constant<int, 13>{}, P3{}, S1{}); else go(std::integral_constant<int, 13>{}, P2{}, S1{}); break;
+          case 14: go(std::integral_constant<int, 14>{}, P2{}, S2{}); break;
+          case 15: go(std::integral_constant<int, 15>{}, P2{}, S2{}); break;
+          default: go(std::integral_constant<int, 16>{}, P2{}, S2{}); break;
+        }
         d_state.p = fd.st_out;
         pending_decide = false;
         gmax_cur = gm_out;

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
   }
 }
 
-// ------------------------------------------------------------------ 17 and 18 cameras in fp64: the same kernel on compact rows
+// ------------------------------------------------------------------ 17 .. 23 cameras in fp64: the same kernel on compact rows
 // The reference's own example rig has 17 cameras (example/config.json:24-42) and PySBA computes in float64: above one camera group
 // the fp64 engine fell back to two linearisation launches + k_point_factor + three pair launches of k_schur_sym (541 us per step at
 // 17 x 50k against 196 at 16 x 50k).  k_schur_fused_wide's row scheme (sba_schur_wide.hpp) -- COMPACT parameter-major rows
@@ -420,16 +420,17 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_f64(
 //              accumulator VGPRs), the fragments of one k-step in registers;
 //   outputs    k_schur_fused_wide's: slab [WIDE_SLOTS][64 lanes][4] per workgroup (k_build_exchange, emajor_mode 3), bpart /
 //              gdpart rows in the exchange buffer's own order with a stride of WIDE_ROWS.
-// 19 cameras and more (14+ tiles: 27 tiles = 216 accumulator VGPRs per consumer wave) stay on the pair kernels.
-template <int NTW, int PW = 2> struct SchurWide64Cfg {
+// 19 .. 23 cameras (14 .. 16 tiles: 27 .. 34 tiles = 216+ accumulator VGPRs per consumer wave) run with TS = 2: two workgroups per
+// slice (grid.y), each building the whole panel and consuming half of the tiles; only the first stores the per-point and per-row results.
+template <int NTW, int PW = 2, int TS = 1> struct SchurWide64Cfg {
   using elem = double;
-  static constexpr int THREADS = SCHUR_THREADS, NPROD = 256, NV = 4;
+  static constexpr int THREADS = SCHUR_THREADS, NPROD = 256, NV = 4 * TS;       // TS workgroups per slice share its tiles (grid.y)
   static constexpr int ROWS = 16 * NTW;
   static constexpr int NTILE = NTW * (NTW + 1) / 2;
   static constexpr int TPW = (NTILE + NV - 1) / NV;
   static constexpr int PTS = 4 * PW, K = 3 * PTS;                // points per chunk: 8 (two per producer wave) or 12 (three, packed)
   static constexpr int BUF = K * ROWS + K;                       // doubles: panel [K][ROWS] + z [K]
-  static constexpr int MAXC = 18;
+  static constexpr int MAXC = TS == 1 ? 18 : 23;
   static constexpr int KREG = SchurF64Cfg::KREG, NL = SchurF64Cfg::NL;
   static constexpr int KH = KREG / 2, KS = KH + 1;               // register accumulators handed over per pass, lane stride (odd)
   static constexpr size_t CAM_OFF = (size_t)2 * BUF * sizeof(double);
@@ -473,7 +474,7 @@ __device__ __forceinline__ double wave_scan(double v) {
   return v;
 }
 
-template <int NTW, int PW>
+template <int NTW, int PW, int TS>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
     const ParamSets<double> ps, const FusedDecide fd, int C,
     const double2* __restrict__ uv, const double* __restrict__ w,
@@ -484,10 +485,11 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
     long long* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem[];
   using T = double;
-  using Cfg = SchurWide64Cfg<NTW, PW>;
+  using Cfg = SchurWide64Cfg<NTW, PW, TS>;
+  const int z = TS == 1 ? 0 : (int)blockIdx.y;      // which share of the slice's tiles this workgroup consumes (both build the whole panel)
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, K = Cfg::K, BUF = Cfg::BUF, ROWS = Cfg::ROWS;
   constexpr int KREG = Cfg::KREG, NL = Cfg::NL, KH = Cfg::KH, KS = Cfg::KS, MAXC = Cfg::MAXC;
-  const bool stamp_wg = dbg && blockIdx.x == 0;
+  const bool stamp_wg = dbg && blockIdx.x == 0 && blockIdx.y == 0;
   if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();
   __shared__ LMState s_st;
   __shared__ LMLogRow s_row;
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
         uint4* z4 = reinterpret_cast<uint4*>(smem);
         for (int i = threadIdx.x; i < 5 * THREADS * (int)sizeof(double) / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
       }
-      if (blockIdx.x == 0) {
+      if (blockIdx.x == 0 && z == 0) {
         if ((int)threadIdx.x < NWORD) reinterpret_cast<int*>(fd.st_out)[threadIdx.x] = reinterpret_cast<const int*>(&s_st)[threadIdx.x];
         if (threadIdx.x == 0 && s_have_row && fd.log) fd.log[s_st.iter - 1] = s_row;
       }
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
           f[8] = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
           f[9] = (T)1;
         }
-        if (have_pt && cam_ok && c == 0) {
+        if (have_pt && cam_ok && c == 0 && z == 0) {      // (the other workgroup of the slice computes the same values)
           D2p[3 * (size_t)p] = E0; D2p[3 * (size_t)p + 1] = E1; D2p[3 * (size_t)p + 2] = E2;
           gp[3 * (size_t)p] = g3[0]; gp[3 * (size_t)p + 1] = g3[1]; gp[3 * (size_t)p + 2] = g3[2];
           double2* o2 = reinterpret_cast<double2*>(pf + (size_t)p * PF);
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
     fold_u(KH);
     __syncthreads();
   } else {
-    const int cw = wid - NPROD / 64;
+    const int cw = wid - NPROD / 64, vw = 4 * z + cw;            // virtual consumer wave of the slice
     typename Mfma<T>::acc_t acc[TPW];
 #pragma unroll
     for (int s = 0; s < TPW; ++s) acc[s] = typename Mfma<T>::acc_t{0, 0, 0, 0};
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
         const T* pl = panel + lane_off;
         static_for<0, Cfg::NV>([&](auto vc) {
           constexpr int V = decltype(vc)::value;
-          if (cw == V) {
+          if (vw == V) {
             constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
             constexpr int RMIN = wide_tile_R<NTW>(LO);
 #pragma unroll
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
     const float invC = 1.0f / (float)C;
     static_for<0, Cfg::NV>([&](auto vc) {
       constexpr int V = decltype(vc)::value;
-      if (cw == V) {
+      if (vw == V) {
         constexpr int T0 = schur_lo(Cfg::NTILE, Cfg::NV, V), T1 = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
         static_for<T0, T1>([&](auto tc) {
           constexpr int t = decltype(tc)::value;
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
     T* slab = slabs + (size_t)blockIdx.x * (size_t)WIDE_SLOTS * 256;
     static_for<0, Cfg::NV>([&](auto vc) {
       constexpr int V = decltype(vc)::value;
-      if (cw == V) {
+      if (vw == V) {
         constexpr int LO = schur_lo(Cfg::NTILE, Cfg::NV, V), HI = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
 #pragma unroll
         for (int t = LO; t < HI; ++t) {
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
     if (ct < ROWS) {
       // this thread's compact row rho = e C + c goes out in the exchange buffer's order o = c * 11 + e
       const int er = (int)(((float)ct + 0.5f) * invC), cr = ct - er * C;
-      if (ct < n) {
+      if (ct < n && z == 0) {
         const int o = cr * NCP + er;
         const double gpart = s_Ured[cr * UPK + NCP * (NCP + 1) / 2 + er];
         const double dpart = s_Ured[cr * UPK + (er * NCP - (er * (er - 1)) / 2)];
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide_f64(
       }
     }
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && z == 0) {
     double cs = 0, gm_ = 0;
     for (int wv = 0; wv < NPROD / 64; ++wv) { cs += s_scr[0][wv]; gm_ = fmax(gm_, s_scr[1][wv]); }
     cost_part[blockIdx.x] = 0.5 * cs;

@@ -166,8 +166,10 @@ def test_fused_f64_full_size_16x50k_properties():
     assert 0.35 < rms < 0.45                                      # 0.3 px noise per axis
 
 
-# ---------------------------------------------------------------- 17 and 18 cameras: k_schur_fused_wide_f64 (compact rows)
-@pytest.mark.parametrize("C,N,vis", [(17, 333, 1.0), (17, 4099, 1.0), (17, 500, 0.5), (18, 260, 1.0), (18, 700, 0.6), (17, 50, 1.0)])
+# ---------------------------------------------------------------- 17 .. 23 cameras: k_schur_fused_wide_f64 (compact rows; 19+: two
+# workgroups per slice share the tiles)
+@pytest.mark.parametrize("C,N,vis", [(17, 333, 1.0), (17, 4099, 1.0), (17, 500, 0.5), (18, 260, 1.0), (18, 700, 0.6), (17, 50, 1.0),
+                                     (19, 203, 0.8), (20, 150, 1.0), (20, 2100, 1.0), (21, 97, 0.7), (22, 120, 1.0), (23, 260, 0.6)])
 @pytest.mark.parametrize("pw2", [False, True])
 def test_wide_f64_builds_the_pair_kernel_system(monkeypatch, C, N, vis, pw2):
     """The reference's own rig shape (17 cameras, example/config.json:24-42) in PySBA's own dtype: the one-launch kernel against
@@ -185,7 +187,7 @@ def test_wide_f64_builds_the_pair_kernel_system(monkeypatch, C, N, vis, pw2):
     _compare(Ea, sa, da, Eb, sb, db, 11 * C)
 
 
-@pytest.mark.parametrize("C,N,vis", [(17, 600, 1.0), (18, 500, 0.55)])
+@pytest.mark.parametrize("C,N,vis", [(17, 600, 1.0), (18, 500, 0.55), (20, 400, 0.7), (23, 300, 1.0)])
 def test_wide_f64_solve_follows_the_pair_kernel_solve_and_the_oracle(monkeypatch, C, N, vis):
     rig = make_rig(C, N, seed=5 + C, visibility=vis, min_cams_per_point=4)
     args = (rig["points_2d"], rig["camera_ind"], rig["point_ind"])

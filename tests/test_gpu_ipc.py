@@ -114,3 +114,19 @@ def test_in_library_sharded_loop_17_cameras_f32_wide_kernel():
     assert abs(rep.cost - r0[2]) <= 1e-4 * rep.cost
     ref, _, _ = orc.bundle_adjust(*a, ftol=1e-4)
     assert abs(r0[2] - ref.cost) <= 1e-4 * ref.cost
+
+
+def test_in_library_sharded_loop_17_cameras_f64_wide_kernel():
+    """The same rig in the class's default dtype: every rank's shard runs k_schur_fused_wide_f64 (csrc/sba_schur_f64.hpp), the
+    exchanged system goes through k_cholesky_ll<double>; the two ranks agree bit for bit, and with the single-rank fp64 solve to
+    the rounding of the different summation order."""
+    sys.path.insert(0, ROOT)
+    from lasercalib_amd import _native
+    res = _run("rig17", "f64", world=2)
+    r0, r1 = res
+    assert r0[1] == r1[1] and r0[1] in (2, 3, 4) and r0[3] == r1[3] and r0[2] == r1[2]
+    assert np.array_equal(r0[4], r1[4]) and np.array_equal(r0[5], r1[5])
+    a = _rig17()
+    with _native.Problem(*a, dtype="f64") as prob:
+        _, _, rep, _ = prob.solve_lm(prob.make_opts(ftol=1e-4))
+    assert abs(rep.cost - r0[2]) <= 1e-9 * rep.cost
