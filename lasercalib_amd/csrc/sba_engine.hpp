@@ -539,7 +539,12 @@ struct Engine : EngineBase {
     E_own.alloc((size_t)n * n + 3 * n + 1); scal_own.alloc(NSCAL); delta_c.alloc(n);
     const int nres_blocks = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
     dense_one_group = dense && C <= GROUP_CAMS && N > 0 && !getenv("SBA_NO_DENSE");
-    nbs_dense = std::max(1, std::min((N + 15) / 16, getenv("SBA_BS_WGS") ? atoi(getenv("SBA_BS_WGS")) : (sizeof(T) == 4 ? 768 : 512)));
+    // 17 .. 23 cameras, dense or group-indexed and dense enough (the rigs of the wide fused kernels): the same back substitution
+    // with a point per 32-lane wave half
+    backsub_wide = C > GROUP_CAMS && C <= 23 && N > 0 && (dense || (grp_indexed && (double)M >= 0.35 * (double)N * C)) &&
+                   !getenv("SBA_NO_DENSE") && !getenv("SBA_NO_WIDE");
+    const int bs_ppc = backsub_wide ? 8 : 16;
+    nbs_dense = std::max(1, std::min((N + bs_ppc - 1) / bs_ppc, getenv("SBA_BS_WGS") ? atoi(getenv("SBA_BS_WGS")) : (sizeof(T) == 4 ? 768 : 512)));
     // the fused linearise+Schur kernel also serves sparse one-group rigs through the visibility mask; its producer cost
     // does not shrink with the number of observations, so below ~35 % visibility the three-pass path is used
     const bool masked_fused = masked_ok && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
@@ -888,10 +893,17 @@ struct Engine : EngineBase {
   }
   // dense visibility with one camera group: the row-reduction kernel (any dtype); its partial rows are per workgroup
   bool backsub_masked = false;       // sparse one-group rig dense enough for the lane = (point, camera) back substitution (visibility mask)
-  bool backsub_dense() const { return dense_one_group || backsub_masked; }
+  bool backsub_wide = false;         // 17 .. 23 cameras: k_backsub_dense<T, 32>
+  bool backsub_dense() const { return dense_one_group || backsub_masked || backsub_wide; }
   int n_trial_parts() const { return backsub_dense() ? nbs_dense : nblk; }
   void launch_backsub_trial() {
     if (nblk == 0) return;
+    if (backsub_wide) {
+      hipLaunchKernelGGL((k_backsub_dense<T, 32>), dim3(nbs_dense), dim3(PM_BLOCK), 0, stream, ps_lm(), C, uv_pm.p,
+                         has_w ? w_pm.p : nullptr, N, pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nbs_dense,
+                         dense ? (const uint16_t*)nullptr : grp_mask.p, dense ? (const int32_t*)nullptr : grp_start.p);
+      return;
+    }
     if (backsub_dense()) {
       hipLaunchKernelGGL(k_backsub_dense<T>, dim3(nbs_dense), dim3(PM_BLOCK), 0, stream, ps_lm(), C, uv_pm.p,
                          has_w ? w_pm.p : nullptr, N, pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nbs_dense,

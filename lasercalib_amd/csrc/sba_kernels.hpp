@@ -727,6 +727,21 @@ __device__ __forceinline__ double row16_sum(double v) {
   v += dpp_mov<0x140>(v);
   return v;
 }
+// sum over the 32 lanes of a wave half (two DPP rows), result in all 32: DPP row sum + one row swap (v_permlane16_swap; inline
+// assembly with the wait states the instruction needs, see xrow_sum)
+__device__ __forceinline__ float half32_sum(float v) {
+  v = row16_sum(v);
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ double half32_sum(double v) {
+  v = row16_sum(v);
+  unsigned lo0 = __double2loint(v), hi0 = __double2hiint(v), lo1 = lo0, hi1 = hi0;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
+               : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
+  return __hiloint2double(hi0, lo0) + __hiloint2double(hi1, lo1);
+}
 // L^-1 of the 3x3 SPD matrix (v00,v01,v02,v11,v12,v22) with hardware rsq (1 ulp): no sqrt / divide sequences
 __device__ __forceinline__ bool chol3_inv_fast(const float v[6], float li[6]) {
   // straight-line: a failing pivot is replaced by 1 so that everything stays finite, and the verdict is one flag at the

@@ -571,15 +571,20 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_trial_scalars(const double* 
 // Same arithmetic as k_backsub_trial, laid out like k_schur_fused: lane (q, c) = (point of a 16-point chunk, camera),
 // so W_p^T delta_c is a DPP row sum instead of an LDS staging pass with two barriers, the workgroup is persistent
 // (camera tables staged once, chunks strided over the grid) and each partial row holds a whole workgroup's share.
-template <typename T>
+// LW = lanes per point: 16 (one DPP row: up to 16 cameras) or 32 (a wave half: 17 .. 23 cameras, the rigs of k_schur_fused_wide --
+// sums over the half, 8 points per chunk; 17 of 32 lanes work at 17 cameras, so it only draws level with k_backsub_trial there
+// (17 x 50k: 166.8 us per iteration either way) and gains from 20 cameras on (20 x 50k 218 -> 213.8 us).
+template <typename T, int LW = 16>
 __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
     const ParamSets<T> ps, int C, const typename Vec2<T>::type* __restrict__ uv /* observation (p, c) at p*C + c */,
     const T* __restrict__ w, int N, const T* __restrict__ pf, const double* __restrict__ gp, const double* __restrict__ D2p,
     const double* __restrict__ delta_c, const LMState* __restrict__ st, double* __restrict__ trial_part, int nparts,
-    const uint16_t* __restrict__ vis = nullptr /* sparse one-group rigs (round 3): per-point visibility mask; observation (p, c) then sits at
-                                                  pt_start[p] + popcount(mask below bit c), a lane without one idles through the row sums */,
+    const uint16_t* __restrict__ vis = nullptr /* sparse rigs: per (16-camera group, point) visibility mask [groups][N]; observation (p, c) then
+                                                  sits at pt_start[group][p] + popcount(mask below bit c & 15), a lane without one idles through
+                                                  the row sums (one group: the point's mask and first observation) */,
     const int32_t* __restrict__ pt_start = nullptr) {
-  __shared__ T s_cam01[2][GROUP_CAMS * CAMPRE], s_dc[GROUP_CAMS * NCP];
+  constexpr int MAXC = LW == 16 ? GROUP_CAMS : 24, PPC = PM_BLOCK / LW;       // cameras the tables hold, points per chunk
+  __shared__ T s_cam01[2][MAXC * CAMPRE], s_dc[MAXC * NCP];
   __shared__ double s_scr[PM_BLOCK / 64];
   // both camera tables are needed whichever is current: they and the camera step are requested before the state record's round trip
   stage_campre(ps.campre[0], s_cam01[0], C);
@@ -596,23 +601,25 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
   const bool free_cams = st->free_cams != 0;
   const double lam = st->lam;
   __syncthreads();
-  const int q = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const int q = threadIdx.x / LW, c = threadIdx.x % LW;
   const bool cam_ok = c < C;
+  const int grp = (cam_ok ? c : 0) >> 4, cc = c & 15;
+  auto lane_sum = [](T v) -> T { if constexpr (LW == 16) return row16_sum(v); else return half32_sum(v); };
   T dc[NCP];
 #pragma unroll
   for (int e = 0; e < NCP; ++e) dc[e] = cam_ok ? s_dc[c * NCP + e] : (T)0;
   const T* cp = s_cam + (cam_ok ? c : 0) * CAMPRE;
   const T* cpn = s_camn + (cam_ok ? c : 0) * CAMPRE;
   double sq = 0, pred = 0, dx2 = 0, x2 = 0;
-  const int nch = (N + 15) / 16;
+  const int nch = (N + PPC - 1) / PPC;
   for (int ch = blockIdx.x; ch < nch; ch += gridDim.x) {
-    const int p = ch * 16 + q;
+    const int p = ch * PPC + q;
     const bool pt_ok = p < N;
     const size_t pp = (size_t)(pt_ok ? p : 0);
     unsigned mask = 0xffffu;
     size_t o = pp * C + c;
-    if (vis) { mask = vis[pp]; o = (size_t)pt_start[pp] + __builtin_popcount(mask & ((1u << c) - 1u)); }
-    const bool valid = pt_ok && cam_ok && ((mask >> c) & 1u);
+    if (vis) { mask = vis[(size_t)grp * N + pp]; o = (size_t)pt_start[(size_t)grp * N + pp] + __builtin_popcount(mask & ((1u << cc) - 1u)); }
+    const bool valid = pt_ok && cam_ok && ((mask >> cc) & 1u);
     typename Vec2<T>::type m; m.x = 0; m.y = 0;
     T ww = (T)1;
     if (valid) { m = uv[o]; if (w) ww = w[o]; }
@@ -635,7 +642,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
       t1 = Jp[0][1] * sj[0] + Jp[1][1] * sj[1];
       t2 = Jp[0][2] * sj[0] + Jp[1][2] * sj[1];
     }
-    const double T0 = (double)row16_sum(t0), T1 = (double)row16_sum(t1), T2 = (double)row16_sum(t2);
+    const double T0 = (double)lane_sum(t0), T1 = (double)lane_sum(t1), T2 = (double)lane_sum(t2);
     double e0 = 0, e1 = 0, e2 = 0;
     if (f[9] != (T)0) {     // delta = -(V + lam D)^-1 (g + t) = -L^-T ( z + L^-1 t )
       const double l0 = f[0], l1 = f[1], l2 = f[2], l3 = f[3], l4 = f[4], l5 = f[5];

@@ -446,14 +446,6 @@ template <int NTW, int PW = 2, int TS = 1> struct SchurWide64Cfg {
   static_assert(K % 4 == 0, "whole k-steps per chunk");
 };
 
-// sum over the 32 lanes of a wave half (two DPP rows) of a double, result in all 32
-__device__ __forceinline__ double half32_sum(double v) {
-  v = row16_sum(v);
-  unsigned lo0 = __double2loint(v), hi0 = __double2hiint(v), lo1 = lo0, hi1 = hi0;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
-               : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
-  return __hiloint2double(hi0, lo0) + __hiloint2double(hi1, lo1);
-}
 
 // inclusive prefix sum of a double over the 64 lanes of the wave (wave_scan of sba_schur_wide.hpp on both dwords): Hillis-Steele
 // inside every DPP row (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then the row totals travel on

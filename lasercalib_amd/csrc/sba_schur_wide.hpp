@@ -57,13 +57,6 @@ template <int NTW> __host__ __device__ constexpr int wide_tile_T(int t) {
   while (rem >= NTW - R) { rem -= NTW - R; ++R; }
   return R + rem;
 }
-// sum over the 32 lanes of a wave half (two DPP rows), result in all 32
-__device__ __forceinline__ float half32_sum(float v) {
-  v = row16_sum(v);
-  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
-}
 
 // inclusive prefix sum over the 64 lanes of the wave: Hillis-Steele inside every DPP row (row_shr 1, 2, 4, 8; lanes shifted in from
 // outside the row read 0), then the row totals travel on: row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3
