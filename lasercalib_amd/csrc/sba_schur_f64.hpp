@@ -1,18 +1,22 @@
-// fp64 fused linearise + Schur kernel for one camera group (<= 16 cameras of the 11-parameter model, dense or masked visibility).
+// fp64 fused linearise + Schur kernels: k_schur_fused_f64 for one camera group (<= 16 cameras of the 11-parameter model, dense or
+// masked visibility) and k_schur_fused_wide_f64 for 17 .. 23 cameras (compact rows; further down).
 // Test/bench infrastructure never includes this file directly: it is part of the engine translation unit (sba_engine.hpp).
 //
-// What it replaces (round 3): the fp64 default path ran k_linearize_cams<double> (Jacobians + U_c on the f64 MFMA, 32 us at
-// 16 x 50k), k_reduce_cams (5 us) and k_schur_sym<double, LIN> (135 us: all eight waves build a 32-point panel, then all eight
-// consume it -- profiles/r3_sq_counters_16x50k_f64.json: matrix pipe 42-48 % busy, VALU and MFMA phases alternate in lockstep).
-// Here the fp32 kernels' structure is used instead (k_schur_fused, sba_kernels.hpp): four producer waves evaluate every
-// observation's Jacobian ONCE per iteration (lane = (point of a 16-point chunk, camera)), accumulate U_c / g_c in registers,
-// reduce V_p / g_p over the DPP row, factor the damped 3x3 block and write the 48 x 176 panel Ytilde of the chunk into one of
-// two LDS buffers; four consumer waves (one per SIMD, 17/17/16/16 of the 66 upper-triangle tiles each, 8 VGPRs per tile) form
-// panel^T panel with v_mfma_f64_16x16x4_f64 from the other buffer.  f64 MFMA and f64 VALU of the two waves of a SIMD do not
-// overlap on gfx950 (tools/micro/mix_rate.hip), so the floor is the SUM of the two instruction streams -- what the split buys is
-// that neither pipe idles while the other role waits on memory or LDS, and that the Jacobians are no longer evaluated twice.
-//   LDS: 2 x (48 x 176 + 48) doubles of panel + z (135,936 B), camera table 16 x 25 doubles, folded U_c 16 x 77 doubles: 148,992 B.
-//   The per-lane U_c / g_c accumulators (77 doubles x 256 lanes = 157 KB) are handed over through the panel buffers in two passes.
+// What k_schur_fused_f64 replaces (round 3): the fp64 default path ran k_linearize_cams<double> (Jacobians + U_c on the f64 MFMA,
+// 35 us at 16 x 50k), k_reduce_cams (5 us), k_schur_sym<double, LIN> (141 us: all eight waves build a 32-point panel, then all eight
+// consume it -- profiles/r3_sq_counters_16x50k_f64.json: matrix pipe 42-48 % busy, VALU and MFMA phases alternate in lockstep) and
+// k_decide (5 us).  Here the fp32 kernels' structure is used instead (k_schur_fused, sba_kernels.hpp): the previous step's LM
+// decision in the prologue; four producer waves evaluate every observation's Jacobian ONCE per iteration (lane = (point of a
+// 16-point chunk, camera)), accumulate U_c / g_c, reduce V_p / g_p over the DPP row, factor the damped 3x3 block and write the
+// 48 x 176 panel Ytilde of the chunk into one of two LDS buffers; four consumer waves (one per SIMD, 17/17/16/16 of the 66
+// upper-triangle tiles each, 8 VGPRs per tile) form panel^T panel with v_mfma_f64_16x16x4_f64 from the other buffer.  On gfx950 the
+// f64 MFMA holds the SIMD's issue for 64 cycles and a VALU wave beside it gets about three instructions in per MFMA
+// (tools/micro/rate_f64.hip): the time of a chunk is, to first order, the SUM of the two instruction streams (12.8k MFMA cycles +
+// ~760 VALU instructions per observation = 18.6k cycles per 16 points), so what the kernel gains over its predecessors is the
+// second Jacobian evaluation, three launches, and every instruction it does not issue -- and it only gains as long as it runs
+// without scratch (see SchurF64Cfg::KREG).
+//   LDS: 2 x (48 x 176 + 48) doubles of panel + z (135,936 B), camera table 16 x 25 doubles, folded U_c 16 x 77 doubles, the
+//   accumulator sets 4 x 16 x 25 doubles: 161,792 B.  The register accumulators are handed over through the panel buffers.
 //   Outputs are those of k_schur_fused in T = double: slab [121 tile slots][64 lanes][4] per workgroup, bpart, gdpart, pf, gp, D2p.
 #pragma once
 #include "sba_kernels.hpp"
