@@ -242,3 +242,19 @@ def test_fused_f64_kernels_on_tiny_rigs(monkeypatch, C, N):
     Ea, sa, da = _system(*args, fused=True, lam=1e-2)
     Eb, sb, db = _system(*args, fused=False, lam=1e-2)
     _compare(Ea, sa, da, Eb, sb, db, 11 * C, tol=1e-10)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fused_f64_kernels_on_random_shapes(monkeypatch, seed):
+    """Shapes nobody picked by hand: 2 .. 23 cameras, 1 .. 3000 points, visibility 0.4 .. 1, with and without weights."""
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.integers(2, 24))
+    N = int(rng.integers(1, 3001))
+    vis = float(rng.choice([1.0, rng.uniform(0.4, 1.0)]))
+    rig = make_rig(C, N, seed=2000 + seed, visibility=vis, min_cams_per_point=min(2, C))
+    ci = rig["camera_ind"]
+    wts = rng.uniform(0.5, 1.5, ci.size) if seed % 2 else None
+    args = (rig, rig["points_2d"], ci, rig["point_ind"], wts, monkeypatch)
+    Ea, sa, da = _system(*args, fused=True, lam=1e-3)
+    Eb, sb, db = _system(*args, fused=False, lam=1e-3)
+    _compare(Ea, sa, da, Eb, sb, db, 11 * C, tol=1e-10)
