@@ -65,15 +65,22 @@ def _env_device():
 
 
 class SBAResult(OptimizeResult):
-    """scipy ``OptimizeResult`` whose ``jac`` / ``grad`` are computed on first access.
+    """scipy ``OptimizeResult`` whose ``fun`` and ``jac`` / ``grad`` are computed on first access.
 
-    scipy returns the final Jacobian as a (2M x n) CSR matrix (least_squares.py:950-961); at
-    800k observations that is 22.4M non-zeros which the reference's caller never reads
-    (scripts/calibrate_camera.py:71 discards the result), so it is materialised lazily by the
-    device Jacobian kernel instead of on every solve.
+    scipy returns the final residual vector and the final Jacobian -- a (2M x n) CSR matrix (least_squares.py:950-961), 22.4M
+    non-zeros at 800k observations -- with every result; the reference's caller never reads either (scripts/calibrate_camera.py:71
+    discards the result).  The residual read-back alone was 0.6 ms of the 2.7 ms a ``bundleAdjust`` call takes at 16 x 50k
+    (tools/wall_pysba.py), so both are materialised by the device kernels when somebody asks: attribute or item access, ``in``,
+    iteration over the keys, ``repr`` and pickling all see a complete result.
     """
 
     def __missing__(self, key):
+        if key == "fun":
+            maker = dict.get(self, "_fun_maker")
+            if maker is None:
+                raise KeyError(key)
+            dict.__setitem__(self, "fun", maker())
+            return dict.__getitem__(self, "fun")
         if key in ("jac", "grad"):
             maker = dict.get(self, "_jac_maker")
             if maker is None:
@@ -90,9 +97,31 @@ class SBAResult(OptimizeResult):
         except KeyError as e:
             raise AttributeError(name) from e
 
-    def __reduce__(self):   # drop the closure when pickled
-        d = {k: v for k, v in self.items() if k != "_jac_maker"}
-        return (OptimizeResult, (d,))
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (key == "fun" and dict.get(self, "_fun_maker") is not None)
+
+    def _materialise(self):
+        if not dict.__contains__(self, "fun") and dict.get(self, "_fun_maker") is not None:
+            self["fun"]
+
+    def keys(self):
+        self._materialise()
+        return [k for k in dict.keys(self) if not k.startswith("_")]
+
+    def items(self):
+        return [(k, dict.__getitem__(self, k)) for k in self.keys()]
+
+    def values(self):
+        return [dict.__getitem__(self, k) for k in self.keys()]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __repr__(self):
+        return repr(OptimizeResult(self.items()))
+
+    def __reduce__(self):   # drop the closures when pickled; the residual vector goes along
+        return (OptimizeResult, (dict(self.items()),))
 
 
 def _print_table(log, initial_cost, report, message, verbose):
@@ -233,7 +262,7 @@ class PySBA:
             self._apply_extensions(prob, pts.shape[0])
             opts = prob.make_opts(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev or 0, mode=mode, verbose=verbose)
             cams_opt, pts_opt, rep, log = prob.solve_lm(opts)
-            fvec, _ = prob.residual()
+        fvec = None                    # res.fun is evaluated on first access (SBAResult)
         if first is not None:          # one report over both stages: counts add up, the table runs on
             rep1, log1 = first
             for row in log:
@@ -266,9 +295,18 @@ class PySBA:
             return assemble_jacobian(Jc, Jp, ci, pi, C_, N_, points_only=(mode == _native.MODE_POINTS_ONLY),
                                      shared_intrinsics=(mode == _native.MODE_SHARED_INTR))
 
-        res = SBAResult(x=x, cost=rep.cost, fun=fvec, optimality=rep.optimality,
+        def make_fun():
+            with _native.Problem(cams_opt, pts_opt, uv, ci, pi, weights=w, dtype=dt, device=dev) as prob:
+                self._apply_extensions(prob, N_)
+                return prob.residual()[0]
+
+        res = SBAResult(x=x, cost=rep.cost, optimality=rep.optimality,
                         active_mask=np.zeros_like(x), nfev=int(rep.nfev), njev=int(rep.njev),
                         status=int(rep.status), message=message, success=rep.status > 0)
+        if fvec is not None:
+            dict.__setitem__(res, "fun", fvec)
+        else:
+            dict.__setitem__(res, "_fun_maker", make_fun)
         dict.__setitem__(res, "_jac_maker", make_jac)
         return res, cams_opt, pts_opt
 

@@ -103,3 +103,26 @@ def test_mixed_precision_mode_lands_on_the_fp64_solution(monkeypatch, capsys):
         assert abs(cost - ref.cost) <= 5e-5 * ref.cost       # same bar as test_solve_and_exports_on_the_example_rig
     assert abs(out["mixed"][1] - out["f64"][1]) <= 5e-5 * out["f64"][1]
     assert out["mixed"][0].nfev >= 2
+
+
+def test_result_object_materialises_fun_on_demand():
+    """res.fun (and res.jac / res.grad) are evaluated when somebody asks -- the reference's caller never does
+    (scripts/calibrate_camera.py:71 discards the result): attribute and item access, `in`, the key views, repr and pickling all see
+    the complete scipy result, and the values are the oracle's residual at the returned point."""
+    import pickle
+    from lasercalib_amd.synth import make_rig
+    rig = make_rig(6, 300, seed=8, visibility=0.8)
+    sba = PySBA(rig["cams0"].copy(), rig["pts0"].copy(), rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    res = sba.bundleAdjust(1e-6)
+    assert not dict.__contains__(res, "fun") and "fun" in res          # not computed yet, but part of the result
+    f = orc.fun(np.hstack((sba.cameraArray.ravel(), sba.points3D.ravel())), 6, 300, rig["camera_ind"], rig["point_ind"],
+                rig["points_2d"], orc.default_weights(rig["point_ind"]))
+    assert np.max(np.abs(res.fun - f)) <= 1e-9 and abs(0.5 * res.fun @ res.fun - res.cost) <= 1e-10 * res.cost
+    assert dict.__contains__(res, "fun") and res["fun"] is res.fun
+    res2 = sba.bundleAdjust(1e-6)
+    assert set(res2.keys()) >= {"x", "cost", "fun", "optimality", "nfev", "njev", "status", "message", "success", "active_mask"}
+    assert "fun:" in repr(sba.bundleAdjust(1e-6))
+    back = pickle.loads(pickle.dumps(sba.bundleAdjust(1e-6)))          # (every call continues from the point of the one before)
+    f = orc.fun(np.hstack((sba.cameraArray.ravel(), sba.points3D.ravel())), 6, 300, rig["camera_ind"], rig["point_ind"],
+                rig["points_2d"], orc.default_weights(rig["point_ind"]))
+    assert np.max(np.abs(back.fun - f)) <= 1e-9 and back.status in (2, 3, 4)
