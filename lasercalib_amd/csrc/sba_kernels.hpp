@@ -742,6 +742,42 @@ __device__ __forceinline__ double half32_sum(double v) {
                : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
   return __hiloint2double(hi0, lo0) + __hiloint2double(hi1, lo1);
 }
+// inclusive prefix sum over the 64 lanes of the wave: Hillis-Steele inside every DPP row (row_shr 1, 2, 4, 8; lanes shifted in from
+// outside the row read 0), then the row totals travel on: row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3
+__device__ __forceinline__ float wave_scan(float v) {
+  auto dpp = [](float x, auto ctrl, auto rmask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true));
+  };
+  using I = std::integral_constant<int, 0xf>;
+  v += dpp(v, std::integral_constant<int, 0x111>{}, I{});      // row_shr:1
+  v += dpp(v, std::integral_constant<int, 0x112>{}, I{});      // row_shr:2
+  v += dpp(v, std::integral_constant<int, 0x114>{}, I{});      // row_shr:4
+  v += dpp(v, std::integral_constant<int, 0x118>{}, I{});      // row_shr:8
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});      // row_bcast:15 -> rows 1, 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});      // row_bcast:31 -> rows 2, 3
+  return v;
+}
+// inclusive prefix sum of a double over the 64 lanes of the wave (wave_scan of sba_schur_wide.hpp on both dwords): Hillis-Steele
+// inside every DPP row (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then the row totals travel on
+// (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
+__device__ __forceinline__ double wave_scan(double v) {
+  auto dpp = [](double x, auto ctrl, auto rmask) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  using I = std::integral_constant<int, 0xf>;
+  v += dpp(v, std::integral_constant<int, 0x111>{}, I{});      // row_shr:1
+  v += dpp(v, std::integral_constant<int, 0x112>{}, I{});      // row_shr:2
+  v += dpp(v, std::integral_constant<int, 0x114>{}, I{});      // row_shr:4
+  v += dpp(v, std::integral_constant<int, 0x118>{}, I{});      // row_shr:8
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});      // row_bcast:15 -> rows 1, 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});      // row_bcast:31 -> rows 2, 3
+  return v;
+}
+// wave-uniform copy of lane `src` (a wave-uniform index)
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
+__device__ __forceinline__ double lane_bcast(double v, int src) { return lane_f64(v, src); }
 // L^-1 of the 3x3 SPD matrix (v00,v01,v02,v11,v12,v22) with hardware rsq (1 ulp): no sqrt / divide sequences
 __device__ __forceinline__ bool chol3_inv_fast(const float v[6], float li[6]) {
   // straight-line: a failing pivot is replaced by 1 so that everything stays finite, and the verdict is one flag at the

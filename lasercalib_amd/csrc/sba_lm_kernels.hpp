@@ -573,7 +573,8 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_trial_scalars(const double* 
 // (camera tables staged once, chunks strided over the grid) and each partial row holds a whole workgroup's share.
 // LW = lanes per point: 16 (one DPP row: up to 16 cameras) or 32 (a wave half: 17 .. 23 cameras, the rigs of k_schur_fused_wide --
 // sums over the half, 8 points per chunk; 17 of 32 lanes work at 17 cameras, so it only draws level with k_backsub_trial there
-// (17 x 50k: 166.8 us per iteration either way) and gains from 20 cameras on (20 x 50k 218 -> 213.8 us).
+// (17 x 50k: 166.8 us per iteration either way) and gains from 20 cameras on (20 x 50k 218 -> 213.8 us).  LW = 0 (17 .. 21 cameras):
+// three points per wave, packed -- 17 x 50k 166.8 -> 162.5 us per iteration in fp32, 273.0 -> 268.8 in fp64, 20 x 50k 213.8 -> 209.6.
 template <typename T, int LW = 16>
 __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
     const ParamSets<T> ps, int C, const typename Vec2<T>::type* __restrict__ uv /* observation (p, c) at p*C + c */,
@@ -583,7 +584,10 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
                                                   sits at pt_start[group][p] + popcount(mask below bit c & 15), a lane without one idles through
                                                   the row sums (one group: the point's mask and first observation) */,
     const int32_t* __restrict__ pt_start = nullptr) {
-  constexpr int MAXC = LW == 16 ? GROUP_CAMS : 24, PPC = PM_BLOCK / LW;       // cameras the tables hold, points per chunk
+  // LW = 0: PACKED -- three points per wave, lane l -> point l / C, camera l % C (17 .. 21 cameras: 51 .. 63 of the 64 lanes work
+  // instead of 34 .. 42 with a point per half); the sums over a point's cameras = segment differences of a wave-wide prefix scan
+  constexpr bool PACK = LW == 0;
+  constexpr int MAXC = LW == 16 ? GROUP_CAMS : 24, PPC = PACK ? 3 * (PM_BLOCK / 64) : PM_BLOCK / (PACK ? 1 : LW);       // cameras the tables hold, points per chunk
   __shared__ T s_cam01[2][MAXC * CAMPRE], s_dc[MAXC * NCP];
   __shared__ double s_scr[PM_BLOCK / 64];
   // both camera tables are needed whichever is current: they and the camera step are requested before the state record's round trip
@@ -601,10 +605,21 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
   const bool free_cams = st->free_cams != 0;
   const double lam = st->lam;
   __syncthreads();
-  const int q = threadIdx.x / LW, c = threadIdx.x % LW;
-  const bool cam_ok = c < C;
+  const int lane_ = threadIdx.x & 63;
+  const int hseg = PACK ? ((lane_ >= C) + (lane_ >= 2 * C) + (lane_ >= 3 * C)) : 0;
+  const int q = PACK ? 3 * (int)(threadIdx.x >> 6) + min(hseg, 2) : (int)threadIdx.x / (PACK ? 1 : LW);
+  const int c = PACK ? lane_ - hseg * C : (int)threadIdx.x % (PACK ? 1 : LW);
+  const bool cam_ok = PACK ? hseg < 3 : c < C;
   const int grp = (cam_ok ? c : 0) >> 4, cc = c & 15;
-  auto lane_sum = [](T v) -> T { if constexpr (LW == 16) return row16_sum(v); else return half32_sum(v); };
+  auto lane_sum = [&](T v) -> T {
+    if constexpr (LW == 16) return row16_sum(v);
+    else if constexpr (LW == 32) return half32_sum(v);
+    else {
+      const T sc = wave_scan(v);
+      const T e0 = lane_bcast(sc, C - 1), e1 = lane_bcast(sc, 2 * C - 1), e2 = lane_bcast(sc, 3 * C - 1);
+      return hseg == 0 ? e0 : hseg == 1 ? e1 - e0 : e2 - e1;
+    }
+  };
   T dc[NCP];
 #pragma unroll
   for (int e = 0; e < NCP; ++e) dc[e] = cam_ok ? s_dc[c * NCP + e] : (T)0;
@@ -654,7 +669,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
       e2 = l5 * y2;
     }
     const double n0 = X0 + e0, n1 = X1 + e1, n2 = X2 + e2;
-    if (pt_ok && c == 0) {
+    if (pt_ok && cam_ok && c == 0) {
       pts_new[pp * 3] = n0; pts_new[pp * 3 + 1] = n1; pts_new[pp * 3 + 2] = n2;
       ptsT_new[pp * 3] = (T)n0; ptsT_new[pp * 3 + 1] = (T)n1; ptsT_new[pp * 3 + 2] = (T)n2;
       pred += 0.5 * (e0 * (lam * dd0 * e0 - g0) + e1 * (lam * dd1 * e1 - g1) + e2 * (lam * dd2 * e2 - g2));

@@ -58,21 +58,6 @@ template <int NTW> __host__ __device__ constexpr int wide_tile_T(int t) {
   return R + rem;
 }
 
-// inclusive prefix sum over the 64 lanes of the wave: Hillis-Steele inside every DPP row (row_shr 1, 2, 4, 8; lanes shifted in from
-// outside the row read 0), then the row totals travel on: row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3
-__device__ __forceinline__ float wave_scan(float v) {
-  auto dpp = [](float x, auto ctrl, auto rmask) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true));
-  };
-  using I = std::integral_constant<int, 0xf>;
-  v += dpp(v, std::integral_constant<int, 0x111>{}, I{});      // row_shr:1
-  v += dpp(v, std::integral_constant<int, 0x112>{}, I{});      // row_shr:2
-  v += dpp(v, std::integral_constant<int, 0x114>{}, I{});      // row_shr:4
-  v += dpp(v, std::integral_constant<int, 0x118>{}, I{});      // row_shr:8
-  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});      // row_bcast:15 -> rows 1, 3
-  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});      // row_bcast:31 -> rows 2, 3
-  return v;
-}
 
 template <int NTW, int PW>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
