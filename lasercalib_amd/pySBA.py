@@ -56,7 +56,8 @@ def _env_mixed():
     """LASERCALIB_SBA_DTYPE=mixed: bundleAdjust / _nocam / _sharedcam iterate on the fp32 engine (the fused bf16-pipe kernels) until
     the caller's tolerances stop it, then continue on the fp64 engine from that point with the same tolerances.  The returned
     point is the fp64 engine's -- it satisfies the same termination tests as a pure fp64 solve -- while most iterations ran at
-    the fp32 rate (17 cameras x 10k points at the example's visibility: 109 us per iteration instead of 232)."""
+    the fp32 rate (17 cameras x 10k points at the example's visibility: 109 us per iteration instead of 140; 232 before the fp64 engine
+    got its own one-launch kernels in round 3)."""
     return os.environ.get("LASERCALIB_SBA_DTYPE", "f64") == "mixed"
 
 
