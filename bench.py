@@ -66,6 +66,62 @@ def pmc_traffic_bytes(slot, C, Np, dtype, tangential=False, visibility=1.0):
     return None, None
 
 
+def rocprof_kernel_us(kname, C, Np, dtype, tangential=False, visibility=1.0):
+    """(average launch duration in us, source file) of a kernel from the newest committed rocprofv3 --kernel-trace --stats summary
+    of this bench command on this shape (profiles/r*_bench_<shape>_kernel_stats.csv), or (None, None)."""
+    import csv
+    import glob
+    import re
+    if tangential or visibility < 1.0:
+        return None, None
+    tag = f"{C}x{Np // 1000}k_{dtype}"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{tag}_kernel_stats.csv")),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)), reverse=True)
+    for f in files:
+        try:
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    name = row["Name"]
+                    if "::" + kname + "(" in name or "::" + kname + "<" in name:
+                        return float(row["AverageNs"]) * 1e-3, os.path.relpath(f, ROOT)
+        except Exception:      # noqa: BLE001
+            continue
+    return None, None
+
+
+def e2e_block(rig, dtype, calls=7):
+    """Wall time of the drop-in call as the reference's caller makes it (scripts/calibrate_camera.py:62-72): construct PySBA on the
+    host arrays, bundleAdjust(1e-4) -- handle creation, upload (PCIe), device layout, the LM solve to ITS OWN convergence, download
+    of cameras and points, result packaging -- in a warm process.  Median of `calls` calls after one untimed call."""
+    import contextlib
+    import io
+    from lasercalib_amd.pySBA import PySBA
+    old = os.environ.get("LASERCALIB_SBA_DTYPE")
+    os.environ["LASERCALIB_SBA_DTYPE"] = dtype
+    try:
+        times, res = [], None
+        for k in range(calls + 1):
+            cams, pts = rig["cams0"].copy(), rig["pts0"].copy()
+            t0 = time.perf_counter()
+            sba = PySBA(cams, pts, rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = sba.bundleAdjust(1e-4)
+            dt = time.perf_counter() - t0
+            if k:
+                times.append(dt)
+    finally:
+        if old is None:
+            os.environ.pop("LASERCALIB_SBA_DTYPE", None)
+        else:
+            os.environ["LASERCALIB_SBA_DTYPE"] = old
+    med = float(np.median(times))
+    iters = max(1, int(res.nfev) - 1)
+    return {"dtype": dtype, "seconds": med, "seconds_min": float(min(times)), "seconds_max": float(max(times)), "calls": calls,
+            "lm_iterations": iters, "nfev": int(res.nfev), "status": int(res.status), "final_cost": float(res.cost),
+            "lm_iters_per_s_incl_upload": iters / med,
+            "what": "PySBA(...) + bundleAdjust(1e-4): handle, host-to-device upload, layout, LM solve to convergence, download, packaging"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +136,8 @@ def parse():
     ap.add_argument("--f64-record", default="auto", choices=["auto", "off"], help="also time the f64 engine (PySBA's default dtype) "
                     "on the same workload and report it as the `f64` block (N=1, f32 runs only)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--e2e", default="auto", choices=["auto", "off"], help="also time the drop-in call PySBA(...).bundleAdjust(1e-4) "
+                    "end to end (upload included) on the same rig, f32 and f64 (N=1)")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline solve; 0 = the GPU workload's own point count "
                     "(16 x 50,000: about 2 minutes of scipy); pass e.g. 5000 for a short sample")
     return ap.parse_args()
@@ -160,8 +218,13 @@ def roofline_of_step(kt, dtype, P, C, Nloc, M_local, shape):
         else:
             kname = "k_schur_diag_bf3 + k_schur_offdiag_bf3" if C > 16 else "k_schur<float>"
         tb, tsrc = traffic("schur_fused" if fused else "schur")
+        # the same fraction from the committed rocprofv3 kernel-trace summary of this command (its average duration for the kernel);
+        # `frac` itself stays the live HIP-event figure of THIS run
+        rp_us, rp_src = rocprof_kernel_us(kname, *shape) if " " not in kname and "<" not in kname else (None, None)
         return {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dtype],
                 "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[dtype], "traffic": tb, "traffic_source": tsrc,
+                "frac_rocprof": (flops_mfma / (rp_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS[dtype]) if rp_us else None,
+                "rocprof_launch_us": rp_us, "rocprof_source": rp_src,
                 "algorithmic_flops_per_launch": flops_mfma, "launch_us": kt["schur"],
                 # the linearisation the fused kernel also carries on the VALU (SURVEY 8d estimate), kept apart from `frac`
                 "valu_flops_estimate": flops_valu,
@@ -374,6 +437,9 @@ def main():
             # the timed region is the K iterations (sba_lm_run); once per solve, outside it: sba_lm_begin (reset + cost of the initial
             # point) and sba_lm_finish (gradient at the returned point + download of cameras and points to pageable host memory)
             "timed_region": "K LM iterations (sba_lm_run) between sba_lm_begin and sba_lm_finish",
+            # version 1 (rounds 1, 2 and the first half of 3): sba_lm_begin and sba_lm_finish inside the timer -- that figure is
+            # `ms_per_step_with_begin_and_finish`, the one to compare with those rounds; version 2: the iterations alone
+            "timed_region_version": 2,
             "per_solve_us": per_solve_main,
             "ms_per_step_with_begin_and_finish": (dt + (per_solve_main.get("lm_begin", 0.0) + per_solve_main.get("lm_finish", 0.0)) * 1e-6) / a.steps * 1e3,
             "cost_first_last": [costs[0], costs[-1]] if costs else None,
@@ -396,6 +462,11 @@ def main():
                       "cost_first_last": [costs64[0], costs64[-1]] if costs64 else None,
                       "roofline": roofline_of_step(kt64, "f64", P, C, Nloc, M_local, (C, Np, "f64", a.tangential, a.visibility)),
                       "note": "the drop-in class's default engine (LASERCALIB_SBA_DTYPE unset): same workload and step as the headline"}
+    # end-to-end wall time of the drop-in call on the same rig (SURVEY 8(d) metric (1): "report both incl./excl." upload), N = 1
+    if world == 1 and rank == 0 and a.e2e != "off":
+        prob.close()
+        out["e2e"] = {dt_: e2e_block(rig, dt_) for dt_ in ("f32", "f64")}
+        out["lm_iters_per_s_incl_upload"] = out["e2e"][a.dtype]["lm_iters_per_s_incl_upload"]
     # SBA_BENCH_COMPARE_IPC=1 (N > 1, opt-in): the same steps once more over the one-shot exchange through peer-mapped buffers
     # (csrc/sba_ipc.hpp) on a second handle, reported beside the headline as `ipc_exchange` -- the comparison of the two exchange
     # mechanisms on whatever node this runs on.  Off by default: the headline is the RCCL path BASELINE.json names.
@@ -426,7 +497,13 @@ def main():
             cb = cpu_baseline(C, cpu_pts, rig_kw=rig_kw)
             out["cpu_baseline"] = cb
             if cpu_pts == Np:      # same configuration on both sides: the ratio of LM iterations per second is meaningful
+                # steady-state device iterations against scipy's whole-solve wall / iterations: NOT like for like (stated);
+                # `speedup_e2e` below is
                 out["speedup_vs_cpu_lm_iters_per_s"] = out["lm_iters_per_s"] / cb["lm_iters_per_s"]
+                if "e2e" in out:
+                    # like for like: ONE bundleAdjust(1e-4) call on the same rig, both sides to their own convergence, everything
+                    # included on both sides (scipy: sparsity build, grouping, FD Jacobians, LSMR; device: upload, solve, download)
+                    out["speedup_e2e"] = {k: cb["seconds"] / v["seconds"] for k, v in out["e2e"].items()}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()          # (sba_ipc: nobody frees an area a peer may still be reading)

@@ -213,13 +213,14 @@ int sba_lm_get_log(sba_handle* h, sba_lm_iter_log* log, int32_t log_capacity, in
  * sba_set_fixed_points: the reference accepts `points3Dfixed` and never uses it (pySBA.py:28,55), so all 7 degrees of freedom of
  *     the similarity gauge float.  fixed_mask[p] != 0 holds point p at its uploaded coordinates: it drops out of the unknowns (no
  *     3x3 block, no step, not counted in x / gradient norms) while its observations keep constraining the cameras.  NULL clears.
- * sba_set_robust_loss: the objective of scipy.optimize.least_squares(loss='huber', f_scale), on every residual component
- *     (rho(z) = z for z <= 1, 2 sqrt(z) - 1 beyond, z = (f / f_scale)^2; cost = 0.5 f_scale^2 sum rho), minimised by
+ * sba_set_robust_loss: the objective of scipy.optimize.least_squares(loss='huber' | 'soft_l1' | 'cauchy', f_scale), on every
+ *     residual component (z = (f / f_scale)^2; huber: rho(z) = z for z <= 1, 2 sqrt(z) - 1 beyond; soft_l1: 2 (sqrt(1 + z) - 1);
+ *     cauchy: ln(1 + z); cost = 0.5 f_scale^2 sum rho -- scipy/optimize/_lsq/least_squares.py:189-226), minimised by
  *     iteratively re-weighted Gauss-Newton steps (rows scaled by sqrt(rho')); the reference calls least_squares with the
  *     default linear loss (pySBA.py:141).  sba_residual keeps returning the plain residual vector;
  *     reported costs are the robust ones.  Applies to modes FULL / POINTS_ONLY / SHARED_INTR.
  * Both persist on the handle until changed. */
-typedef enum { SBA_LOSS_LINEAR = 0, SBA_LOSS_HUBER = 1 } sba_loss;
+typedef enum { SBA_LOSS_LINEAR = 0, SBA_LOSS_HUBER = 1, SBA_LOSS_SOFT_L1 = 2, SBA_LOSS_CAUCHY = 3 } sba_loss;
 int sba_set_fixed_points(sba_handle* h, const uint8_t* fixed_mask /*N bytes or NULL*/);
 int sba_set_robust_loss(sba_handle* h, int32_t loss /*sba_loss*/, double f_scale);
 
@@ -243,10 +244,15 @@ int sba_comm_init(sba_handle* h, const uint8_t* id /*SBA_COMM_ID_BYTES*/, int32_
  * exports one "area" (sba_ipc_export: hipIpcGetMemHandle of uncached device memory sized for n_ranks), the caller carries the
  * 64-byte handles between the processes (any channel: the Python host uses torch.distributed / gloo), and every rank maps all
  * of them (sba_ipc_attach).  Per LM trial a rank writes its packed reduced system, later its 8 trial scalars, into its own area,
- * raises a flag, waits in a one-wave kernel (bounded: 5 s, then the solve returns SBA_ERR_STATE on that rank) for the peers'
+ * raises a flag, waits in a one-wave kernel (bounded: 5 s by default, SBA_IPC_TIMEOUT_S in the environment of sba_ipc_export
+ * changes it; then the solve returns SBA_ERR_STATE on that rank and the handle takes no further exchange) for the peers'
  * flags and adds the n_ranks copies in rank order: the same bits on every rank, two or three small launches per exchange
  * instead of an RCCL collective.  Works between processes sharing ONE device (how tests/test_gpu_ipc.py runs the in-library
- * sharded loop on a one-GPU box) and between peer GPUs of one node.  Exclusive with sba_comm_init. */
+ * sharded loop on a one-GPU box), between handles of ONE process (ranks as threads: the library finds same-process areas
+ * in a table instead of opening their handles) and between peer GPUs of one node (EXPERIMENTAL: never run across devices,
+ * see DESIGN.md section 6).  Exclusive with sba_comm_init, both ways.  The area is uncached device memory; where that
+ * cannot be allocated sba_ipc_export fails (SBA_IPC_ALLOW_CACHED=1 accepts cached memory, valid on one device only).
+ * A caller must not destroy a handle while a peer may still be reading its area (barrier first). */
 #define SBA_IPC_HANDLE_BYTES 64
 int sba_ipc_export(sba_handle* h, int32_t n_ranks, uint8_t* handle_out /*SBA_IPC_HANDLE_BYTES*/);
 int sba_ipc_attach(sba_handle* h, int32_t rank, int32_t n_ranks, const uint8_t* handles_all /*n_ranks * SBA_IPC_HANDLE_BYTES, rank order*/);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsba_hip.so")
 
 SBA_F64, SBA_F32 = 0, 1
 CAM_RADIAL, CAM_RADIAL_TANGENTIAL = 0, 1        # sba_cam_model: 11 / 13 parameters per camera
-LOSS_LINEAR, LOSS_HUBER = 0, 1                   # sba_loss
+LOSS_LINEAR, LOSS_HUBER, LOSS_SOFT_L1, LOSS_CAUCHY = 0, 1, 2, 3      # sba_loss
 MODE_FULL, MODE_POINTS_ONLY, MODE_SHARED_INTR, MODE_CAMS_ONLY_SQ, MODE_TRANSFORM_SQ = 0, 1, 2, 3, 4
 NSCALARS = 8
 
@@ -298,10 +298,10 @@ class Problem:
         _check(self._lib.sba_set_fixed_points(self._h, m.ctypes.data_as(C.c_void_p)), self._h)
 
     def set_robust_loss(self, loss="huber", f_scale=1.0):
-        """scipy.optimize.least_squares(loss=..., f_scale=...) semantics; loss in ('linear', 'huber')."""
-        code = {"linear": LOSS_LINEAR, "huber": LOSS_HUBER}.get(loss)
+        """scipy.optimize.least_squares(loss=..., f_scale=...) semantics; loss in ('linear', 'huber', 'soft_l1', 'cauchy')."""
+        code = {"linear": LOSS_LINEAR, "huber": LOSS_HUBER, "soft_l1": LOSS_SOFT_L1, "cauchy": LOSS_CAUCHY}.get(loss)
         if code is None:
-            raise ValueError("loss must be 'linear' or 'huber'")
+            raise ValueError("loss must be 'linear', 'huber', 'soft_l1' or 'cauchy'")
         _check(self._lib.sba_set_robust_loss(self._h, code, float(f_scale)), self._h)
 
     # -- lifetime

@@ -127,6 +127,31 @@ struct HostResPool {
   }
 };
 
+// Exchange areas exported by handles of THIS process (sba_ipc_export): hipIpcOpenMemHandle refuses a handle of the calling
+// process, so ranks that share a process (one handle per thread, or per device of a single-process multi-GPU host) look their
+// peers' areas up here and only open what the table does not know.
+struct IpcLocalAreas {
+  struct Entry { uint8_t key[SBA_IPC_HANDLE_BYTES]; double* p; };
+  std::mutex mu;
+  std::vector<Entry> entries;
+  static IpcLocalAreas& get() { static IpcLocalAreas* t = new IpcLocalAreas(); return *t; }
+  void add(const uint8_t* key, double* p) {
+    std::lock_guard<std::mutex> lk(mu);
+    Entry e; memcpy(e.key, key, sizeof e.key); e.p = p;
+    entries.push_back(e);
+  }
+  void remove(const uint8_t* key) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < entries.size(); ++i)
+      if (!memcmp(entries[i].key, key, sizeof entries[i].key)) { entries.erase(entries.begin() + i); return; }
+  }
+  double* find(const uint8_t* key) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry& e : entries) if (!memcmp(e.key, key, sizeof e.key)) return e.p;
+    return nullptr;
+  }
+};
+
 inline thread_local Arena* tl_arena = nullptr;      // set for the duration of a call on a handle (ArenaScope)
 struct ArenaScope {
   Arena* prev;

@@ -30,6 +30,10 @@ struct Engine : EngineBase {
   bool dense = false;                // every point is observed by every camera exactly once
   bool dense_one_group = false;      // dense and <= 16 cameras: lane = (point, camera) kernels apply
   int nbs_dense = 1;                 // workgroups of k_backsub_dense
+  // The lane = (point, camera) kernels (fused linearise + Schur, wide, dense back substitution) cost the DENSE instruction count
+  // whatever the visibility; below this fraction of the N x C slots filled the observation-driven three-pass path takes over.
+  // SBA_DENSE_MIN_VIS overrides it (measurements: profiles/r4_visibility_sweep.txt)
+  double dense_min_vis = 0.35;
   bool fused_masked = false;         // the fused kernel runs with the visibility mask
   bool lin_pts_ok = false;           // f64, one group: the point linearisation runs inside k_schur_sym (LIN)
   bool masked_ok = false;            // one group, no duplicate (point, camera) pairs, not dense: visibility mask available
@@ -103,16 +107,21 @@ struct Engine : EngineBase {
   DevBuf<int> up_flag;
   DevBuf<unsigned char> pt_fixed_mask;   // sba_set_fixed_points: 1 = the point is a gauge anchor (never moves, not an unknown)
   bool has_fixed = false;
-  double loss_delta = 0;                // sba_set_robust_loss: Huber f_scale, 0 = linear loss
+  double loss_delta = 0;                // sba_set_robust_loss: f_scale of the robust loss, 0 = linear loss
+  int loss_kind = 0;                    // ... and which one (sba_loss)
   Rccl::comm_t comm = nullptr;
   int comm_rank = 0, comm_n = 1;
   DevBuf<double> xpack, sc_loc, sc_all, comm_tmp;
   double* h_comm = nullptr;             // pinned staging of the few scalars all-reduced at begin / finish
   // one-shot exchange through peer-mapped buffers instead of RCCL (sba_ipc.hpp; sba_ipc_export / sba_ipc_attach)
   bool ipc_on = false;
+  bool ipc_dead = false;                // an exchange outside the LM loop timed out: the ranks' exchange counters no longer agree
   int ipc_planned = 0;                  // n_ranks the area was exported for
   double* ipc_mine = nullptr;           // this rank's area (uncached device memory)
+  uint8_t ipc_my_handle[SBA_IPC_HANDLE_BYTES] = {};
   std::vector<double*> ipc_area;        // every rank's area as mapped into this process (own entry = ipc_mine)
+  std::vector<char> ipc_opened;         // ... 1 where this handle called hipIpcOpenMemHandle (and has to close it)
+  long long ipc_timeout_ticks = IPC_TIMEOUT_TICKS;       // SBA_IPC_TIMEOUT_S: how long a gate waits for a peer (100 MHz ticks)
   DevBuf<double*> ipc_ptrs;             // ... the same table on the device
   DevBuf<int> ipc_fail;                 // set by a gate that ran out of time outside the LM loop
   IpcLayout ipc_L{};
@@ -155,9 +164,8 @@ struct Engine : EngineBase {
   ~Engine() override {
     if (comm) (void)Rccl::get().comm_destroy(comm);
     if (stream) (void)hipStreamSynchronize(stream);
-    for (size_t r = 0; r < ipc_area.size(); ++r)
-      if (ipc_area[r] && ipc_area[r] != ipc_mine) (void)hipIpcCloseMemHandle(ipc_area[r]);
-    if (ipc_mine) (void)hipFree(ipc_mine);
+    ipc_close_peers();
+    if (ipc_mine) { IpcLocalAreas::get().remove(ipc_my_handle); (void)hipFree(ipc_mine); }
     if (h_comm) (void)hipHostFree(h_comm);
     if (have_hres) {
       if (stream) (void)hipStreamSynchronize(stream);     // nothing of this handle may still be in flight when its buffers are recycled
@@ -190,6 +198,11 @@ struct Engine : EngineBase {
     d_state_buf.alloc(2);
     d_state.p = d_state_buf.p;
     if (getenv("SBA_DECIDE_KERNEL")) defer_decide = false;
+    if (const char* e = getenv("SBA_DENSE_MIN_VIS")) {
+      char* end = nullptr;
+      const double v = strtod(e, &end);
+      if (end != e && v >= 0 && v <= 1) dense_min_vis = v;
+    }
     // SBA_FUSED_MFMA=f32 keeps the f32-input MFMA kernel (A/B measurements, equivalence test); default: bf16 x 3 split
     if (const char* e = getenv("SBA_FUSED_MFMA")) fused_bf3 = (std::string(e) != "f32");
     if (const char* e = getenv("SBA_CHOL")) {
@@ -497,7 +510,7 @@ struct Engine : EngineBase {
     // one-group kernel its producer cost does not shrink with the visibility, so below ~35 % the three-pass path stays.
     fused_wide = false;
     if constexpr (sizeof(T) == 4) {
-      const bool dense_enough = (double)M >= 0.35 * (double)N * C;
+      const bool dense_enough = (double)M >= dense_min_vis * (double)N * C;
       const bool rig_ok = C > GROUP_CAMS ? (dense || (grp_indexed && dense_enough))
                                          : (NCP != 11 && !getenv("SBA_NO_DENSE") && (dense || (masked_ok && dense_enough)));
       fused_wide = rig_ok && C * NCP <= 16 * WIDE_MAX_NTW && N > 0 && fused_bf3 && !getenv("SBA_NO_FUSED") && !getenv("SBA_NO_WIDE");
@@ -512,7 +525,7 @@ struct Engine : EngineBase {
     // fp64, 17 and 18 cameras (12 / 13 row tiles): k_schur_fused_wide_f64 (sba_schur_f64.hpp), same eligibility; SBA_NO_FUSED64=1 or
     // SBA_NO_WIDE=1 keep the pair kernels
     if constexpr (sizeof(T) == 8) {
-      const bool dense_enough = (double)M >= 0.35 * (double)N * C;
+      const bool dense_enough = (double)M >= dense_min_vis * (double)N * C;
       fused_wide = C > GROUP_CAMS && C * NCP <= 16 * WIDE_MAX_NTW && (dense || (grp_indexed && dense_enough)) && N > 0 &&
                    !getenv("SBA_NO_FUSED") && !getenv("SBA_NO_FUSED64") && !getenv("SBA_NO_WIDE");
       if (fused_wide) {
@@ -541,14 +554,14 @@ struct Engine : EngineBase {
     dense_one_group = dense && C <= GROUP_CAMS && N > 0 && !getenv("SBA_NO_DENSE");
     // 17 .. 23 cameras, dense or group-indexed and dense enough (the rigs of the wide fused kernels): the same back substitution
     // with a point per 32-lane wave half
-    backsub_wide = C > GROUP_CAMS && C <= 23 && N > 0 && (dense || (grp_indexed && (double)M >= 0.35 * (double)N * C)) &&
+    backsub_wide = C > GROUP_CAMS && C <= 23 && N > 0 && (dense || (grp_indexed && (double)M >= dense_min_vis * (double)N * C)) &&
                    !getenv("SBA_NO_DENSE") && !getenv("SBA_NO_WIDE");
     backsub_pack = backsub_wide && 3 * C <= 64 && !getenv("SBA_WIDE_PW2");       // three points per wave (17 .. 21 cameras)
     const int bs_ppc = backsub_pack ? 12 : backsub_wide ? 8 : 16;
     nbs_dense = std::max(1, std::min((N + bs_ppc - 1) / bs_ppc, getenv("SBA_BS_WGS") ? atoi(getenv("SBA_BS_WGS")) : (sizeof(T) == 4 ? 768 : 512)));
     // the fused linearise+Schur kernel also serves sparse one-group rigs through the visibility mask; its producer cost
     // does not shrink with the number of observations, so below ~35 % visibility the three-pass path is used
-    const bool masked_fused = masked_ok && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
+    const bool masked_fused = masked_ok && N > 0 && (double)M >= dense_min_vis * (double)N * C && !getenv("SBA_NO_DENSE");
     // (the fused kernel is built for the 11-parameter model only: 77 register accumulators per lane; 13 parameters need 104)
     // (fp64, round 3: k_schur_fused_f64, same structure on the f64 matrix pipe; SBA_NO_FUSED64=1 keeps the three-launch path)
     fused_f64 = NCP == 11 && sizeof(T) == 8 && (dense_one_group || masked_fused) && !getenv("SBA_NO_FUSED") && !getenv("SBA_NO_FUSED64");
@@ -557,7 +570,7 @@ struct Engine : EngineBase {
     lin_pts_ok = (dense_one_group || masked_fused) && SCHUR_LIN_OK<T> && !getenv("SBA_NO_FUSED") && !fused_f64;
     // (the lane = (point, camera) back substitution serves sparse one-group rigs through the same mask, down to the visibility
     //  where the point-aligned kernel, whose cost follows the observation count, wins)
-    backsub_masked = masked_ok && C <= GROUP_CAMS && N > 0 && (double)M >= 0.35 * (double)N * C && !getenv("SBA_NO_DENSE");
+    backsub_masked = masked_ok && C <= GROUP_CAMS && N > 0 && (double)M >= dense_min_vis * (double)N * C && !getenv("SBA_NO_DENSE");
     if (fused_masked || (lin_pts_ok && !dense_one_group) || (fused_wide && C <= GROUP_CAMS && !dense) || backsub_masked) vis_mask.upload(vmask, stream);
     if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * (fused_wide ? WIDE_ROWS : GROUP_ROWS));
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1)); gmax_alt.alloc(std::max(std::max(nblk, ksplit), 1));
@@ -597,6 +610,7 @@ struct Engine : EngineBase {
     for (int b = 0; b < 2; ++b) { psets.cams[b] = cams[b].p; psets.pts[b] = pts[b].p; psets.ptsT[b] = ptsT[b].p; psets.campre[b] = campre[b].p; }
     psets.base = cur;
     psets.loss_delta = (T)loss_delta;
+    psets.loss_kind = loss_kind;
     psets.fixed = has_fixed ? pt_fixed_mask.p : nullptr;
   }
   // argument for launches inside the LM loop (side = base ^ LMState::cur) ...
@@ -607,7 +621,7 @@ struct Engine : EngineBase {
     const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
     if (g == 0) return;
     hipLaunchKernelGGL(k_residual<T>, dim3(g), dim3(PM_BLOCK), lds_cams(), stream, campre[cur].p, C, ptsT[cur].p,
-                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, r_out, cost_part.p, (T)loss_delta);
+                       uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, M, r_out, cost_part.p, RLoss<T>{(T)loss_delta, loss_kind});
   }
   void launch_resjac(T2* r_out) {
     const int g = (int)((M + PM_BLOCK - 1) / PM_BLOCK);
@@ -1072,6 +1086,7 @@ struct Engine : EngineBase {
   // ------------------------------------------------------------------ multi-rank plumbing (RCCL on the engine's stream)
   int comm_init(const uint8_t* id, int rank, int n_ranks) override {
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks || !id) { err = "bad communicator arguments"; return SBA_ERR_INVALID; }
+    if (ipc_on || ipc_mine) { err = "the handle already has a peer-mapped exchange area (sba_ipc_export): the two exchanges are exclusive"; return SBA_ERR_STATE; }
     Rccl& r = Rccl::get();
     if (!r.ok) { err = r.why; return SBA_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(device));
@@ -1089,15 +1104,34 @@ struct Engine : EngineBase {
   }
   // in-place all-reduce of a few host doubles (begin / finish only: the LM loop itself never leaves the device)
   // ------------------------------------------------------------------ one-shot exchange (sba_ipc.hpp)
+  void ipc_close_peers() {
+    for (size_t r = 0; r < ipc_area.size(); ++r)
+      if (ipc_area[r] && r < ipc_opened.size() && ipc_opened[r]) (void)hipIpcCloseMemHandle(ipc_area[r]);
+    ipc_area.clear(); ipc_opened.clear();
+  }
   int ipc_export(int n_ranks, uint8_t* handle_out) override {
     if (n_ranks < 1 || !handle_out) { err = "bad arguments"; return SBA_ERR_INVALID; }
     if (ipc_on || ipc_mine) { err = "the handle already has an exchange area"; return SBA_ERR_STATE; }
+    if (comm) { err = "the handle already has an RCCL communicator (the two exchanges are exclusive)"; return SBA_ERR_STATE; }
     HIPCHK(hipSetDevice(device));
     ipc_L = IpcLayout::make(n);
+    if (const char* e = getenv("SBA_IPC_TIMEOUT_S")) {
+      char* end = nullptr;
+      const double sec = strtod(e, &end);
+      if (end != e && sec > 0 && sec < 3600) ipc_timeout_ticks = (long long)(sec * 1e8);
+    }
     void* pmem = nullptr;
-    // uncached: the peers read what this rank's kernels wrote without a kernel boundary of THEIR stream in between
+    // uncached: the peers read what this rank's kernels wrote without a kernel boundary of THEIR stream in between.  A cached
+    // allocation would still work between ranks that share one device (one L2) but not between GPUs, so it is never taken
+    // silently: SBA_IPC_ALLOW_CACHED=1 asks for it (one-card rehearsals on a stack without the uncached flag) and says so.
     if (hipExtMallocWithFlags(&pmem, ipc_L.total * sizeof(double), hipDeviceMallocUncached) != hipSuccess) {
       (void)hipGetLastError();
+      if (!getenv("SBA_IPC_ALLOW_CACHED")) {
+        err = "sba_ipc_export: uncached device memory (hipDeviceMallocUncached) is not available; the one-shot exchange needs it between GPUs "
+              "(SBA_IPC_ALLOW_CACHED=1 accepts cached memory for ranks that share ONE device)";
+        return SBA_ERR_HIP;
+      }
+      fprintf(stderr, "[sba_ipc] warning: exchange area in CACHED device memory (SBA_IPC_ALLOW_CACHED=1): valid between ranks on one device only\n");
       HIPCHK(hipMalloc(&pmem, ipc_L.total * sizeof(double)));
     }
     ipc_mine = static_cast<double*>(pmem);
@@ -1107,21 +1141,35 @@ struct Engine : EngineBase {
     HIPCHK(hipIpcGetMemHandle(&hm, ipc_mine));
     static_assert(sizeof(hm) == SBA_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
     memcpy(handle_out, &hm, sizeof hm);
+    memcpy(ipc_my_handle, &hm, sizeof hm);
+    // ranks that live in the SAME process (several handles, one per thread or per device) cannot open each other's handles
+    // (hipIpcOpenMemHandle refuses the exporting process): they find the pointer here instead
+    IpcLocalAreas::get().add(ipc_my_handle, ipc_mine);
     ipc_planned = n_ranks;
     return SBA_OK;
   }
   int ipc_attach(int rank, int n_ranks, const uint8_t* handles) override {
     if (!ipc_mine || n_ranks != ipc_planned || rank < 0 || rank >= n_ranks || !handles) { err = "sba_ipc_export first, with the same n_ranks"; return SBA_ERR_STATE; }
     if (comm) { err = "the handle already has an RCCL communicator"; return SBA_ERR_STATE; }
+    if (ipc_on) { err = "the handle is already attached to its peers' exchange areas"; return SBA_ERR_STATE; }
     HIPCHK(hipSetDevice(device));
     ipc_area.assign(n_ranks, nullptr);
+    ipc_opened.assign(n_ranks, 0);
     for (int r = 0; r < n_ranks; ++r) {
       if (r == rank) { ipc_area[r] = ipc_mine; continue; }
+      if (double* local = IpcLocalAreas::get().find(handles + (size_t)r * SBA_IPC_HANDLE_BYTES)) { ipc_area[r] = local; continue; }
       hipIpcMemHandle_t hp;
       memcpy(&hp, handles + (size_t)r * SBA_IPC_HANDLE_BYTES, sizeof hp);
       void* q = nullptr;
-      HIPCHK(hipIpcOpenMemHandle(&q, hp, hipIpcMemLazyEnablePeerAccess));
+      const hipError_t oe = hipIpcOpenMemHandle(&q, hp, hipIpcMemLazyEnablePeerAccess);
+      if (oe != hipSuccess) {
+        (void)hipGetLastError();
+        ipc_close_peers();
+        err = std::string("hipIpcOpenMemHandle of rank ") + std::to_string(r) + "'s area failed: " + hipGetErrorString(oe);
+        return SBA_ERR_HIP;
+      }
       ipc_area[r] = static_cast<double*>(q);
+      ipc_opened[r] = 1;
     }
     ipc_ptrs.upload(ipc_area, stream);
     if (ipc_fail.n == 0) ipc_fail.alloc(1);
@@ -1139,11 +1187,14 @@ struct Engine : EngineBase {
   }
   void ipc_gate(int kind, unsigned long long seq, LMState* st, size_t copy_off, int ncopy, double* dst) {
     hipLaunchKernelGGL(k_ipc_gate, dim3(1), dim3(64), 0, stream, ipc_ptrs.p, comm_n, ipc_L.flag_of(kind, (int)(seq & 1)), seq, st,
-                       st ? (int*)nullptr : ipc_fail.p, copy_off, ncopy, dst);
+                       st ? (int*)nullptr : ipc_fail.p, copy_off, ncopy, dst, ipc_timeout_ticks);
   }
   void comm_reduce(double* v, int count, int op) {
     for (int i = 0; i < count; ++i) h_comm[i] = v[i];
     if (ipc_on) {
+      // after a timeout the ranks' exchange counters no longer agree (some passed the gate, some did not): the handle cannot
+      // take part in another exchange and has to be destroyed -- on every rank
+      if (ipc_dead) throw HipError{hipErrorNotReady, "an earlier exchange of this handle timed out (sba_ipc): destroy it and start over", __FILE__, __LINE__};
       const unsigned long long s = ++ipc_seq[2];
       const size_t slot = ipc_L.vec_slot((int)(s & 1));
       HIPCHK(hipMemcpyAsync(ipc_mine + slot, h_comm, sizeof(double) * count, hipMemcpyHostToDevice, stream));
@@ -1154,7 +1205,7 @@ struct Engine : EngineBase {
       HIPCHK(hipMemcpyAsync(h_comm, comm_tmp.p, sizeof(double) * count, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipMemcpyAsync(&failed, ipc_fail.p, sizeof(int), hipMemcpyDeviceToHost, stream));
       sync();
-      if (failed) throw HipError{hipErrorNotReady, "a peer rank did not reach the exchange within 5 s (sba_ipc)", __FILE__, __LINE__};
+      if (failed) { ipc_dead = true; throw HipError{hipErrorNotReady, "a peer rank did not reach the exchange in time (sba_ipc; SBA_IPC_TIMEOUT_S, default 5 s)", __FILE__, __LINE__}; }
       for (int i = 0; i < count; ++i) v[i] = h_comm[i];
       return;
     }
@@ -1503,7 +1554,7 @@ struct Engine : EngineBase {
     HIPCHK(hipGetLastError());
     prof_collect();
     const LMState& s = *h_state;
-    if (s.comm_fail) { err = "a peer rank did not reach the exchange within 5 s (sba_ipc): the sharded solve was stopped"; lm_active = false; return SBA_ERR_STATE; }
+    if (s.comm_fail) { err = "a peer rank did not reach the exchange in time (sba_ipc; SBA_IPC_TIMEOUT_S, default 5 s): the sharded solve was stopped and the handle can take no further exchange"; lm_active = false; ipc_dead = true; return SBA_ERR_STATE; }
     cur = cur_at_begin ^ (s.cur & 1);
     const int have = std::min(s.iter, LOG_CAP);
     if (have > log_read) {
@@ -1777,9 +1828,11 @@ struct Engine : EngineBase {
     return SBA_OK;
   }
   int set_robust_loss(int loss, double f_scale) override {
-    if (loss != SBA_LOSS_LINEAR && loss != SBA_LOSS_HUBER) { err = "unknown loss"; return SBA_ERR_INVALID; }
-    if (loss == SBA_LOSS_HUBER && !(f_scale > 0 && std::isfinite(f_scale))) { err = "f_scale must be positive"; return SBA_ERR_INVALID; }
-    loss_delta = loss == SBA_LOSS_HUBER ? f_scale : 0.0;
+    static_assert(SBA_LOSS_HUBER == LOSS_HUBER && SBA_LOSS_SOFT_L1 == LOSS_SOFT_L1 && SBA_LOSS_CAUCHY == LOSS_CAUCHY, "sba_loss values");
+    if (loss < SBA_LOSS_LINEAR || loss > SBA_LOSS_CAUCHY) { err = "unknown loss"; return SBA_ERR_INVALID; }
+    if (loss != SBA_LOSS_LINEAR && !(f_scale > 0 && std::isfinite(f_scale))) { err = "f_scale must be positive"; return SBA_ERR_INVALID; }
+    loss_delta = loss != SBA_LOSS_LINEAR ? f_scale : 0.0;
+    loss_kind = loss;
     push_ptrs();
     return SBA_OK;
   }

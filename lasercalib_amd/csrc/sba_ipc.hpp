@@ -20,7 +20,7 @@ namespace SBA_NS {
 
 constexpr int IPC_KINDS = 3;                 // 0: reduced system, 1: trial scalars, 2: small host-side vectors (begin / finish)
 constexpr int IPC_FLAG_STRIDE = 16;          // doubles (128 bytes) between flags
-constexpr long long IPC_TIMEOUT_TICKS = 500000000LL;      // 5 s of the 100 MHz wall clock: a gate never waits longer for a peer
+constexpr long long IPC_TIMEOUT_TICKS = 500000000LL;      // 5 s of the 100 MHz wall clock: the default bound of a gate's wait for a peer (SBA_IPC_TIMEOUT_S)
 struct IpcLayout {                           // offsets in doubles from the start of an area
   size_t flag, sys, scal, vec, total;
   int nvec;
@@ -50,7 +50,7 @@ __global__ void k_ipc_publish(double* __restrict__ mine, size_t flag_off, unsign
 // dst[r * ncopy + i].  On a timeout the solve is stopped: status 0 with the failure flag LMState::comm_fail set.
 __global__ __launch_bounds__(64) void k_ipc_gate(double* const* __restrict__ areas, int n_ranks, size_t flag_off, unsigned long long value,
                                                  LMState* __restrict__ st, int* __restrict__ fail /* outside the LM loop (st == NULL) */,
-                                                 size_t copy_off, int ncopy, double* __restrict__ dst) {
+                                                 size_t copy_off, int ncopy, double* __restrict__ dst, long long timeout_ticks) {
   if (st && st->status >= 0) return;
   const int lane = threadIdx.x;
   bool late = false;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void k_ipc_gate(double* const* __restrict__ are
     const unsigned long long* f = reinterpret_cast<const unsigned long long*>(areas[r] + flag_off);
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
-      if (wall_clock64() - t0 > IPC_TIMEOUT_TICKS) { late = true; break; }
+      if (wall_clock64() - t0 > timeout_ticks) { late = true; break; }
       __builtin_amdgcn_s_sleep(4);
     }
   }

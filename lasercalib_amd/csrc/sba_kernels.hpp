@@ -52,7 +52,9 @@ __host__ __device__ inline void wide_tile_rc(int ntw, int t, int& R, int& Tc) { 
 template <typename T> struct ParamSets {
   double* cams[2]; double* pts[2]; T* ptsT[2]; T* campre[2];
   int base;
-  T loss_delta;                     // (the engine's real type: the same rounded value everywhere, launch_residual included) > 0: Huber loss with this f_scale on every residual component (sba_set_robust_loss); 0: linear
+  T loss_delta;                     // (the engine's real type: the same rounded value everywhere, launch_residual included) > 0: robust loss with this f_scale on every residual component (sba_set_robust_loss); 0: linear
+  int loss_kind;                    // sba_loss: which rho (Huber, soft-l1, Cauchy) when loss_delta > 0
+  __host__ __device__ RLoss<T> loss() const { return RLoss<T>{loss_delta, loss_kind}; }
   const unsigned char* fixed;       // per point: 1 = held fixed (gauge anchor, sba_set_fixed_points); NULL: every point is free
 };
 template <typename T> __device__ inline bool pt_fixed(const ParamSets<T>& ps, size_t p) { return ps.fixed != nullptr && ps.fixed[p] != 0; }
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_residual(
     const T* __restrict__ campre, int C, const T* __restrict__ ptsT,
     const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w,
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, int64_t M,
-    typename Vec2<T>::type* __restrict__ r_out, double* __restrict__ cost_part, T loss_delta) {
+    typename Vec2<T>::type* __restrict__ r_out, double* __restrict__ cost_part, RLoss<T> loss) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* s_cam = reinterpret_cast<T*>(smem);
   __shared__ double s_red[PM_BLOCK / 64];
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_residual(
     obs_project<T>(s_cam + c * CAMPRE, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2], u, v);
     const T r0 = ww * (u - m.x), r1 = ww * (v - m.y);
     if (r_out) { typename Vec2<T>::type rr; rr.x = r0; rr.y = r1; r_out[o] = rr; }
-    sq = (loss_delta > (T)0) ? (double)robust_cost<T>(loss_delta, r0, r1) : (double)r0 * (double)r0 + (double)r1 * (double)r1;
+    sq = (loss.delta > (T)0) ? (double)robust_cost<T>(loss, r0, r1) : (double)r0 * (double)r0 + (double)r1 * (double)r1;
   }
   const double s = block_sum(sq, s_red);
   if (threadIdx.x == 0) cost_part[blockIdx.x] = 0.5 * s;
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points(
     T r[2], Jc[2][NCP], Jp[2][3];
     obs_resjac<T>(s_cam + c * CAMPRE, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2],
                   m.x, m.y, ww, r, Jc, Jp);
-    if (ps.loss_delta > 0.f) sq = (double)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+    if (ps.loss_delta > 0.f) sq = (double)robust_apply<T>(ps.loss(), r, Jc, Jp);
     else sq = (double)r[0] * r[0] + (double)r[1] * r[1];
     double* d = s_red + threadIdx.x * 9;
     d[0] = (double)Jp[0][0] * Jp[0][0] + (double)Jp[1][0] * Jp[1][0];
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(256) void k_linearize_cams(
       const T ww = w_cm ? w_cm[o] : (T)1;
       T r[2], Jc[2][NCP], Jp[2][3];
       obs_resjac<T>(s_cam, ptsT[3 * (size_t)p], ptsT[3 * (size_t)p + 1], ptsT[3 * (size_t)p + 2], m.x, m.y, ww, r, Jc, Jp);
-      if (ps.loss_delta > 0.f) (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+      if (ps.loss_delta > 0.f) (void)robust_apply<T>(ps.loss(), r, Jc, Jp);
 #pragma unroll
       for (int k = 0; k < NCP; ++k) { row0[k] = Jc[0][k]; row1[k] = Jc[1][k]; }
       row0[NCP] = r[0]; row1[NCP] = r[1];
@@ -998,7 +1000,7 @@ __device__ __forceinline__ void schur_emit_block(T* __restrict__ pan, int q, int
 template <typename T, bool DIAG>
 __device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict__ panelB, T* __restrict__ s_z,
                                            const T* __restrict__ s_cam, int camA0, int nA, int camB0, int nB, int dense,
-                                           int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f, T loss_delta = (T)0) {
+                                           int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f, RLoss<T> loss = RLoss<T>{}) {
   const bool inA = (c >= camA0 && c < camA0 + nA);
   const bool inB = !DIAG && (c >= camB0 && c < camB0 + nB);
   if (!inA && !inB) return;
@@ -1008,7 +1010,7 @@ __device__ __forceinline__ void schur_emit(T* __restrict__ panelA, T* __restrict
   if (f[9] != (T)0) {
     const T* cp = s_cam + (inA ? (c - camA0) : (GROUP_CAMS + c - camB0)) * CAMPRE;
     obs_resjac<T>(cp, X0, X1, X2, ux, uy, ww, r, Jc, Jp);
-    if (loss_delta > (T)0) (void)robust_apply<T>(loss_delta, r, Jc, Jp);
+    if (loss.delta > (T)0) (void)robust_apply<T>(loss, r, Jc, Jp);
   }
   schur_emit_block<T>(pan, q, col0, dense, Jc, Jp, f);
   if (DIAG && f[9] != (T)0) { s_z[3 * q + 0] = f[6]; s_z[3 * q + 1] = f[7]; s_z[3 * q + 2] = f[8]; }   // same 3 values from every observation of the point
@@ -1108,7 +1110,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(
             if (rowi >= 3 * (p1 - p0)) buf[i] = (T)0;
           }
         auto emit = [&](int c, int q, T ux, T uy, T ww, T X0, T X1, T X2, const T* f) {
-          schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, c, q, ux, uy, ww, X0, X1, X2, f, (T)ps.loss_delta);
+          schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, c, q, ux, uy, ww, X0, X1, X2, f, ps.loss());
         };
         if (piped) {
           // <= 16 points x 16 cameras = 256 observations = one per producer lane; operands of the NEXT chunk were
@@ -1340,7 +1342,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
 #pragma unroll
       for (int d = 0; d < 3; ++d) { Jp[0][d] = 0; Jp[1][d] = 0; }
       if (valid) obs_resjac<T>(s_cam + lc * CAMPRE, X0, X1, X2, m.x, m.y, ww, r, Jc, Jp);
-      if (ps.loss_delta > 0.f) l_sq += (double)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+      if (ps.loss_delta > 0.f) l_sq += (double)robust_apply<T>(ps.loss(), r, Jc, Jp);
       else l_sq += (double)r[0] * r[0] + (double)r[1] * r[1];
       double v6[6], g3[3];
       v6[0] = row16_sum((double)(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]));
@@ -1384,7 +1386,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
     } else if (piped) {
       if (cur_valid)
         schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, cur_c, cur_p - p0, cur_uv.x, cur_uv.y, cur_w,
-                            cur_X[0], cur_X[1], cur_X[2], cur_f, (T)ps.loss_delta);
+                            cur_X[0], cur_X[1], cur_X[2], cur_f, ps.loss());
       cur_valid = n1_valid; cur_c = n1_c; cur_p = n1_p; cur_uv = n1_uv; cur_w = n1_w;
       load_point();
       load_idx(it + 2, n1_valid, n1_c, n1_p, n1_uv, n1_w);
@@ -1408,7 +1410,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
             for (int k = 0; k < PF; ++k) f[k] = pf[(size_t)pp * PF + k];
             const auto mm = uv[o];
             schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, g * GROUP_CAMS + cl, q, mm.x, mm.y, w ? w[o] : (T)1,
-                                ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f, (T)ps.loss_delta);
+                                ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f, ps.loss());
           }
         }
       }
@@ -1423,7 +1425,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_sym(
         for (int k = 0; k < PF; ++k) f[k] = pf[(size_t)pp * PF + k];
         const auto m = uv[o];
         schur_emit<T, DIAG>(panelA, panelB, s_z, s_cam, camA0, nA, camB0, nB, dense, c, pp - p0, m.x, m.y, w ? w[o] : (T)1,
-                            ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f, (T)ps.loss_delta);
+                            ptsT[3 * (size_t)pp], ptsT[3 * (size_t)pp + 1], ptsT[3 * (size_t)pp + 2], f, ps.loss());
       }
     }
     const bool stamp = dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && it < 20 && threadIdx.x == 0;
@@ -1604,7 +1606,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused(
         // harmless depth: no branch, no zero-initialised outputs
         T r[2], Jc[2][NCP], Jp[2][3];
         obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
-        sq += robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+        sq += robust_apply<T>(ps.loss(), r, Jc, Jp);
         // per-point blocks: V (6) and g_p (3), summed over the 16 cameras of the DPP row
         T v6[6], g3[3];
         v6[0] = row16_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
@@ -1922,7 +1924,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
         request(it + 1);
         T r[2], Jc[2][NCP], Jp[2][3];
         obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
-        sq += robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+        sq += robust_apply<T>(ps.loss(), r, Jc, Jp);
         T v6[6], g3[3];
         v6[0] = row16_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
         v6[1] = row16_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);
@@ -2254,7 +2256,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
         request(it + 1);
         T r[2], Jc[2][NCP], Jp[2][3];
         obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
-        (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+        (void)robust_apply<T>(ps.loss(), r, Jc, Jp);
         // Ytilde = Jc^T (Jp L^-T) (all zero for a degenerate or fixed point: its factor row is zero), its three bf16 pieces
         // into the planes, and the right-hand side  b_c += Ytilde z
         T Jt[2][3];
@@ -2493,7 +2495,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_offdiag_bf3(
         request(it + 1);
         T r[2], Jc[2][NCP], Jp[2][3];
         obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
-        (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+        (void)robust_apply<T>(ps.loss(), r, Jc, Jp);
         T Jt[2][3];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {

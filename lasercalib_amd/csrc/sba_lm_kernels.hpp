@@ -361,11 +361,10 @@ __global__ void k_nocam_step(LMState* __restrict__ st, const double* __restrict_
   }
 }
 
-// ------------------------------------------------------------------ large camera systems (n_sys > 176): library factorisation
-// For more than 16 cameras the reduced system no longer fits the single-workgroup LDS Cholesky; the dense
-// factor/solve is then a plain library call (rocSOLVER potrf/potrs on the engine's stream) bracketed by these
-// two kernels, which keep the LM-specific parts on our side: Marquardt scaling + damping before, step, trial
-// cameras and the step's scalars after.
+// ------------------------------------------------------------------ large camera systems: prepare / epilogue around a separate factorisation
+// Systems that do not go through one of the all-in-one kernels (k_cholesky_blocked up to 176 unknowns, k_cholesky_ll up to 256)
+// are factored by k_cholesky_stream or the multi-workgroup kernels of sba_chol_big.hpp, bracketed by these two kernels, which
+// keep the LM-specific parts: Marquardt scaling + damping before; step, trial cameras and the step's scalars after.
 __global__ void k_chol_prepare(double* __restrict__ E, int n, LMState* __restrict__ st, double* __restrict__ D2c,
                                double* __restrict__ sol /* [n] rhs in, solution out */) {
   if (st->status >= 0) return;
@@ -486,7 +485,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
       T r[2], Jc[2][NCP], Jp[2][3];
       obs_resjac<T>(s_cam + my_c * CAMPRE, ptsT[3 * (size_t)my_p], ptsT[3 * (size_t)my_p + 1],
                     ptsT[3 * (size_t)my_p + 2], my_uv.x, my_uv.y, my_w, r, Jc, Jp);
-      if (ps.loss_delta > 0.f) (void)robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+      if (ps.loss_delta > 0.f) (void)robust_apply<T>(ps.loss(), r, Jc, Jp);
       T s0 = 0, s1 = 0;
 #pragma unroll
       for (int e = 0; e < NCP; ++e) { s0 += Jc[0][e] * s_dc[my_c * NCP + e]; s1 += Jc[1][e] * s_dc[my_c * NCP + e]; }
@@ -537,7 +536,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_trial(
     T u, v;
     obs_project<T>(s_camn + my_c * CAMPRE, (T)s_xn[q * 3], (T)s_xn[q * 3 + 1], (T)s_xn[q * 3 + 2], u, v);
     const T r0 = my_w * (u - my_uv.x), r1 = my_w * (v - my_uv.y);
-    sq = (ps.loss_delta > 0.f) ? (double)robust_cost<T>((T)ps.loss_delta, r0, r1) : (double)r0 * r0 + (double)r1 * r1;
+    sq = (ps.loss_delta > 0.f) ? (double)robust_cost<T>(ps.loss(), r0, r1) : (double)r0 * r0 + (double)r1 * r1;
   }
   const double c_new = block_sum(sq, s_scr);
   const double b_pred = block_sum(pred, s_scr);
@@ -652,7 +651,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
       // W^T dc of this observation = Jp^T (Jc dc): the point block and the directional derivative along the camera step
       T r[2], Jp[2][3], sj[2];
       obs_jp_jvp<T>(cp, ptsT[pp * 3], ptsT[pp * 3 + 1], ptsT[pp * 3 + 2], m.x, m.y, ww, dc, r, Jp, sj);
-      if (ps.loss_delta > 0.f) robust_apply_jvp<T>((T)ps.loss_delta, r, Jp, sj);
+      if (ps.loss_delta > 0.f) robust_apply_jvp<T>(ps.loss(), r, Jp, sj);
       t0 = Jp[0][0] * sj[0] + Jp[1][0] * sj[1];
       t1 = Jp[0][1] * sj[0] + Jp[1][1] * sj[1];
       t2 = Jp[0][2] * sj[0] + Jp[1][2] * sj[1];
@@ -680,7 +679,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
       T u, v;
       obs_project<T>(cpn, (T)n0, (T)n1, (T)n2, u, v);
       const T r0 = ww * (u - m.x), r1 = ww * (v - m.y);
-      sq += (ps.loss_delta > 0.f) ? (double)robust_cost<T>((T)ps.loss_delta, r0, r1) : (double)r0 * r0 + (double)r1 * r1;
+      sq += (ps.loss_delta > 0.f) ? (double)robust_cost<T>(ps.loss(), r0, r1) : (double)r0 * r0 + (double)r1 * r1;
     }
   }
   const double c_new = block_sum(sq, s_scr);

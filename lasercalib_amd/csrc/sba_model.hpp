@@ -270,22 +270,43 @@ __device__ inline void obs_jp_jvp(const T* __restrict__ cp, T X0, T X1, T X2, T 
   }
 }
 
-// ------------------------------------------------------------------ robust loss (opt-in; the objective of scipy least_squares(loss='huber', f_scale=delta))
-// The loss applies to every residual component f: z = (f/delta)^2, rho(z) = z (z <= 1) or 2 sqrt(z) - 1, cost =
-// 0.5 delta^2 sum rho.  Its gradient is J^T (rho' f).  For the Gauss-Newton model the rows of J and f are both scaled by
+// ------------------------------------------------------------------ robust loss (opt-in; the objective of scipy least_squares(loss=..., f_scale=delta))
+// The loss applies to every residual component f: z = (f/delta)^2, cost = 0.5 delta^2 sum rho(z) with scipy's rho
+// (scipy/optimize/_lsq/least_squares.py:189-226):
+//   huber    rho = z (z <= 1), 2 sqrt(z) - 1 beyond          rho' = 1, z^-1/2
+//   soft_l1  rho = 2 (sqrt(1 + z) - 1)                       rho' = (1 + z)^-1/2
+//   cauchy   rho = ln(1 + z)                                 rho' = 1 / (1 + z)
+// Its gradient is J^T (rho' f).  For the Gauss-Newton model the rows of J and f are both scaled by
 // sqrt(rho') -- iteratively re-weighted least squares: J_s^T f_s = J^T rho' f is the exact gradient and J_s^T J_s = J^T rho' J
 // stays positive -- applied right after the residual/Jacobian blocks, so that every kernel downstream (normal-equation
 // blocks, Schur complement, step) is robust without knowing about it; only the cost sums take rho instead of f^2.
 // scipy scales rows by sqrt(max(rho' + 2 rho'' z, EPS)) instead (common.py, scale_for_robust_loss_function), which for Huber
-// is sqrt(EPS) for EVERY row beyond f_scale: the model loses all curvature there and only the trust region bounds the step
-// (12 719 evaluations on the 6 x 300 test rig); with multiplicative Levenberg-Marquardt damping that is unusable (a point
-// whose observations all start beyond f_scale has a zero 3x3 block).  Same objective, same stationary points, different
-// quadratic model -- the Ceres choice when rho' + 2 rho'' z <= 0.
+// is sqrt(EPS) for EVERY row beyond f_scale (and for Cauchy for every row with z > 1): the model loses all curvature there and
+// only the trust region bounds the step (12 719 evaluations on the 6 x 300 test rig); with multiplicative Levenberg-Marquardt
+// damping that is unusable (a point whose observations all start beyond f_scale has a zero 3x3 block).  Same objective, same
+// stationary points, different quadratic model -- the Ceres choice when rho' + 2 rho'' z <= 0.
 // delta <= 0: linear loss, nothing happens (one uniform branch).
+__device__ inline double log1p_t(double x) { return log1p(x); }
+__device__ inline float log1p_t(float x) { return log1pf(x); }
+constexpr int LOSS_HUBER = 1, LOSS_SOFT_L1 = 2, LOSS_CAUCHY = 3;          // = sba_loss (include/sba_hip.h)
+template <typename T> struct RLoss { T delta = (T)0; int kind = 0; };
 template <typename T>
-__device__ __forceinline__ T robust_component(T delta, T& f, T& jscale) {       // returns delta^2 rho(z) (= f^2 when z <= 1)
+__device__ __forceinline__ T robust_component(RLoss<T> L, T& f, T& jscale) {       // returns delta^2 rho(z) (= f^2 when nothing is scaled)
+  const T delta = L.delta;
   const T z = (f / delta) * (f / delta);
   jscale = (T)1;
+  if (L.kind == LOSS_SOFT_L1) {                        // (uniform branch: the kind is a kernel argument)
+    const T s1 = sqrt((T)1 + z);
+    jscale = sqrt((T)1 / s1);
+    f = f * jscale;
+    return delta * delta * (T)2 * (z / (s1 + (T)1));   // 2 (sqrt(1 + z) - 1) without the cancellation at small z
+  }
+  if (L.kind == LOSS_CAUCHY) {
+    const T cost = delta * delta * log1p_t(z);
+    jscale = sqrt((T)1 / ((T)1 + z));
+    f = f * jscale;
+    return cost;
+  }
   if (z <= (T)1) return f * f;
   const T sz = sqrt(z);                                  // |f| / delta;  rho'(z) = 1 / sz
   jscale = sqrt((T)1 / sz);
@@ -295,20 +316,20 @@ __device__ __forceinline__ T robust_component(T delta, T& f, T& jscale) {       
 }
 // residual only (trial points, sba_residual): delta^2 (rho(z0) + rho(z1)), or r0^2 + r1^2 for the linear loss
 template <typename T>
-__device__ __forceinline__ T robust_cost(T delta, T r0, T r1) {
-  if (!(delta > (T)0)) return r0 * r0 + r1 * r1;
+__device__ __forceinline__ T robust_cost(RLoss<T> L, T r0, T r1) {
+  if (!(L.delta > (T)0)) return r0 * r0 + r1 * r1;
   T js;
-  return robust_component<T>(delta, r0, js) + robust_component<T>(delta, r1, js);
+  return robust_component<T>(L, r0, js) + robust_component<T>(L, r1, js);
 }
 // residual + Jacobian blocks: scale in place, return the cost term
 template <typename T>
-__device__ __forceinline__ T robust_apply(T delta, T r[2], T Jc[2][NCP], T Jp[2][3]) {
-  if (!(delta > (T)0)) return r[0] * r[0] + r[1] * r[1];
+__device__ __forceinline__ T robust_apply(RLoss<T> L, T r[2], T Jc[2][NCP], T Jp[2][3]) {
+  if (!(L.delta > (T)0)) return r[0] * r[0] + r[1] * r[1];
   T cost = 0;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     T js;
-    cost += robust_component<T>(delta, r[k], js);
+    cost += robust_component<T>(L, r[k], js);
     if (js != (T)1) {
 #pragma unroll
       for (int e = 0; e < NCP; ++e) Jc[k][e] *= js;
@@ -321,12 +342,12 @@ __device__ __forceinline__ T robust_apply(T delta, T r[2], T Jc[2][NCP], T Jp[2]
 
 // the same for (r, Jp, s = Jc dc): the rows of Jc are scaled like the residual, so s is
 template <typename T>
-__device__ __forceinline__ void robust_apply_jvp(T delta, T r[2], T Jp[2][3], T s[2]) {
-  if (!(delta > (T)0)) return;
+__device__ __forceinline__ void robust_apply_jvp(RLoss<T> L, T r[2], T Jp[2][3], T s[2]) {
+  if (!(L.delta > (T)0)) return;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     T js;
-    (void)robust_component<T>(delta, r[k], js);
+    (void)robust_component<T>(L, r[k], js);
     if (js != (T)1) {
       s[k] *= js;
 #pragma unroll

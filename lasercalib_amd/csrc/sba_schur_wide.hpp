@@ -231,7 +231,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_wide(
         request(it + 1);
         T r[2], Jc[2][NCP], Jp[2][3];
         obs_resjac<T>(cp_safe, X0, X1, X2, m.x, m.y, valid ? ww : (T)0, r, Jc, Jp, valid);
-        sq += robust_apply<T>((T)ps.loss_delta, r, Jc, Jp);
+        sq += robust_apply<T>(ps.loss(), r, Jc, Jp);
         T v6[6], g3[3];
         v6[0] = point_sum(Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0]);
         v6[1] = point_sum(Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1]);

@@ -219,6 +219,18 @@ class HipEngine:
         self.prob.close()
 
 
+def _bounded_barrier(d, seconds=60.0):
+    """Barrier that gives up: gloo has monitored_barrier(timeout); other backends get a plain barrier.  Never raises."""
+    import datetime
+    try:
+        if d.get_backend() == "gloo":
+            d.monitored_barrier(timeout=datetime.timedelta(seconds=seconds))
+        else:
+            d.barrier()
+    except Exception:      # noqa: BLE001  (a peer is gone: nothing left to protect)
+        pass
+
+
 def raise_everywhere(comm, local_error):
     """A failure on ANY rank (e.g. a non-finite initial cost in one shard) becomes the same ValueError on ALL ranks, so
     nobody walks into a collective its peers will never join.  local_error: message or None."""
@@ -326,9 +338,12 @@ def solve_sharded(sba, mode, ftol, xtol, gtol, max_nfev, verbose, dtype, device,
             if bad is not None:
                 raise bad
             fvec_loc, _ = prob.residual()
-            if mode_comm == "ipc":
-                comm.d.barrier()          # nobody unmaps or frees an area a peer's last kernels may still be reading
         finally:
+            if mode_comm == "ipc":
+                # nobody unmaps or frees an area a peer's last kernels may still be reading -- on the failure paths too (a rank
+                # that raised would otherwise free memory a slower peer is still spinning on in k_ipc_gate); best effort and
+                # bounded, because a peer that died will never arrive
+                _bounded_barrier(comm.d)
             prob.close()
         status, cost, opt, cost0 = rep.status, rep.cost, rep.optimality, rep.initial_cost     # whole-job figures already
         parts = comm.all_gather_var((shard["p0"], pts_loc, shard["obs_index"], fvec_loc))

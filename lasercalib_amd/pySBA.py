@@ -18,7 +18,7 @@ Environment knobs (the script itself stays unchanged):
   LASERCALIB_SBA_USE_FIXED 1: honour ``points3Dfixed`` (a boolean mask over the 3-D points, or an array of point indices) as gauge
                          anchors: those points keep their coordinates and drop out of the unknowns.  Default 0: stored and
                          ignored, exactly like the reference (pySBA.py:28,55).
-  LASERCALIB_SBA_LOSS    linear (default, the reference's) | huber, with LASERCALIB_SBA_F_SCALE (default 1.0 px): scipy's
+  LASERCALIB_SBA_LOSS    linear (default, the reference's) | huber | soft_l1 | cauchy, with LASERCALIB_SBA_F_SCALE (default 1.0 px): scipy's
                          ``least_squares(loss=, f_scale=)`` semantics for bundleAdjust / _nocam / _sharedcam.
   LASERCALIB_SBA_SHARD   1: with a torch.distributed process group up, bundleAdjust / _nocam / _sharedcam shard the points
                          over the ranks (every rank calls with the same full problem).  Default 0: never implicit.
@@ -71,43 +71,71 @@ class SBAResult(OptimizeResult):
     scipy returns the final residual vector and the final Jacobian -- a (2M x n) CSR matrix (least_squares.py:950-961), 22.4M
     non-zeros at 800k observations -- with every result; the reference's caller never reads either (scripts/calibrate_camera.py:71
     discards the result).  The residual read-back alone was 0.6 ms of the 2.7 ms a ``bundleAdjust`` call takes at 16 x 50k
-    (tools/wall_pysba.py), so both are materialised by the device kernels when somebody asks: attribute or item access, ``in``,
-    iteration over the keys, ``repr`` and pickling all see a complete result.
+    (tools/wall_pysba.py), so both are materialised by the device kernels when somebody asks.  The closures that do it live
+    OUTSIDE the mapping (instance attributes), so the dict protocol stays consistent: ``'fun' in res``, ``'jac' in res`` and
+    ``'grad' in res`` are true while they can be made, ``res.get(k)`` / ``res[k]`` / ``res.k`` make them, ``len`` / ``keys`` / ``items`` /
+    ``copy`` / ``repr`` / pickling see a complete result (fun; jac and grad only once somebody has asked for them -- they are
+    large) and never the closures.  Should the device be gone by then (a worker process without the GPU unpickles nothing lazy:
+    pickling materialises ``fun`` first), the key is simply absent: KeyError / AttributeError, as for any missing key.
     """
+    _LAZY = ("fun", "jac", "grad")
+
+    def _maker(self, name):
+        return self.__dict__.get(name)
+
+    def set_makers(self, fun_maker=None, jac_maker=None):
+        object.__setattr__(self, "_fun_maker", fun_maker)
+        object.__setattr__(self, "_jac_maker", jac_maker)
 
     def __missing__(self, key):
-        if key == "fun":
-            maker = dict.get(self, "_fun_maker")
-            if maker is None:
-                raise KeyError(key)
-            dict.__setitem__(self, "fun", maker())
-            return dict.__getitem__(self, "fun")
-        if key in ("jac", "grad"):
-            maker = dict.get(self, "_jac_maker")
-            if maker is None:
-                raise KeyError(key)
-            J = maker()
-            dict.__setitem__(self, "jac", J)
-            dict.__setitem__(self, "grad", J.T.dot(self["fun"]))
-            return dict.__getitem__(self, key)
+        try:
+            if key == "fun" and self._maker("_fun_maker") is not None:
+                dict.__setitem__(self, "fun", self._maker("_fun_maker")())
+                return dict.__getitem__(self, "fun")
+            if key in ("jac", "grad") and self._maker("_jac_maker") is not None:
+                J = self._maker("_jac_maker")()
+                fvec = self["fun"]
+                dict.__setitem__(self, "jac", J)
+                dict.__setitem__(self, "grad", J.T.dot(fvec))
+                return dict.__getitem__(self, key)
+        except (_native.SbaError, OSError) as e:      # no device (any more): the lazy key does not exist
+            raise KeyError(key) from e
         raise KeyError(key)
 
     def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
         try:
             return self[name]
         except KeyError as e:
             raise AttributeError(name) from e
 
+    def _can_make(self, key):
+        if key == "fun":
+            return self._maker("_fun_maker") is not None
+        if key in ("jac", "grad"):
+            return self._maker("_jac_maker") is not None and (dict.__contains__(self, "fun") or self._maker("_fun_maker") is not None)
+        return False
+
     def __contains__(self, key):
-        return dict.__contains__(self, key) or (key == "fun" and dict.get(self, "_fun_maker") is not None)
+        return dict.__contains__(self, key) or self._can_make(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
 
     def _materialise(self):
-        if not dict.__contains__(self, "fun") and dict.get(self, "_fun_maker") is not None:
-            self["fun"]
+        if not dict.__contains__(self, "fun") and self._maker("_fun_maker") is not None:
+            try:
+                self["fun"]
+            except KeyError:
+                pass
 
     def keys(self):
         self._materialise()
-        return [k for k in dict.keys(self) if not k.startswith("_")]
+        return list(dict.keys(self))
 
     def items(self):
         return [(k, dict.__getitem__(self, k)) for k in self.keys()]
@@ -118,10 +146,17 @@ class SBAResult(OptimizeResult):
     def __iter__(self):
         return iter(self.keys())
 
+    def __len__(self):
+        return len(self.keys())
+
+    def copy(self):
+        """A plain, complete OptimizeResult (no closures)."""
+        return OptimizeResult(self.items())
+
     def __repr__(self):
         return repr(OptimizeResult(self.items()))
 
-    def __reduce__(self):   # drop the closures when pickled; the residual vector goes along
+    def __reduce__(self):   # the closures never travel; the residual vector goes along
         return (OptimizeResult, (dict(self.items()),))
 
 
@@ -267,7 +302,7 @@ class PySBA:
         if first is not None:          # one report over both stages: counts add up, the table runs on
             rep1, log1 = first
             for row in log:
-                row.iteration += len(log1)
+                row.iteration += rep1.iterations       # (not len(log1): the device log is capped at LOG_CAP rows)
                 row.nfev += rep1.nfev - 1
             rep.initial_cost = rep1.initial_cost
             rep.nfev += rep1.nfev - 1          # (the fp64 stage's first evaluation is the fp32 stage's last point)
@@ -306,9 +341,7 @@ class PySBA:
                         status=int(rep.status), message=message, success=rep.status > 0)
         if fvec is not None:
             dict.__setitem__(res, "fun", fvec)
-        else:
-            dict.__setitem__(res, "_fun_maker", make_fun)
-        dict.__setitem__(res, "_jac_maker", make_jac)
+        res.set_makers(None if fvec is not None else make_fun, make_jac)
         return res, cams_opt, pts_opt
 
     def bundleAdjust(self, ftol=1e-4):
@@ -448,7 +481,7 @@ class PySBA:
         res = SBAResult(x=x, cost=rep.cost, fun=fvec, optimality=rep.optimality, active_mask=np.zeros_like(x),
                         nfev=int(rep.nfev), njev=int(rep.njev), status=int(rep.status), message=message,
                         success=rep.status > 0)
-        dict.__setitem__(res, "_jac_maker", make_jac)
+        res.set_makers(None, make_jac)
         return res, cams_opt, pts_opt
 
     def bundle_adjustment_camonly(self, ftol=1e-4):

@@ -106,8 +106,13 @@ def make_rig(n_cams, n_points, seed=0, visibility=1.0, noise_px=0.3,
     point_ind = point_ind.astype(np.int64)
     camera_ind = camera_ind.astype(np.int64)
 
-    uv = _project_np(pts[point_ind], cams[camera_ind])
-    uv = uv + rng.normal(0.0, noise_px, uv.shape)
+    # (projected in blocks of observations: the gathered (M, 3) / (M, 13) operands of one call would be 16 GB at config 5's
+    #  128 M observations; the values and the random stream are those of the single call)
+    uv = np.empty((point_ind.size, 2))
+    blk = 1 << 22
+    for o in range(0, point_ind.size, blk):
+        uv[o:o + blk] = _project_np(pts[point_ind[o:o + blk]], cams[camera_ind[o:o + blk]])
+    uv += rng.normal(0.0, noise_px, uv.shape)
 
     cams0 = cams.copy()
     pts0 = pts.copy()

@@ -102,6 +102,65 @@ def test_huber_loss_matches_scipy(C, N, vis, dtype):
     assert rms <= 0.6 and rms < np.sqrt(np.mean(np.sum(rl[inl] ** 2, axis=1)))      # 0.3 px noise per axis: 0.42 without outliers
 
 
+_RHO = {"huber": lambda z: np.where(z <= 1, z, 2 * np.sqrt(z) - 1), "soft_l1": lambda z: 2 * (np.sqrt(1 + z) - 1), "cauchy": lambda z: np.log1p(z)}
+_ROBUST_REF = {}
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("loss", ["soft_l1", "cauchy"])
+@pytest.mark.parametrize("C,N,vis", [(6, 300, 0.8), (17, 200, 0.7)])
+def test_soft_l1_and_cauchy_losses_match_scipy(C, N, vis, loss, dtype):
+    """scipy's other two smooth robust losses (least_squares.py:189-226: soft_l1 rho = 2 (sqrt(1 + z) - 1), cauchy rho = ln(1 + z)),
+    same IRLS row scaling as Huber.  soft_l1 keeps positive curvature in scipy's own model too, so scipy converges and the
+    comparison is two-sided; Cauchy's Triggs factor is clipped for every row with z > 1 (the Huber situation): one-sided plus the
+    restart check."""
+    rig = make_rig(C, N, seed=43, visibility=vis, min_cams_per_point=3)
+    rng = np.random.default_rng(5)
+    uv = rig["points_2d"].copy()
+    bad = rng.random(uv.shape[0]) < 0.03
+    uv[bad] += rng.normal(0, 40.0, (int(bad.sum()), 2))
+    args = (uv, rig["camera_ind"], rig["point_ind"])
+    f_scale = 1.5
+    key = (C, N, vis, loss)
+    if key not in _ROBUST_REF:
+        _ROBUST_REF[key] = orc.bundle_adjust_ext(rig["cams0"], rig["pts0"], *args, loss=loss, f_scale=f_scale, ftol=1e-9, max_nfev=300)
+    ref, _, _ = _ROBUST_REF[key]
+    with _native.Problem(rig["cams0"], rig["pts0"], *args, dtype=dtype) as prob:
+        prob.set_robust_loss(loss, f_scale)
+        r0, c0 = prob.residual()
+        cams, pts, rep, log = prob.solve_lm(prob.make_opts(ftol=1e-10 if dtype == "f64" else 1e-6))
+        r1, c1 = prob.residual(np.hstack((cams.ravel(), pts.ravel())))
+    rho = _RHO[loss]
+    tol_c = 1e-9 if dtype == "f64" else 2e-5
+    assert abs(c0 - 0.5 * f_scale ** 2 * np.sum(rho((r0 / f_scale) ** 2))) <= tol_c * c0          # the cost IS scipy's definition
+    assert abs(c1 - 0.5 * f_scale ** 2 * np.sum(rho((r1 / f_scale) ** 2))) <= tol_c * c1
+    assert rep.status in (2, 3, 4) and abs(c1 - rep.cost) <= (1e-9 if dtype == "f64" else 1e-4) * c1
+    tol = 1e-6 if dtype == "f64" else 1e-4
+    assert rep.cost <= ref.cost * (1 + tol)
+    if loss == "soft_l1" and ref.status > 0:
+        assert rep.cost >= ref.cost * (1 - 10 * tol)           # both converged: the same minimum
+    again, _, _ = orc.bundle_adjust_ext(cams, pts, *args, loss=loss, f_scale=f_scale, ftol=1e-9, max_nfev=20)
+    assert again.cost >= rep.cost * (1 - 100 * tol)
+    # the outliers are down-weighted: the inliers fit better than under the linear loss (a loss with linear tails still lets a
+    # 40 px outlier drag a point seen by three cameras, so no absolute bound here; Cauchy redescends and gets one)
+    inl = ~bad
+    rms = np.sqrt(np.mean(np.sum(r1.reshape(-1, 2)[inl] ** 2, axis=1)))
+    lin, cl, pl = orc.bundle_adjust(rig["cams0"], rig["pts0"], *args, ftol=1e-6)
+    rl = orc.fun(np.hstack((cl.ravel(), pl.ravel())), C, N, args[1], args[2], uv, 1.0).reshape(-1, 2)
+    assert rms < np.sqrt(np.mean(np.sum(rl[inl] ** 2, axis=1)))
+    if loss == "cauchy":
+        assert rms <= 1.0
+
+
+def test_unknown_loss_is_refused():
+    rig = make_rig(4, 50, seed=1)
+    with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"]) as prob:
+        with pytest.raises(ValueError):
+            prob.set_robust_loss("arctan", 1.0)
+        with pytest.raises(_native.SbaError):
+            prob.set_robust_loss("cauchy", 0.0)
+
+
 def test_pysba_env_knobs_and_default_off(monkeypatch, capsys):
     rig = make_rig(5, 300, seed=7, visibility=0.8)
     fixed_idx = np.array([3, 50, 120, 200, 280])

@@ -101,6 +101,16 @@ def test_indefinite_big_system_is_a_rejected_step_not_a_crash():
 def test_per_gpu_shares_of_configs_4_and_5(C, N, tangential):
     """fp32, full visibility: one GPU's share of BASELINE config 4 (64 x 200k / 8) and of config 5 (128 x 1M / 8) with the
     reference's radial model and with the radial + tangential model config 5 names (13 parameters: 1664 camera unknowns)."""
+    _size_independent_properties(C, N, tangential)
+
+
+def test_config_4_at_full_size_on_one_gpu():
+    """BASELINE config 4 as stated -- 64 cameras x 200,000 points = 12.8 M observations -- unsharded on ONE GPU in fp32 (the
+    sharded form runs in tests/test_gpu_multirank.py at small N): same size-independent properties as the per-GPU shares."""
+    _size_independent_properties(64, 200000, False)
+
+
+def _size_independent_properties(C, N, tangential):
     from oracle import sba_oracle_tangential as orc13
     rig = make_rig(C, N, seed=0, tangential=tangential)
     M = rig["camera_ind"].size

@@ -124,3 +124,45 @@ def test_shard_handles_unsorted_observations():
         got[sh["obs_index"]] += 1
         assert np.array_equal(sh["uv"], uv[sh["obs_index"]])
     assert np.all(got == 1)
+
+
+def test_lazy_result_is_a_consistent_mapping():
+    """SBAResult (the OptimizeResult bundleAdjust returns): fun / jac / grad are made on first access, and the mapping protocol
+    never shows the closures that make them (get / in / len / keys / copy / pickle agree with each other)."""
+    import pickle
+    from scipy.sparse import csr_matrix
+    from lasercalib_amd.pySBA import SBAResult
+    calls = {"fun": 0, "jac": 0}
+
+    def mk_fun():
+        calls["fun"] += 1
+        return np.arange(4.0)
+
+    def mk_jac():
+        calls["jac"] += 1
+        return csr_matrix(np.eye(4))
+
+    res = SBAResult(x=np.zeros(3), cost=1.0, status=2)
+    res.set_makers(mk_fun, mk_jac)
+    assert "fun" in res and "jac" in res and "grad" in res and "nope" not in res
+    assert calls == {"fun": 0, "jac": 0}                          # membership alone makes nothing
+    assert np.array_equal(res.get("fun"), np.arange(4.0)) and calls["fun"] == 1
+    assert res.get("nope", 7) == 7
+    assert set(res.keys()) == {"x", "cost", "status", "fun"} and len(res) == 4 and len(res.copy()) == 4
+    assert not any(k.startswith("_") for k in res)
+    assert np.array_equal(res.grad, np.arange(4.0)) and calls == {"fun": 1, "jac": 1}
+    assert set(res.keys()) == {"x", "cost", "status", "fun", "jac", "grad"}
+    back = pickle.loads(pickle.dumps(res))
+    assert set(back.keys()) == set(res.keys()) and np.array_equal(back["fun"], res["fun"])
+    with pytest.raises(AttributeError):
+        res.nope
+    # a result whose device is gone: the lazy key is simply absent
+    from lasercalib_amd import _native
+
+    def broken():
+        raise _native.SbaError("no device")
+    res2 = SBAResult(x=np.zeros(3))
+    res2.set_makers(broken, None)
+    assert res2.get("fun") is None and "jac" not in res2 and list(res2.keys()) == ["x"]
+    with pytest.raises(KeyError):
+        res2["fun"]
