@@ -102,7 +102,8 @@ typedef struct {
   int32_t iterations;      /* LM trial steps taken (accepted + rejected)        */
   int32_t accepted;        /* accepted steps                                    */
   int32_t status;          /* 0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 ftol+xtol (scipy codes) */
-  int32_t reserved;
+  int32_t reserved;        /* diagnostic: reduced camera systems the fp32 engine had to factor a second time in f64
+                              (its f32-lane Cholesky refused them: non-positive or vanishing pivot); 0 for the fp64 engine */
   double  seconds_total;   /* wall time inside sba_solve_lm                     */
   double  seconds_device;  /* HIP-event time of the iteration loop              */
 } sba_lm_report;

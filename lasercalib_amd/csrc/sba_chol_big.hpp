@@ -272,4 +272,85 @@ __global__ __launch_bounds__(256) void k_chol_big_back(const double* __restrict_
   if (part == 0) yv[t * BB + i] -= (s_p[0][i] + s_p[1][i]) + (s_p[2][i] + s_p[3][i]);
 }
 
+// ------------------------------------------------------------------ back substitution in ONE launch (round 4)
+// The per-block launches above cost ~10 us each for a 64 x 64 matrix-vector product (launch + three dependent round trips to memory):
+// 11 of them at n = 704, 26 at n = 1664.  Here block row t is ONE workgroup for the whole substitution,
+//     y_t -= L(b,t)^T x_b   for b = last .. t + 1, as the x_b arrive;      x_t = Minv_t^T y_t,   published with a flag,
+// so the chain through the blocks is a flag hand-over between resident workgroups (at most 26 of them) instead of a launch
+// boundary: the L(b,t) block a workgroup needs next is already in its registers when x_b arrives.  The waits are bounded
+// (CHOLBIG_WAIT_TICKS of the 100 MHz clock, then the solve is flagged as failed: a rejected LM step) and every workgroup of
+// the launch is resident at once -- the rule of sba_ipc.hpp.  Flags carry the launch's epoch, so they are never reset.
+constexpr long long CHOLBIG_WAIT_TICKS = 200000000LL;      // 2 s
+__global__ __launch_bounds__(256) void k_chol_big_back_all(const double* __restrict__ W, int npad, int n, const double* __restrict__ Ld_ws,
+                                                           const double* __restrict__ Minv_ws, double* __restrict__ xv /* [npad] */,
+                                                           unsigned* __restrict__ flags /* [block rows] */, unsigned epoch,
+                                                           double* __restrict__ sol, int* __restrict__ info, const LMState* __restrict__ st) {
+  __shared__ double s_y[BB], s_x[BB], s_p[4][BB], s_M[BB * BB];
+  __shared__ int s_late;
+  if (st->status >= 0) return;                      // (the same record on every workgroup: nobody is left waiting)
+  const int nbx = (n + BB - 1) / BB;
+  const int t = blockIdx.x, i = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int R = cholbig_rhs_row(n), Rb = R / BB, Rl = R % BB;
+  // y_t = row R of the factor (columns of block t), Minv_t, and the first L block: all requested before anything is waited for
+  double yk = 0;
+  if (threadIdx.x < BB) {
+    const int k = t * BB + threadIdx.x;
+    if (k < n) yk = (t < Rb) ? W[(size_t)(t * BB + Rl) * npad + Rb * BB + threadIdx.x] : Ld_ws[(size_t)Rb * BB * BB + Rl * BB + threadIdx.x];
+  }
+  const double* Mg = Minv_ws + (size_t)t * BB * BB;
+  double mreg[BB * BB / 256];
+#pragma unroll
+  for (int u = 0; u < BB * BB / 256; ++u) mreg[u] = Mg[threadIdx.x + 256 * u];
+  double lreg[BB / 4];                               // L(b,t)[k][i], k = part + 4 u
+  auto fetch_L = [&](int b) {
+    const double* Lb = W + (size_t)(t * BB) * npad + b * BB;
+#pragma unroll
+    for (int u = 0; u < BB / 4; ++u) lreg[u] = Lb[(size_t)(part + 4 * u) * npad + i];
+  };
+  if (nbx - 1 > t) fetch_L(nbx - 1);
+  if (threadIdx.x == 0) s_late = 0;
+  if (threadIdx.x < BB) s_y[threadIdx.x] = yk;
+#pragma unroll
+  for (int u = 0; u < BB * BB / 256; ++u) s_M[threadIdx.x + 256 * u] = mreg[u];
+  __syncthreads();
+  for (int b = nbx - 1; b > t; --b) {
+    if (threadIdx.x < BB) {                          // wave 0 waits for x_b and brings it in
+      const long long t0 = wall_clock64();
+      bool late = false;
+      while (__hip_atomic_load(flags + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        if (wall_clock64() - t0 > CHOLBIG_WAIT_TICKS) { late = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (late) s_late = 1;
+      s_x[threadIdx.x] = late ? 0.0 : __builtin_nontemporal_load(xv + b * BB + threadIdx.x);
+    }
+    __syncthreads();
+    if (s_late) break;
+    double u_ = 0;
+#pragma unroll
+    for (int u = 0; u < BB / 4; ++u) u_ += lreg[u] * s_x[part + 4 * u];
+    if (b - 1 > t) fetch_L(b - 1);                   // the next block travels while this one is folded
+    s_p[part][i] = u_;
+    __syncthreads();
+    if (part == 0) s_y[i] -= (s_p[0][i] + s_p[1][i]) + (s_p[2][i] + s_p[3][i]);
+    __syncthreads();
+  }
+  if (s_late) { if (threadIdx.x == 0) atomicOr(info, 2); return; }     // (this workgroup's flag stays down: the rows above time out too)
+  // x_t = Minv_t^T y_t   (Minv is lower: entries k < i are stored zeros)
+  double s = 0;
+  for (int k = part; k < BB; k += 4) s += s_M[k * BB + i] * s_y[k];
+  s_p[part][i] = s;
+  __syncthreads();
+  if (part == 0) {
+    const double x = (s_p[0][i] + s_p[1][i]) + (s_p[2][i] + s_p[3][i]);
+    __builtin_nontemporal_store(x, xv + t * BB + i);
+    if (t * BB + i < n) sol[t * BB + i] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    __hip_atomic_store(flags + t, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace SBA_NS

@@ -173,6 +173,356 @@ __device__ __forceinline__ void chol_panel_update_diag(double* __restrict__ Pblk
   __builtin_amdgcn_wave_barrier();
 }
 
+// ------------------------------------------------------------------ the same building blocks for either scalar type
+// S = double: the kernel as it has been since round 1 (f64 VALU chain, v_mfma_f64_16x16x4).  S = float (round 4, fp32 engine only):
+// the tile factorisation on f32 lanes (v_rsq_f32 is accurate to 1 ulp: no Newton step; one v_readlane per broadcast instead of two;
+// f32 VALU instructions issue in half the cycles) and the panel / trailing products on v_mfma_f32_16x16x4_f32 (32 cycles instead of
+// 64, half the LDS bytes).  The two MFMAs place their accumulators differently (Mfma<S>::row_of), everything else is shared.
+template <typename S> struct CholNum;
+template <> struct CholNum<double> {
+  static constexpr int LD = CLD, BS = CB * LD;                 // row stride inside a 16 x 16 block: 17 doubles (conflict-free 8-byte MFMA operand reads)
+  static __device__ __forceinline__ int off(int r, int c) { return (r * (r + 1) / 2 + c) * BS; }
+  static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+  static __device__ __forceinline__ double bcast(double v, int src) { return readlane_f64(v, src); }
+  static __device__ __forceinline__ double rsq(double x) { return __builtin_amdgcn_rsq(x); }
+  static __device__ __forceinline__ double xrow(double v) { return xrow_sum(v); }
+};
+template <> struct CholNum<float> {
+  // 20 floats: operand reads (row lane & 15, k = lane >> 4) and accumulator accesses (row 4 (lane >> 4) + reg, column lane & 15) both
+  // fall on 32 different banks per half wave (17 floats: up to four lanes per bank on the accumulator pattern)
+  static constexpr int LD = 20, BS = CB * LD;
+  static __device__ __forceinline__ int off(int r, int c) { return (r * (r + 1) / 2 + c) * BS; }
+  static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+  static __device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+  static __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ float xrow(float v) {       // sum over lanes l, l^16, l^32, l^48 (see xrow_sum)
+    unsigned a0 = __float_as_uint(v), a1 = a0;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(a1));
+    const float p = __uint_as_float(a0) + __uint_as_float(a1);
+    a0 = __float_as_uint(p); a1 = a0;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(a1));
+    return __uint_as_float(a0) + __uint_as_float(a1);
+  }
+};
+
+// chol16_wave for either scalar type.  a0 (S = float): the 16 diagonal entries of the DAMPED system as they were loaded; the
+// factorisation is refused (returns false) when a pivot L_ii^2 has sunk below tau * a0_i -- at tau ~ 2^-23 the pivot is the rounding
+// noise of its own diagonal entry and the rows behind it carry no information (the caller then factors in f64).
+template <typename S, bool NEWTON>
+__device__ __forceinline__ bool chol16_wave_t(S* __restrict__ blk, const S* __restrict__ a0 = nullptr, S tau = (S)0) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15;
+  const bool ident = lane >= 16;
+  S a[CB];
+#pragma unroll
+  for (int j = 0; j < CB; ++j) { const S v = blk[i * CholNum<S>::LD + j]; a[j] = ident ? ((j == i) ? (S)1 : (S)0) : v; }
+  S dg = blk[i * CholNum<S>::LD + i];
+  __builtin_amdgcn_wave_barrier();
+  auto pivot = [](S x) -> S {
+    if constexpr (NEWTON) return (S)rsqrt_nr((double)x);
+    else return CholNum<S>::rsq(x);
+  };
+  S akk = CholNum<S>::bcast(dg, 0);
+  S piv = pivot(akk);
+  S chk = piv;
+#pragma unroll
+  for (int k = 0; k < CB; ++k) {
+    const S lik = a[k] * piv;
+    a[k] = lik;
+    if (k + 1 < CB) {
+      dg = CholNum<S>::fma(-lik, lik, dg);
+      akk = CholNum<S>::bcast(dg, k + 1);
+      piv = pivot(akk);
+      chk += piv;
+    }
+#pragma unroll
+    for (int j = k + 1; j < CB; ++j) a[j] -= lik * CholNum<S>::bcast(lik, j);
+  }
+  if (lane >= 16 && lane < 32) {
+#pragma unroll
+    for (int j = 0; j < CB; ++j) blk[i * CholNum<S>::LD + j] = a[j];     // row i of Linv^T (zero left of the diagonal)
+  }
+  bool ok = isfinite(chk) && chk > (S)0;
+  if (a0) {                                                    // pivot growth test (wave-uniform pointer)
+    __builtin_amdgcn_wave_barrier();
+    const S li = blk[i * CholNum<S>::LD + i];                             // 1 / L_ii
+    const bool sunk = lane < 16 && !(((S)1 / (li * li)) >= tau * a0[i]);
+    ok = ok && !__any(sunk);
+  }
+  return ok;
+}
+
+template <typename S>
+__device__ __forceinline__ void chol_panel_block_t(S* __restrict__ Ablk, const S* __restrict__ LinvT) {
+  const int lane = threadIdx.x & 63;
+  const S* Pa = Ablk + (lane & 15) * CholNum<S>::LD + (lane >> 4);
+  const S* Pl = LinvT + (lane >> 4) * CholNum<S>::LD + (lane & 15);
+  typename Mfma<S>::acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) acc = Mfma<S>::mma(Pa[4 * ks], Pl[4 * ks * CholNum<S>::LD], acc);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Ablk[Mfma<S>::row_of(lane, rg) * CholNum<S>::LD + (lane & 15)] = acc[rg];
+  __builtin_amdgcn_wave_barrier();
+}
+
+// (see chol_panel_update_diag: the transposed panel product's accumulators are the operands of the downdate; with the f32 MFMA the
+//  accumulator rows are 4 (lane >> 4) + reg instead of (lane >> 4) + 4 reg -- another order of the same sixteen k, used on both sides)
+template <typename S>
+__device__ __forceinline__ void chol_panel_update_diag_t(S* __restrict__ Pblk, const S* __restrict__ LinvT, S* __restrict__ Dt) {
+  const int lane = threadIdx.x & 63;
+  const S* Pa = Pblk + (lane & 15) * CholNum<S>::LD + (lane >> 4);
+  const S* Pl = LinvT + (lane >> 4) * CholNum<S>::LD + (lane & 15);
+  typename Mfma<S>::acc_t d;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) d[rg] = Dt[Mfma<S>::row_of(lane, rg) * CholNum<S>::LD + (lane & 15)];
+  typename Mfma<S>::acc_t pt = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) pt = Mfma<S>::mma(Pl[4 * ks * CholNum<S>::LD], Pa[4 * ks], pt);
+  __builtin_amdgcn_wave_barrier();
+  typename Mfma<S>::acc_t pp = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) pp = Mfma<S>::mma(pt[ks], pt[ks], pp);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) d[rg] -= pp[rg];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Pblk[(lane & 15) * CholNum<S>::LD + Mfma<S>::row_of(lane, rg)] = pt[rg];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Dt[Mfma<S>::row_of(lane, rg) * CholNum<S>::LD + (lane & 15)] = d[rg];
+  __builtin_amdgcn_wave_barrier();
+}
+
+// What k_cholesky_blocked shares between its two scalar types (static LDS, the same for both)
+struct CholbShared {
+  int fail;
+  short rc[CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2];   // block index -> (r << 8 | c)
+  double dd[CHOLB_MAX_NB * CB];                       // lam * D2c (diagonal damping); 0 in the padded tail
+  double x[CHOLB_MAX_NB * CB];                        // rhs in, solution out
+};
+constexpr int CHOLB_BPR = CHOLB_LDS_THREADS / 128;                                  // blocks of the first column per load round (128 threads each)
+constexpr int CHOLB_U0 = (CHOLB_MAX_NB + CHOLB_BPR - 1) / CHOLB_BPR;                // rounds for the first block column
+constexpr int CHOLB_NREM = CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2;                   // 55 other blocks
+constexpr int CHOLB_TREM = CHOLB_LDS_THREADS - 64;                                  // loaded by waves 1..7
+constexpr int CHOLB_U1 = (CHOLB_NREM * 128 + CHOLB_TREM - 1) / CHOLB_TREM;          // 16 rounds
+
+// Factorisation + both substitutions in scalar type S on the block triangle in dynamic LDS.  PREFETCHED: the system's entries are in
+// the c0 / c1 registers the kernel requested in its first instructions; otherwise (second attempt after a refused f32 factorisation)
+// they are read from E here.  Returns the failure flag; the solution is left in sh.x.
+template <typename S, bool NEWTON, bool PREFETCHED>
+__device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, CholbShared& sh, const double* __restrict__ E, const int n,
+                                           double (&c0)[CHOLB_U0][2], double (&c1)[CHOLB_U1][2], const int (&rc1)[CHOLB_U1],
+                                           const S tau, long long* __restrict__ dbg, int& nstamp) {
+#define CHOL_STAMP() do { if (dbg && threadIdx.x == 0) dbg[nstamp] = clock64(); ++nstamp; } while (0)
+  constexpr int BPR = CHOLB_BPR, U0 = CHOLB_U0, TREM = CHOLB_TREM, U1 = CHOLB_U1;
+  constexpr bool F32 = std::is_same<S, float>::value;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nb = (n + CB - 1) / CB;
+  const int n16 = nb * CB;
+  const int nblk = nb * (nb + 1) / 2;
+  S* Lb = reinterpret_cast<S*>(smem);                          // nblk blocks
+  S* s_y = Lb + nblk * CholNum<S>::BS;                                    // [n16]  rhs -> y -> x
+  S* s_a0 = s_y + n16;                                         // [n16]  damped diagonal as loaded (growth test of the f32 factorisation)
+  const int s4 = tid >> 7, ii0 = (tid >> 3) & 15, jp0 = tid & 7;
+  auto fix = [&](int I, int J, double& v0, double& v1) {       // padded tail = identity
+    if (I >= n || J >= n) v0 = (I == J) ? 1.0 : 0.0;
+    if (I >= n || J + 1 >= n) v1 = (I == J + 1) ? 1.0 : 0.0;
+  };
+  if (tid < n16) s_y[tid] = (S)sh.x[tid];
+  if constexpr (PREFETCHED) {
+#pragma unroll
+    for (int u = 0; u < U0; ++u) fix((BPR * u + s4) * CB + ii0, 2 * jp0, c0[u][0], c0[u][1]);
+    {
+      const int ii = ii0, jp = jp0;
+#pragma unroll
+      for (int u = 0; u < U0; ++u) {
+        const int r = BPR * u + s4;
+        if (r < nb) {
+          const int I = r * CB + ii, J = 2 * jp;
+          S* dst = Lb + CholNum<S>::off(r, 0) + ii * CholNum<S>::LD + J;
+          const double v0 = c0[u][0] + ((I == J && I < n) ? sh.dd[I] : 0.0), v1 = c0[u][1] + ((I == J + 1 && I < n) ? sh.dd[I] : 0.0);
+          dst[0] = (S)v0;
+          dst[1] = (S)v1;
+          if (F32 && I == J) s_a0[I] = (S)v0;
+          if (F32 && I == J + 1) s_a0[I] = (S)v1;
+        }
+      }
+    }
+    __syncthreads();
+    CHOL_STAMP();
+    if (wid > 0) {
+#pragma unroll
+      for (int u = 0; u < U1; ++u) {
+        const int e = (tid - 64) + TREM * u;
+        if (e < (nblk - nb) * 128) {
+          // (row, column) from the load loop's registers: as a table lookup in LDS in front of every store, sixteen dependent
+          // LDS round trips per thread made this phase 9k cycles, twice the first tile's factorisation it runs beside
+          const int rc = rc1[u];
+          const int br = rc >> 8, bc = rc & 255;
+          const int ii = (e >> 3) & 15, I = br * CB + ii, J = bc * CB + 2 * (e & 7);
+          S* dst = Lb + CholNum<S>::off(br, bc) + ii * CholNum<S>::LD + 2 * (e & 7);
+          fix(I, J, c1[u][0], c1[u][1]);
+          double d0 = 0.0, d1 = 0.0;
+          if (br == bc) {              // only a diagonal block carries damping (uniform for the 128 threads of a block)
+            d0 = (I == J && I < n) ? sh.dd[I] : 0.0;
+            d1 = (I == J + 1 && I < n) ? sh.dd[I] : 0.0;
+          }
+          dst[0] = (S)(c1[u][0] + d0);
+          dst[1] = (S)(c1[u][1] + d1);
+          if (F32 && br == bc && I == J) s_a0[I] = (S)(c1[u][0] + d0);
+          if (F32 && br == bc && I == J + 1) s_a0[I] = (S)(c1[u][1] + d1);
+        }
+      }
+    }
+  } else {
+    // second attempt: everything once more from E (L2 by now), no overlap with the first tile
+    for (int e = tid; e < nblk * CB * CB; e += CHOLB_LDS_THREADS) {
+      const int k = e >> 8, rc = sh.rc[k], br = rc >> 8, bc = rc & 255;
+      const int ii = (e >> 4) & 15, jj = e & 15, I = br * CB + ii, J = bc * CB + jj;
+      double v = (I < n && J < n) ? E[(size_t)I * n + J] : ((I == J) ? 1.0 : 0.0);
+      if (I == J && I < n) v += sh.dd[I];
+      Lb[CholNum<S>::off(br, bc) + ii * CholNum<S>::LD + jj] = (S)v;
+      if (F32 && I == J) s_a0[I] = (S)v;
+    }
+    __syncthreads();
+    CHOL_STAMP();
+  }
+  if (wid == 0) {
+    if (!chol16_wave_t<S, NEWTON>(Lb + CholNum<S>::off(0, 0), F32 ? s_a0 : nullptr, tau)) { if (lane == 0) sh.fail = 1; }
+  }
+  __syncthreads();
+  CHOL_STAMP();
+
+  constexpr int NW = CHOLB_LDS_THREADS / 64;
+  for (int jb = 0; jb < nb && !sh.fail; ++jb) {
+    const int m = (nb - jb - 1) * CB;              // rows below the diagonal block
+    const S* LinvT = Lb + CholNum<S>::off(jb, jb);
+    // ---- B: L21 = A21 Linv^T block by block; wave 0 takes the block right below the diagonal and downdates the next
+    //      diagonal tile with it, the last wave forward-solves the rhs block
+    if (wid == 0) {
+      if (jb + 1 < nb) chol_panel_update_diag_t<S>(Lb + CholNum<S>::off(jb + 1, jb), LinvT, Lb + CholNum<S>::off(jb + 1, jb + 1));
+    } else {
+      for (int r = jb + 2 + (wid - 1); r < nb; r += NW - 1) chol_panel_block_t<S>(Lb + CholNum<S>::off(r, jb), LinvT);
+      if (wid == NW - 1) {
+        // y_blk = Linv rhs_blk :  y[i] = sum_k LinvT[k][i] rhs[k]   (lane = (part, i): 4 terms each, then 2 swaps)
+        const int i = lane & 15, part = lane >> 4;
+        S x = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { const int k = part + 4 * kk; x += LinvT[k * CholNum<S>::LD + i] * s_y[jb * CB + k]; }
+        x = CholNum<S>::xrow(x);
+        __builtin_amdgcn_wave_barrier();
+        if (part == 0) s_y[jb * CB + i] = x;
+      }
+    }
+    __syncthreads();
+    CHOL_STAMP();
+    // ---- C: look-ahead factorisation of the next diagonal tile (wave 0) | rhs tail + trailing update (waves 1..7)
+    if (wid == 0) {
+      if (jb + 1 < nb) {
+        if (!chol16_wave_t<S, NEWTON>(Lb + CholNum<S>::off(jb + 1, jb + 1), F32 ? s_a0 + (jb + 1) * CB : nullptr, tau)) { if (lane == 0) sh.fail = 1; }
+      }
+    } else {
+      // The wave that shares its SIMD with wave 0 (wave 4: waves go round the four SIMDs, tools/micro/hw_id.hip) takes the light
+      // part, the right-hand side's tail, and stays out of the update: an f64 MFMA holds the SIMD's issue for 64 cycles and the pivot
+      // chain (~30 dependent f64 VALU instructions per pivot) gets three instructions in per MFMA (tools/micro/rate_f64.hip).
+      if (wid == 4) {
+        // rhs tail: y_i -= sum_k L21[i][k] y_blk[k]
+        for (int t = lane; t < m; t += 64) {
+          const S* row = Lb + CholNum<S>::off(jb + 1 + (t >> 4), jb) + (t & 15) * CholNum<S>::LD;
+          S s0 = 0, s1 = 0;
+#pragma unroll
+          for (int k = 0; k < CB; k += 2) { s0 += row[k] * s_y[jb * CB + k]; s1 += row[k + 1] * s_y[jb * CB + k + 1]; }
+          s_y[(jb + 1) * CB + t] -= s0 + s1;
+        }
+      } else {
+        // tiles (r,c), jb < c <= r < nb, except (jb+1,jb+1): the trailing block triangle in row-major order from index 1, a CONTIGUOUS
+        // run per worker: consecutive tiles share their row, so the row block's fragment (r, jb) stays in registers, the target and
+        // the column block's fragment advance by constant strides, and a tile costs 8 LDS reads, 4 MFMAs, 4 subtractions and 4 LDS
+        // writes.  (Measured, n = 176, f64, sum of the ten look-ahead phases: table-driven tiles dealt round robin to seven workers 49.0k
+        //  cycles; six workers taking two tiles at a time with interleaved MFMA chains 49.7k; these strips 48.3k; sixteen waves 49k.
+        //  A tile costs a wave ~850 cycles in every variant and a SIMD ~450: docs/EXPERIMENTS.md.)
+        constexpr int NWORK = NW - 2;
+        const int wk = wid - 1 - (wid > 4 ? 1 : 0);
+        const int q = nb - jb - 1;
+        const int ntile = q * (q + 1) / 2;
+        const int per = (ntile - 1 + NWORK - 1) / NWORK;
+        int t = 1 + wk * per;
+        const int t_hi = min(ntile, t + per);
+        if (t < t_hi) {
+          const int rc = sh.rc[t];
+          int r = jb + 1 + (rc >> 8), c = jb + 1 + (rc & 255);
+          const int po = (lane & 15) * CholNum<S>::LD + (lane >> 4);              // operand pattern: [row lane & 15][k = 4 ks + (lane >> 4)]
+          const int to = Mfma<S>::row_of(lane, 0) * CholNum<S>::LD + (lane & 15);   // accumulator pattern: [row_of(lane, reg)][col lane & 15]
+          constexpr int trs = F32 ? CholNum<S>::LD : 4 * CholNum<S>::LD;                      // ... whose rows are `trs` apart from register to register
+          while (t < t_hi) {
+            const S* Ap = Lb + CholNum<S>::off(r, jb) + po;
+            S a[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a[ks] = Ap[4 * ks];
+            S* D = Lb + CholNum<S>::off(r, c) + to;
+            const S* Bp = Lb + CholNum<S>::off(c, jb) + po;
+            for (; c <= r && t < t_hi; ++c, ++t) {
+              S bq[4];
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) bq[ks] = Bp[4 * ks];
+              typename Mfma<S>::acc_t acc, prod = {0, 0, 0, 0};
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) acc[rg] = D[rg * trs];
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) prod = Mfma<S>::mma(a[ks], bq[ks], prod);
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) D[rg * trs] = acc[rg] - prod[rg];
+              D += CholNum<S>::BS;
+              Bp += (c + 1) * CholNum<S>::BS;                                      // CholNum<S>::off(c + 1, jb) - CholNum<S>::off(c, jb)
+            }
+            ++r;
+            c = jb + 1;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    if (dbg && jb == 0 && lane == 0) dbg[40 + wid] = clock64();      // diagnostic: when each wave finished its share of C0
+    __syncthreads();
+    CHOL_STAMP();
+  }
+  const bool fail = sh.fail != 0;
+  // ---- back substitution, right-looking:  x_b = Linv_b^T y_b  (wave 0), then every earlier row t < 16 b takes
+  //      y_t -= sum_i L[16b+i][t] x_b[i]  (all waves).  The diagonal blocks hold Linv^T.
+  if (!fail) {
+    for (int b = nb - 1; b >= 0; --b) {
+      if (wid == 0) {
+        const int j = lane & 15, part = lane >> 4;
+        const S* LiT = Lb + CholNum<S>::off(b, b) + j * CholNum<S>::LD;    // row j of Linv^T
+        S x = 0;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) { const int i = part + 4 * ii; x += LiT[i] * s_y[b * CB + i]; }
+        x = CholNum<S>::xrow(x);
+        __builtin_amdgcn_wave_barrier();
+        if (part == 0) s_y[b * CB + j] = x;
+      }
+      __syncthreads();
+      if (tid < b * CB) {
+        const S* col = Lb + CholNum<S>::off(b, tid >> 4) + (tid & 15);
+        S s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < CB; i += 2) { s0 += col[i * CholNum<S>::LD] * s_y[b * CB + i]; s1 += col[(i + 1) * CholNum<S>::LD] * s_y[b * CB + i + 1]; }
+        s_y[tid] -= s0 + s1;
+      }
+      __syncthreads();
+    }
+    if (tid < n16) sh.x[tid] = (double)s_y[tid];
+  }
+  __syncthreads();
+  CHOL_STAMP();
+  return fail;
+#undef CHOL_STAMP
+}
+
+// use_f32 (fp32 engine only): 0 = the f64 factorisation, as every round before; 1 = factor on f32 lanes first and repeat in f64 when that
+// is refused (a non-positive or non-finite pivot, or a pivot below tau32 times its diagonal entry).  In the LM loop a refused f32
+// factorisation is almost always followed by a refused f64 one (S carries the 1e-7 rounding of its f32 products either way,
+// tools/chol_f32_model.py), so the repeat costs little; for a caller that hands sba_lm_solve_trial an arbitrary system it is what
+// keeps the answer right (tests/test_gpu_cholesky.py: condition 1e9).
 template <typename T>
 __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     const double* __restrict__ E /* summed exchange buffer [S | rhs | diagU | gc | cost] */, int C,
@@ -180,9 +530,9 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     double* __restrict__ delta_c, int n_sys /* size of the system in E: 11*C, or fewer when cameras share parameters */,
     const int32_t* __restrict__ tie /* [11*C] camera parameter -> system row, or NULL = identity */,
     const int32_t* __restrict__ first /* [n_sys] system row -> one camera parameter mapped to it, or NULL */,
-    long long* __restrict__ dbg /* optional cycle stamps (diagnostic runs only) */) {
+    long long* __restrict__ dbg /* optional cycle stamps (diagnostic runs only) */, int use_f32, float tau32) {
   extern __shared__ __align__(16) unsigned char smem[];
-  // fp32 engine: the pivot 1/sqrt(a_kk) is the hardware estimate (5e-8 relative) without the Newton step.  L_kk = a_kk piv
+  // fp32 engine, f64 factorisation: the pivot 1/sqrt(a_kk) is the hardware estimate (5e-8 relative) without the Newton step.  L_kk = a_kk piv
   // and the column scaled by the same piv factor a matrix whose row/column k differ from A's by 1e-7 relative -- the size
   // of the rounding error every entry of S already carries there -- and four dependent f64 operations leave each of the
   // 176 links of the pivot chain.
@@ -196,8 +546,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   const double* dU = rhs + n;
   const double* gct = dU + n;
   const bool pair_ok = (n & 1) == 0;
-  constexpr int BPR = CHOLB_LDS_THREADS / 128;                                // blocks of the first column per load round (128 threads each)
-  constexpr int U0 = (CHOLB_MAX_NB + BPR - 1) / BPR;                           // rounds for the first block column
+  constexpr int BPR = CHOLB_BPR, U0 = CHOLB_U0, TREM = CHOLB_TREM, U1 = CHOLB_U1;
   double c0[U0][2];
   const int nlast = n - 1;
   auto addr = [&](int I, int J) { return E + (size_t)min(I, nlast) * n + min(J, nlast - 1 + (pair_ok ? 0 : 1)); };
@@ -220,11 +569,8 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   const double my_g = (tid < n) ? gct[tid] : 0.0;
   // ... and so are the other 55 blocks, column by column (waves 1..7; the factorisation of the first tile does not wait for them).
   // Block k of that list sits in column cc, row cc + (k - base); k grows with the load round, so the search continues where it was.
-  constexpr int NREM = CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2;                  // 55 other blocks
-  constexpr int TREM = CHOLB_LDS_THREADS - 64;                                     // loaded by waves 1..7
-  constexpr int U1 = (NREM * 128 + TREM - 1) / TREM;                           // 16 rounds
   double c1[U1][2];
-  int rc1[U1];                     // (row << 8) | column of the round's block: the LDS stores below use it without a table lookup
+  int rc1[U1];                     // (row << 8) | column of the round's block: the LDS stores use it without a table lookup
   {
     const int nb_ = (n + CB - 1) / CB;
     const int last = (nb_ * (nb_ + 1) / 2 - nb_) * 128 - 1;
@@ -257,12 +603,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   const int nb = (n + CB - 1) / CB;
   const int n16 = nb * CB;
   const int nblk = nb * (nb + 1) / 2;
-  double* Lb = reinterpret_cast<double*>(smem);                   // nblk blocks
-  double* s_y = Lb + nblk * CBS;                                  // [n16]  rhs -> y -> x
-  double* s_d = s_y + n16;                                        // [n16]  lam * D2c (diagonal damping)
-  __shared__ int s_fail;
-  __shared__ short s_rc[CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2];   // block index -> (r << 8 | c)
-  __shared__ short s_cm[CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2];   // column-major list of the blocks with c >= 1
+  __shared__ CholbShared sh;
   __shared__ double s_scr[4][CHOLB_LDS_THREADS / 64];
   const double lam = st->lam;
   const bool fresh = st->fresh != 0;
@@ -273,29 +614,16 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   if (tid < nblk) {
     int r = 0;
     while ((r + 1) * (r + 2) / 2 <= tid) ++r;
-    s_rc[tid] = (short)((r << 8) | (tid - r * (r + 1) / 2));
+    sh.rc[tid] = (short)((r << 8) | (tid - r * (r + 1) / 2));
   }
-  if (tid < nblk - nb) {                           // blocks right of the first block column, column by column
-    int c = 1, q = tid;
-    while (q >= nb - c) { q -= nb - c; ++c; }
-    s_cm[tid] = (short)(((c + q) << 8) | c);
-  }
-  if (tid == 0) { s_fail = 0; st->cost = E[(size_t)n * n + 3 * n]; }
-  __syncthreads();
-  // ---- load the lower block triangle.  E was written by other CUs, so every access is a fabric round trip and one CU
+  if (tid == 0) { sh.fail = 0; st->cost = E[(size_t)n * n + 3 * n]; }
+  // ---- the lower block triangle.  E was written by other CUs, so every access is a fabric round trip and one CU
   // sustains few of them: two doubles per lane per load (16 B, E rows are 16-byte aligned when n is even), all loads
   // of a thread issued before any is used, the first block column first -- its 11 blocks are all the first
   // factorisation step needs, so wave 0 starts on it while waves 1..7 are still receiving the other 55 blocks.
   // The padded tail is the identity.
   // All loads are unconditional (out-of-range ones are clamped to a valid address and replaced afterwards) and sit in
   // straight-line code: only then can the compiler wait with vmcnt(N) for the first block column alone.
-  auto fix = [&](int I, int J, double& v0, double& v1) {       // padded tail = identity
-    if (I >= n || J >= n) v0 = (I == J) ? 1.0 : 0.0;
-    if (I >= n || J + 1 >= n) v1 = (I == J + 1) ? 1.0 : 0.0;
-  };
-  // (c0, c1 and the rhs / scaling entries were requested at the top of the kernel)
-#pragma unroll
-  for (int u = 0; u < U0; ++u) fix((BPR * u + s4) * CB + ii0, 2 * jp0, c0[u][0], c0[u][1]);
   // camera scaling: monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
   if (tid < n16) {                                 // n16 <= 176 < CHOLB_LDS_THREADS
     double dd = 0;
@@ -305,187 +633,38 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
       if (fresh) { d = fmax(d, in_u); D2c[tid] = d; }
       dd = lam * fmax_pos(d);
     }
-    s_y[tid] = in_r;
-    s_d[tid] = dd;
+    sh.x[tid] = in_r;
+    sh.dd[tid] = dd;
   }
   __syncthreads();
-  {
-    const int ii = ii0, jp = jp0;
-#pragma unroll
-    for (int u = 0; u < U0; ++u) {
-      const int r = BPR * u + s4;
-      if (r < nb) {
-        const int I = r * CB + ii, J = 2 * jp;
-        double* dst = Lb + cb_off(r, 0) + ii * CLD + J;
-        dst[0] = c0[u][0] + ((I == J && I < n) ? s_d[I] : 0.0);
-        dst[1] = c0[u][1] + ((I == J + 1 && I < n) ? s_d[I] : 0.0);
-      }
-    }
-  }
-  __syncthreads();
-  CHOL_STAMP();
-  if (wid > 0) {
-#pragma unroll
-    for (int u = 0; u < U1; ++u) {
-      const int e = (tid - 64) + TREM * u;
-      if (e < (nblk - nb) * 128) {
-        // (row, column) from the load loop's registers: as a table lookup in LDS in front of every store, sixteen dependent
-        // LDS round trips per thread made this phase 9k cycles, twice the first tile's factorisation it runs beside
-        const int rc = rc1[u];
-        const int br = rc >> 8, bc = rc & 255;
-        const int ii = (e >> 3) & 15, I = br * CB + ii, J = bc * CB + 2 * (e & 7);
-        double* dst = Lb + cb_off(br, bc) + ii * CLD + 2 * (e & 7);
-        fix(I, J, c1[u][0], c1[u][1]);
-        double d0 = 0.0, d1 = 0.0;
-        if (br == bc) {              // only a diagonal block carries damping (uniform for the 128 threads of a block)
-          d0 = (I == J && I < n) ? s_d[I] : 0.0;
-          d1 = (I == J + 1 && I < n) ? s_d[I] : 0.0;
-        }
-        dst[0] = c1[u][0] + d0;
-        dst[1] = c1[u][1] + d1;
-      }
-    }
-  }
-  if (wid == 0) {
-    if (!chol16_wave<PIV_NEWTON>(Lb + cb_off(0, 0))) { if (lane == 0) s_fail = 1; }
-  }
-  __syncthreads();
-  CHOL_STAMP();
-
-  constexpr int NW = CHOLB_LDS_THREADS / 64;
-  for (int jb = 0; jb < nb && !s_fail; ++jb) {
-    const int m = (nb - jb - 1) * CB;              // rows below the diagonal block
-    const double* LinvT = Lb + cb_off(jb, jb);
-    // ---- B: L21 = A21 Linv^T block by block; wave 0 takes the block right below the diagonal and downdates the next
-    //      diagonal tile with it, the last wave forward-solves the rhs block
-    if (wid == 0) {
-      if (jb + 1 < nb) {
-        chol_panel_update_diag(Lb + cb_off(jb + 1, jb), LinvT, Lb + cb_off(jb + 1, jb + 1));
+  bool fail;
+  if constexpr (std::is_same<T, float>::value) {
+    if (use_f32) {
+      fail = cholb_core<float, false, true>(smem, sh, E, n, c0, c1, rc1, tau32, dbg, nstamp);
+      if (fail) {                                 // refused: once more in f64, from E (sh.x still holds the right-hand side)
+        __syncthreads();
+        if (tid == 0) sh.fail = 0;
+        __syncthreads();
+        fail = cholb_core<double, true, false>(smem, sh, E, n, c0, c1, rc1, 0.0, dbg, nstamp);      // (refined pivots: this pass is about the answer, not the time)
+        if (tid == 0) atomicAdd(&st->chol_f64_retries, 1);
       }
     } else {
-      for (int r = jb + 2 + (wid - 1); r < nb; r += NW - 1) chol_panel_block(Lb + cb_off(r, jb), LinvT);
-      if (wid == NW - 1) {
-        // y_blk = Linv rhs_blk :  y[i] = sum_k LinvT[k][i] rhs[k]   (lane = (part, i): 4 terms each, then 2 shuffles)
-        const int i = lane & 15, part = lane >> 4;
-        double x = 0;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { const int k = part + 4 * kk; x += LinvT[k * CLD + i] * s_y[jb * CB + k]; }
-        x = xrow_sum(x);
-        __builtin_amdgcn_wave_barrier();
-        if (part == 0) s_y[jb * CB + i] = x;
-      }
+      fail = cholb_core<double, PIV_NEWTON, true>(smem, sh, E, n, c0, c1, rc1, 0.0, dbg, nstamp);
     }
-    __syncthreads();
-    CHOL_STAMP();
-    // ---- C: look-ahead factorisation of the next diagonal tile (wave 0) | rhs tail + trailing update (waves 1..7)
-    if (wid == 0) {
-      if (jb + 1 < nb) {
-        if (!chol16_wave<PIV_NEWTON>(Lb + cb_off(jb + 1, jb + 1))) { if (lane == 0) s_fail = 1; }
-      }
-    } else {
-      // The wave that shares its SIMD with wave 0 (wave 4: waves go round the four SIMDs, tools/micro/hw_id.hip) takes the light
-      // part, the right-hand side's tail, and stays out of the update: an f64 MFMA holds the SIMD's issue for 64 cycles and the pivot
-      // chain (~30 dependent f64 VALU instructions per pivot) gets three instructions in per MFMA (tools/micro/rate_f64.hip).
-      if (wid == 4) {
-        // rhs tail: y_i -= sum_k L21[i][k] y_blk[k]
-        for (int t = lane; t < m; t += 64) {
-          const double* row = Lb + cb_off(jb + 1 + (t >> 4), jb) + (t & 15) * CLD;
-          double s0 = 0, s1 = 0;
-#pragma unroll
-          for (int k = 0; k < CB; k += 2) { s0 += row[k] * s_y[jb * CB + k]; s1 += row[k + 1] * s_y[jb * CB + k + 1]; }
-          s_y[(jb + 1) * CB + t] -= s0 + s1;
-        }
-      } else {
-        // tiles (r,c), jb < c <= r < nb, except (jb+1,jb+1): the trailing block triangle in row-major order from index 1, a CONTIGUOUS
-        // run per worker: consecutive tiles share their row, so the row block's fragment (r, jb) stays in registers, the target and
-        // the column block's fragment advance by constant strides, and a tile costs 8 LDS reads, 4 MFMAs, 4 subtractions and 4 LDS
-        // writes.  (Measured, n = 176, sum of the ten look-ahead phases: table-driven tiles dealt round robin to seven workers 49.0k
-        //  cycles; six workers taking two tiles at a time with interleaved MFMA chains 49.7k; these strips 48.3k; sixteen waves 49k.
-        //  A tile costs a wave ~850 cycles in every variant and a SIMD ~450: neither the matrix pipe (256 per tile), the LDS (48)
-        //  nor the instruction count explains it alone -- DESIGN.md, what comes next.)
-        constexpr int NWORK = NW - 2;
-        const int wk = wid - 1 - (wid > 4 ? 1 : 0);
-        const int q = nb - jb - 1;
-        const int ntile = q * (q + 1) / 2;
-        const int per = (ntile - 1 + NWORK - 1) / NWORK;
-        int t = 1 + wk * per;
-        const int t_hi = min(ntile, t + per);
-        if (t < t_hi) {
-          const int rc = s_rc[t];
-          int r = jb + 1 + (rc >> 8), c = jb + 1 + (rc & 255);
-          const int po = (lane & 15) * CLD + (lane >> 4);              // operand pattern: [row lane & 15][k = 4 ks + (lane >> 4)]
-          const int to = (lane >> 4) * CLD + (lane & 15);              // accumulator pattern: [row (lane >> 4) + 4 reg][col lane & 15]
-          while (t < t_hi) {
-            const double* Ap = Lb + cb_off(r, jb) + po;
-            double a[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a[ks] = Ap[4 * ks];
-            double* D = Lb + cb_off(r, c) + to;
-            const double* Bp = Lb + cb_off(c, jb) + po;
-            for (; c <= r && t < t_hi; ++c, ++t) {
-              double bq[4];
-#pragma unroll
-              for (int ks = 0; ks < 4; ++ks) bq[ks] = Bp[4 * ks];
-              Mfma<double>::acc_t acc, prod = {0, 0, 0, 0};
-#pragma unroll
-              for (int rg = 0; rg < 4; ++rg) acc[rg] = D[4 * rg * CLD];
-#pragma unroll
-              for (int ks = 0; ks < 4; ++ks) prod = Mfma<double>::mma(a[ks], bq[ks], prod);
-#pragma unroll
-              for (int rg = 0; rg < 4; ++rg) D[4 * rg * CLD] = acc[rg] - prod[rg];
-              D += CBS;
-              Bp += (c + 1) * CBS;                                      // cb_off(c + 1, jb) - cb_off(c, jb)
-            }
-            ++r;
-            c = jb + 1;
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-    }
-    if (dbg && jb == 0 && lane == 0) dbg[40 + wid] = clock64();      // diagnostic: when each wave finished its share of C0
-    __syncthreads();
-    CHOL_STAMP();
+  } else {
+    fail = cholb_core<double, PIV_NEWTON, true>(smem, sh, E, n, c0, c1, rc1, 0.0, dbg, nstamp);
   }
-  const bool fail = s_fail != 0;
-  // ---- back substitution, right-looking:  x_b = Linv_b^T y_b  (wave 0), then every earlier row t < 16 b takes
-  //      y_t -= sum_i L[16b+i][t] x_b[i]  (all waves).  The diagonal blocks hold Linv^T.
-  if (!fail) {
-    for (int b = nb - 1; b >= 0; --b) {
-      if (wid == 0) {
-        const int j = lane & 15, part = lane >> 4;
-        const double* LiT = Lb + cb_off(b, b) + j * CLD;    // row j of Linv^T
-        double x = 0;
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) { const int i = part + 4 * ii; x += LiT[i] * s_y[b * CB + i]; }
-        x = xrow_sum(x);
-        __builtin_amdgcn_wave_barrier();
-        if (part == 0) s_y[b * CB + j] = x;
-      }
-      __syncthreads();
-      if (tid < b * CB) {
-        const double* col = Lb + cb_off(b, tid >> 4) + (tid & 15);
-        double s0 = 0, s1 = 0;
-#pragma unroll
-        for (int i = 0; i < CB; i += 2) { s0 += col[i * CLD] * s_y[b * CB + i]; s1 += col[(i + 1) * CLD] * s_y[b * CB + i + 1]; }
-        s_y[tid] -= s0 + s1;
-      }
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-  CHOL_STAMP();
   double pred = 0, dx2 = 0, x2 = 0, gm = 0;
   __shared__ double s_cnew[CHOLB_MAX_NB * CB];       // the trial cameras once more in LDS: the CamPre rebuild below reads them
   if (tid < ncam) {                                  // from there instead of waiting for its own global stores to come back
-    const double d = fail ? 0.0 : s_y[tie ? tie[tid] : tid];
+    const double d = fail ? 0.0 : sh.x[tie ? tie[tid] : tid];
     delta_c[tid] = d;
     cams_new[tid] = my_cam + d;
     s_cnew[tid] = my_cam + d;
   }
   if (tid < n) {                                     // scalars of the step live in the system's own unknowns
-    const double d = fail ? 0.0 : s_y[tid];
-    pred = 0.5 * d * (s_d[tid] * d - my_g);
+    const double d = fail ? 0.0 : sh.x[tid];
+    pred = 0.5 * d * (sh.dd[tid] * d - my_g);
     dx2 = d * d;
     x2 = my_xs * my_xs;
     gm = fabs(my_g);

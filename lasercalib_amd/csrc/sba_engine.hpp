@@ -92,12 +92,20 @@ struct Engine : EngineBase {
   // the left-looking kernel with the factor on chip above that (k_cholesky_ll, sba_chol_ll.hpp: 17..23 cameras).
   // SBA_CHOL=ll: the left-looking kernel for every size up to 256; SBA_CHOL=blocked: never (the streamed kernel above 176) -- A/B runs, tests
   bool chol_ll = true, chol_ll_all = false;
+  // fp32 engine, up to 176 unknowns: factor on f32 lanes (v_mfma_f32_16x16x4, f32 pivot chain) and repeat in f64 only when that is
+  // refused -- a non-positive pivot, or one below chol_f32_tau times its diagonal entry (2^-23: the entry's own rounding noise).
+  // SBA_CHOL_F32=0 keeps the f64 factorisation of rounds 1-3; SBA_CHOL_F32_TAU overrides the threshold.
+  int chol_f32 = 1;
+  float chol_f32_tau = 1.1920929e-7f;
   // systems larger than this take the multi-workgroup factorisation (sba_chol_big.hpp); up to CS_MAX_NB * CB = 512 unknowns the
   // streamed one-workgroup kernel could run too, but it only wins below ~210 (measured at 50k points, fp32: 17 cameras 379 vs 388 us
   // per iteration, 20: 417 vs 409, 24: 487 vs 454, 32: 647 vs 515)
   int chol_big_min_n = 209;
   DevBuf<double> chol_sol, chol_work, chol_W, chol_Minv, chol_Ld, chol_yv;
   DevBuf<int> chol_info;
+  DevBuf<unsigned> chol_flags;          // k_chol_big_back_all: x_b published (value = the launch's epoch)
+  unsigned chol_epoch = 0;
+  bool chol_big_back_one = true;        // SBA_CHOL_BIG_BACK=launches keeps one launch per block (rounds 1-3)
   bool chol_debug = false;
   bool schur_debug = false;
   int schur_debug_skip = 0;           // SBA_SCHUR_DEBUG=k: stamps of the (k+1)-th fused launch (k >= 1: one with the decision in its prologue)
@@ -209,6 +217,9 @@ struct Engine : EngineBase {
       chol_old = (std::string(e) == "old"); chol_ll = (std::string(e) != "blocked") && !chol_old; chol_ll_all = (std::string(e) == "ll");
     }
     if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
+    if (const char* e = getenv("SBA_CHOL_BIG_BACK")) chol_big_back_one = std::string(e) != "launches";
+    if (const char* e = getenv("SBA_CHOL_F32")) chol_f32 = atoi(e) != 0;
+    if (const char* e = getenv("SBA_CHOL_F32_TAU")) { char* end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0 && v < 1) chol_f32_tau = (float)v; }
     if (const char* e = getenv("SBA_CHOL_BIG_MIN_N")) {      // diagnostic: route smaller systems through the big path too
       char* end = nullptr;
       const long v = strtol(e, &end, 10);
@@ -257,7 +268,10 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resjac<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_solve<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    // (dynamic: the block triangle of 176 unknowns in doubles + two vectors = 146,432 B; the kernel's static LDS -- tables, damping,
+    //  right-hand side, trial cameras -- comes on top of it and both must fit the 160 KB of a CU)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2 * CBS + 2 * CHOLB_MAX_NB * CB) * sizeof(double))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_ll<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
@@ -1381,6 +1395,13 @@ struct Engine : EngineBase {
       hipLaunchKernelGGL(k_chol_big_step, dim3(std::max(1, q * (q + 1) / 2)), dim3(CHOLBIG_THREADS), lds, stream, chol_W.p, npad, j,
                          chol_Minv.p, chol_Ld.p, chol_info.p, d_state.p);
     }
+    if (chol_big_back_one) {
+      // the whole back substitution in one launch: block row = workgroup, x_b handed over through flags (sba_chol_big.hpp)
+      if (chol_flags.n == 0) { chol_flags.alloc(64); chol_flags.zero(stream); }
+      hipLaunchKernelGGL(k_chol_big_back_all, dim3(nbx), dim3(256), 0, stream, chol_W.p, npad, n_sys, chol_Ld.p, chol_Minv.p, chol_yv.p,
+                         chol_flags.p, ++chol_epoch, chol_sol.p, chol_info.p, d_state.p);
+      return;
+    }
     hipLaunchKernelGGL(k_chol_big_back_init, dim3((npad + 255) / 256), dim3(256), 0, stream, chol_W.p, npad, n_sys, chol_Ld.p,
                        chol_yv.p, d_state.p);
     for (int b = nbx - 1; b >= 0; --b)
@@ -1442,7 +1463,7 @@ struct Engine : EngineBase {
         if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }
         hipLaunchKernelGGL(k_cholesky_blocked<T>, dim3(1), dim3(CHOLB_LDS_THREADS), lds, stream, Esys, C, d_state.p, D2c.p,
                            ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr,
-                           chol_debug ? chol_dbg.p : nullptr);
+                           chol_debug ? chol_dbg.p : nullptr, (sizeof(T) == 4 && chol_f32) ? 1 : 0, chol_f32_tau);
         if (chol_debug) {
           std::vector<long long> st(64);
           HIPCHK(hipMemcpyAsync(st.data(), chol_dbg.p, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
@@ -1668,6 +1689,7 @@ struct Engine : EngineBase {
       rep->cost = cost; rep->initial_cost = initial_cost; rep->optimality = gmax; rep->step_norm = s.step_norm;
       rep->lambda = s.lam; rep->nfev = s.nfev; rep->njev = s.njev; rep->iterations = s.iter; rep->accepted = s.n_accepted;
       rep->status = s.status < 0 ? 0 : s.status;
+      rep->reserved = s.chol_f64_retries;
     }
     lm_active = false;
     return SBA_OK;

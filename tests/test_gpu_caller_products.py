@@ -60,8 +60,10 @@ def test_solve_and_exports_on_the_example_rig(tmp_path, capsys):
     assert "`ftol` termination condition is satisfied." in out or "`xtol`" in out
     ref, _, _ = orc.bundle_adjust(P["cams0"], p3, p2, ci, pi, ftol=1e-4)
     cost = 0.5 * np.sum(orc.fun(np.hstack((sba.cameraArray.ravel(), sba.points3D.ravel())), 17, p3.shape[0], ci, pi, p2, 1.0) ** 2)
-    # both solvers stop on ftol = 1e-4 (relative cost decrease per step): they end within a fraction of that of each other
-    assert abs(cost - ref.cost) <= 5e-5 * ref.cost
+    # both solvers stop on ftol = 1e-4 (relative cost decrease of their LAST step), so their end points differ by a fraction of that
+    # tolerance: SURVEY 8(d)'s 1e-5 was calibrated on the 8 x 2000 rig (F4 `mid`, where tests/test_gpu_parity.py holds it two-sided);
+    # on this 17-camera rig the reference itself moves by 3e-5 between ftol 1e-4 and 1e-5, hence 5e-5 -- two-sided
+    assert abs(cost - ref.cost) <= 5e-5 * ref.cost, (cost, ref.cost)
     assert abs(orc.rms_reprojection(sba.cameraArray, sba.points3D, p2, ci, pi) - np.sqrt(2 * ref.cost / ci.size)) <= 1e-4
     # exports: conversion of the optimised cameras = the pinned restatement (F6), red table survives '%f', pickles keep the module path
     readable = cp.camera_array_to_readable(sba.cameraArray)
@@ -100,9 +102,43 @@ def test_mixed_precision_mode_lands_on_the_fp64_solution(monkeypatch, capsys):
     for mode in ("f64", "mixed"):
         res, cost = out[mode]
         assert res.status in (2, 3, 4)
-        assert abs(cost - ref.cost) <= 5e-5 * ref.cost       # same bar as test_solve_and_exports_on_the_example_rig
+        assert abs(cost - ref.cost) <= 5e-5 * ref.cost, (mode, cost, ref.cost)       # same bar and reason as test_solve_and_exports_on_the_example_rig
     assert abs(out["mixed"][1] - out["f64"][1]) <= 5e-5 * out["f64"][1]
     assert out["mixed"][0].nfev >= 2
+
+
+@pytest.mark.parametrize("which", ["f4_mid", "16x50k"])
+def test_mixed_mode_on_the_f4_rig_and_on_the_benchmark_rig(monkeypatch, capsys, which):
+    """LASERCALIB_SBA_DTYPE=mixed (fp32 engine until the caller's tolerances stop it, then the fp64 engine from there): on F4 `mid`
+    (8 x 2000, pinned by the reference: two-sided 1e-5 on the cost, like the pure fp64 solve) and on BASELINE config 3's rig
+    (16 x 50 000: size-independent properties -- the returned point's fp64 cost is the reported one, equals the pure fp64 solve's
+    to 1e-5, RMS at the noise floor, iteration numbers of the merged log increase)."""
+    from lasercalib_amd.synth import make_rig
+    if which == "f4_mid":
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f4_solves.npz"))
+        a = (g["mid_cams0"], g["mid_pts0"], g["mid_uv"], g["mid_ci"], g["mid_pi"])
+        ref_cost = float(g["mid_loose_cost"])
+    else:
+        rig = make_rig(16, 50000, seed=0)
+        a = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+        ref_cost = None
+    out = {}
+    for mode in ("f64", "mixed"):
+        monkeypatch.setenv("LASERCALIB_SBA_DTYPE", mode)
+        sba = PySBA(a[0].copy(), a[1].copy(), a[2], a[3], a[4])
+        res = sba.bundleAdjust(1e-4)
+        x = np.hstack((sba.cameraArray.ravel(), sba.points3D.ravel()))
+        cost = 0.5 * np.sum(orc.fun(x, a[0].shape[0], a[1].shape[0], a[3], a[4], a[2], 1.0) ** 2)
+        assert res.status in (2, 3, 4) and abs(cost - res.cost) <= 1e-9 * cost
+        out[mode] = (res, cost, orc.rms_reprojection(sba.cameraArray, sba.points3D, a[2], a[3], a[4]))
+    capsys.readouterr()
+    assert abs(out["mixed"][1] - out["f64"][1]) <= 1e-5 * out["f64"][1], (out["mixed"][1], out["f64"][1])
+    assert out["mixed"][0].nfev >= 2
+    if ref_cost is not None:
+        for mode in ("f64", "mixed"):
+            assert out[mode][1] <= ref_cost * (1 + 1e-9) and ref_cost - out[mode][1] <= 1e-5 * ref_cost, (mode, out[mode][1], ref_cost)
+    else:
+        assert 0.40 < out["mixed"][2] < 0.44 and abs(out["mixed"][2] - out["f64"][2]) <= 1e-5      # 0.3 px noise per axis
 
 
 def test_result_object_materialises_fun_on_demand():

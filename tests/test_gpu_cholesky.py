@@ -32,7 +32,7 @@ def _spd(n, rng, cond=1e3):
     return 0.5 * (A + A.T)
 
 
-def _solve_on_device(C, S, rhs, dU, dtype, lam=1e-3):
+def _solve_on_device(C, S, rhs, dU, dtype, lam=1e-3, want_retries=False):
     rig = make_rig(C, 40, seed=C)
     n = 11 * C
     with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], dtype=dtype) as prob:
@@ -46,8 +46,8 @@ def _solve_on_device(C, S, rhs, dU, dtype, lam=1e-3):
         torch.cuda.synchronize()
         prob.lm_solve_trial(E.data_ptr(), sc.data_ptr())
         step = prob.lm_get_step().ravel()
-        prob.lm_finish()
-    return step
+        _, _, rep = prob.lm_finish()
+    return (step, int(rep.reserved)) if want_retries else step
 
 
 CASES = [(2, "f64"), (5, "f64"), (11, "f64"), (16, "f64"), (16, "f32"), (17, "f64"), (17, "f32"), (19, "f64"), (20, "f32"),
@@ -70,9 +70,11 @@ def test_reduced_system_solve_matches_numpy(monkeypatch, C, dtype, mode):
     step = _solve_on_device(C, S, rhs, dU, dtype, lam)
     A = S + lam * np.diag(dU)            # first linearisation: D = max(0, diagU)
     ref = np.linalg.solve(A, rhs)
-    # f64 engine: pivots refined to 4e-15; f32 engine: the 5e-8 hardware estimate of 1/sqrt is used as it is, which
-    # perturbs the factored matrix by 1e-7 relative => solution error <= cond * 1e-7
-    tol = 1e-9 if dtype == "f64" else 1e3 * 2e-7
+    # f64 engine: pivots refined to 4e-15; f32 engine, f64 factorisation (more than 176 unknowns, or SBA_CHOL=ll / SBA_CHOL_F32=0): the
+    # 5e-8 hardware estimate of 1/sqrt is used as it is, which perturbs the factored matrix by 1e-7 relative =>
+    # solution error <= cond * 1e-7; f32 engine up to 176 unknowns (round 4): the factorisation runs on f32 lanes, cond * 1e-6
+    f32_lanes = dtype == "f32" and n <= 176 and mode != "ll"
+    tol = 1e-9 if dtype == "f64" else 1e3 * (1e-6 if f32_lanes else 2e-7)
     assert np.max(np.abs(step - ref)) <= tol * np.max(np.abs(ref)), np.max(np.abs(step - ref)) / np.max(np.abs(ref))
 
 
@@ -97,6 +99,39 @@ def test_ill_conditioned_and_indefinite(monkeypatch, C, mode):
     S2[k, k] = -1.0
     step = _solve_on_device(C, S2, rhs, dU, "f64", lam=1e-6)
     assert np.all(step == 0.0)
+
+
+@pytest.mark.parametrize("C", [5, 11, 16])
+def test_f32_lane_factorisation_of_the_fp32_engine(monkeypatch, C):
+    """fp32 engine, up to 176 unknowns: k_cholesky_blocked factors on f32 lanes (f32 pivot chain, v_mfma_f32_16x16x4) and repeats
+    the factorisation in f64 only when the f32 one is refused.  Bars: solution error <= cond * 1e-6 for cond <= 1e5 with NO
+    repeat; at cond 1e9 (lam 1e-6) the pivots sink below 2^-23 of their diagonal entries, the repeat is taken (counted in the
+    report) and the answer has the f64 kernel's accuracy; SBA_CHOL_F32=0 never takes the f32 path."""
+    monkeypatch.delenv("SBA_CHOL", raising=False)
+    monkeypatch.delenv("SBA_CHOL_F32", raising=False)
+    rng = np.random.default_rng(300 + C)
+    n = 11 * C
+    rhs = rng.standard_normal(n)
+    dU = np.ones(n)
+    for cond in (1e2, 1e4, 1e5):
+        S = _spd(n, rng, cond=cond)
+        step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+        ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
+        err = np.max(np.abs(step - ref)) / np.max(np.abs(ref))
+        assert retries == 0 and err <= cond * 1e-6, (cond, retries, err)
+    S = _spd(n, rng, cond=1e9)
+    ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
+    step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+    assert retries == 1 and np.max(np.abs(step - ref)) <= 1e-5 * np.max(np.abs(ref)), (retries, np.max(np.abs(step - ref)) / np.max(np.abs(ref)))
+    S2 = S.copy()
+    S2[n - 5, n - 5] = -1.0                      # indefinite: refused in f32, refused again in f64, zero step
+    step, retries = _solve_on_device(C, S2, rhs, dU, "f32", lam=1e-6, want_retries=True)
+    assert retries == 1 and np.all(step == 0.0)
+    monkeypatch.setenv("SBA_CHOL_F32", "0")
+    S = _spd(n, rng, cond=1e4)
+    step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+    ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
+    assert retries == 0 and np.max(np.abs(step - ref)) <= 1e4 * 2e-7 * np.max(np.abs(ref))
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

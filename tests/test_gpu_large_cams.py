@@ -59,7 +59,15 @@ def test_large_rigs_vs_reference_oracle(C, N, vis, dtype):
     cost64 = 0.5 * np.sum(orc.fun(np.hstack((cams.ravel(), pts.ravel())), C, N, rig["camera_ind"], rig["point_ind"],
                                   rig["points_2d"], 1.0) ** 2)
     assert abs(cost64 - rep.cost) <= (1e-9 if dtype == "f64" else 1e-4) * cost64       # reported cost = oracle's cost at x
-    assert cost64 <= ref.cost * (1 + 1e-6) and cost64 >= 0.9 * ref.cost               # never above scipy, same basin
+    assert cost64 <= ref.cost * (1 + 1e-6)                                             # never above scipy at the same ftol ...
+    if C == 47:
+        # ... and never below the minimum itself: independent exact optimisers on the oracle's fun from the device's solution
+        # (oracle.tight_optimum: dense SVD trust-region steps, so only the smallest of these rigs; the same pin from the initial
+        # guess is tests/golden/f9_tight.npz, tests/test_gpu_parity.py).  At ftol 1e-4 the device stops within 1e-3 of it.
+        best, _ = orc.tight_optimum(cams, pts, *args, max_nfev=(120, 40))
+        assert best * (1 - (1e-9 if dtype == "f64" else 1e-4)) <= cost64 <= best * (1 + 1e-3), (cost64, best, ref.cost)
+    else:
+        assert cost64 >= 0.9 * ref.cost, "one-sided by construction: scipy's TRF/LSMR stops on ftol 0.1-5 % above the minimum on these weakly conditioned rigs; this only guards against another basin (the two-sided pin is the 47-camera case and F9)"
     again, _, _ = orc.bundle_adjust(cams, pts, *args, ftol=1e-4, max_nfev=10)
     # scipy cannot lower it by more than the stopping tolerance (fp32: plus the 1e-4 fp32 cost bar of SURVEY 8d, observed 1.2e-4)
     assert again.cost >= cost64 * (1 - (1e-4 if dtype == "f64" else 3e-4))

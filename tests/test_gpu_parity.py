@@ -253,12 +253,45 @@ def test_tight_solve_is_an_optimum_the_reference_accepts(golden, tag):
     ref_cost = float(g[f"{tag}_tight_cost"])
     assert rep.status in (2, 3, 4)
     assert rep.cost <= ref_cost * (1 + 1e-9)
-    assert rep.cost >= 0.9 * ref_cost                   # same basin, not a different problem
+    # ... and from below by the minimum itself (F9: independent exact optimisers on the reference's own fun): at ftol 1e-8 the device
+    # stops within 1e-6 of it (observed 1.5e-8), the reference's TRF/LSMR 5e-4 to 1.3e-2 above it
+    f9 = golden("f9_tight.npz")
+    assert np.array_equal(f9[f"{tag}_uv"], p["uv"]) and np.array_equal(f9[f"{tag}_cams0"], p["cams0"])      # the same rig
+    best = float(f9[f"{tag}_cost"])
+    assert best * (1 - 1e-9) <= rep.cost <= best * (1 + 1e-6), (rep.cost, best)
     res, _, _ = orc.bundle_adjust(cams, pts, p["uv"], p["ci"], p["pi"], ftol=1e-8, max_nfev=20)
     assert res.cost >= rep.cost * (1 - 1e-6)            # scipy cannot lower it further
     eng = model.ModelEngine(p["cams0"], p["pts0"], p["uv"], p["ci"], p["pi"])
     out = model.run_lm_single(eng, ftol=1e-8)
     assert abs(rep.cost - out["cost"]) <= 1e-8 * out["cost"]
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "sparse", "var"])
+def test_tight_optimum_two_sided_against_independent_exact_optimisers(golden, tag):
+    """SURVEY 8(d)'s tight bar, two-sided: relative cost difference <= 1e-8 in fp64.  The pin is F9 (tests/golden/f9_tight.npz,
+    oracle/make_golden.py f9): the minimum of the REFERENCE'S OWN `fun` found by scipy's TRF with the exact (SVD) trust-region
+    subproblem on a dense finite-difference Jacobian and polished by MINPACK's lmder -- nothing of the device algorithm or of
+    oracle/lm_schur_model.py is in it.  (The reference's own TRF/LSMR call stalls on ftol above this minimum: f4_solves.npz holds
+    23.7608 / 113.5547 for cfg1 / sparse at ftol 1e-8, the minimum is 23.4586 / 113.4915.)  Gauge-free summaries at 1e-6."""
+    g = golden("f9_tight.npz")
+    p = _f4(g, tag)
+    assert int(g[f"{tag}_status_minpack"]) > 0 or int(g[f"{tag}_status_trf_exact"]) > 0        # the pin itself converged
+    cams, pts, rep, log = _solve(p, 1e-12, xtol=1e-12, gtol=1e-12)
+    best = float(g[f"{tag}_cost"])
+    assert rep.status in (1, 2, 3, 4)
+    assert abs(rep.cost - best) <= 1e-8 * best, (rep.cost, best, (rep.cost - best) / best)
+    x = np.hstack((cams.ravel(), pts.ravel()))
+    cost_ref_fun = 0.5 * np.sum(orc.fun(x, cams.shape[0], pts.shape[0], p["ci"], p["pi"], p["uv"], 1.0) ** 2)
+    assert abs(cost_ref_fun - rep.cost) <= 1e-10 * rep.cost           # the reported cost IS the reference's fun at the returned x
+    assert abs(orc.rms_reprojection(cams, pts, p["uv"], p["ci"], p["pi"]) - float(g[f"{tag}_rms"])) <= 1e-8
+    intr, ratios = orc.gauge_invariants(cams)
+    assert np.max(np.abs(ratios - g[f"{tag}_centre_ratios"])) <= 1e-6
+    d = np.abs(intr - g[f"{tag}_intr"]).max(axis=0)                  # columns f, k1, k2, cx, cy
+    assert d[0] <= 1e-6 * 2400 and d[3] <= 2e-3 and d[4] <= 2e-3 and d[1] <= 1e-6 and d[2] <= 1e-6, d
+    # fp32 engine on the same rigs: the SURVEY 8(d) fp32 bar against the same minimum
+    cams32, pts32, rep32, _ = _solve(p, 1e-9, dtype="f32")
+    c32 = 0.5 * np.sum(orc.fun(np.hstack((cams32.ravel(), pts32.ravel())), cams.shape[0], pts.shape[0], p["ci"], p["pi"], p["uv"], 1.0) ** 2)
+    assert best * (1 - 1e-9) <= c32 <= best * (1 + 1e-4), (c32, best)
 
 
 @pytest.mark.parametrize("tag", ["cfg1", "mid"])
@@ -293,8 +326,10 @@ def test_weighted_solve_matches_oracle():
                                           weights=w.reshape(-1, 1), ftol=1e-8)
     cams, pts, rep, _ = _solve(dict(cams0=rig["cams0"], pts0=rig["pts0"], uv=rig["points_2d"], ci=rig["camera_ind"],
                                     pi=rig["point_ind"]), 1e-8, weights=w)
-    # one-sided at tight tolerance (see test_tight_solve_is_an_optimum_the_reference_accepts)
-    assert rep.cost <= res.cost * (1 + 1e-9) and rep.cost >= 0.9 * res.cost
+    # above: the reference's call at the same tolerance; below: the minimum itself, by the independent exact optimisers of
+    # oracle.tight_optimum started from the device's solution (see test_tight_optimum_two_sided_...)
+    best, _ = orc.tight_optimum(cams, pts, rig["points_2d"], rig["camera_ind"], rig["point_ind"], weights=w.reshape(-1, 1), max_nfev=(40, 20))
+    assert rep.cost <= res.cost * (1 + 1e-9) and best * (1 - 1e-9) <= rep.cost <= best * (1 + 1e-6), (rep.cost, best, res.cost)
     again, _, _ = orc.bundle_adjust(cams, pts, rig["points_2d"], rig["camera_ind"], rig["point_ind"],
                                     weights=w.reshape(-1, 1), ftol=1e-8, max_nfev=20)
     assert again.cost >= rep.cost * (1 - 1e-6)
@@ -577,4 +612,6 @@ def test_dense_kernels_match_general_kernels(monkeypatch, dtype, C, N, vis, rtol
     else:
         ref, _, _ = orc.bundle_adjust(rig["cams0"], rig["pts0"], uv, ci, pi, weights=wts.reshape(-1, 1), ftol=1e-4)
         assert rd.cost <= ref.cost * (1 + 1e-4) and rg_.cost <= ref.cost * (1 + 1e-4)
-        assert min(rd.cost, rg_.cost) >= 0.9 * ref.cost
+        # (from below: the minimum itself -- oracle.tight_optimum, independent exact optimisers from the dense path's solution)
+        best, _ = orc.tight_optimum(cd, pd_, uv, ci, pi, weights=wts.reshape(-1, 1), max_nfev=(60, 30))
+        assert min(rd.cost, rg_.cost) >= best * (1 - 1e-4), (rd.cost, rg_.cost, best)

@@ -92,7 +92,14 @@ def test_converged_solve_13_vs_oracle(C, N, vis, dtype):
     assert cams.shape == (C, 13) and rep.status in (2, 3, 4)
     cost64 = 0.5 * np.sum(orc.fun(np.hstack((cams.ravel(), pts.ravel())), C, N, args[1], args[2], args[0], 1.0) ** 2)
     assert abs(cost64 - rep.cost) <= (1e-9 if dtype == "f64" else 1e-4) * cost64
-    assert cost64 <= ref.cost * (1 + (1e-9 if dtype == "f64" else 1e-4)) and cost64 >= 0.9 * ref.cost
+    assert cost64 <= ref.cost * (1 + (1e-9 if dtype == "f64" else 1e-4))
+    if C == 4:
+        # from below: the minimum of the 13-parameter oracle's fun by independent exact optimisers (oracle.tight_optimum) from the
+        # device's solution; the larger rigs keep the basin guard only (dense SVD steps at 20 x 13 + 450 unknowns would dominate the suite)
+        best, _ = orc11.tight_optimum(cams, pts, *args, max_nfev=(80, 30), model=orc)
+        assert best * (1 - (1e-9 if dtype == "f64" else 1e-4)) <= cost64 <= best * (1 + 1e-3), (cost64, best, ref.cost)
+    else:
+        assert cost64 >= 0.9 * ref.cost, "basin guard only: scipy stops on ftol above the minimum (two-sided pin: the 4-camera case)"
     assert orc.rms_reprojection(cams, pts, *args) <= np.sqrt(2 * ref.cost / args[1].size) + (1e-6 if dtype == "f64" else 1e-3)
     # the tangential coefficients (truth ~1e-3, start 0) are recovered as well as the noise allows, i.e. as well as scipy does
     # (p1, p2 trade off against the principal point; observed errors 1e-4 .. 7e-4 for both solvers at 200 points per camera)
