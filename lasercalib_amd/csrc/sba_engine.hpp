@@ -31,9 +31,12 @@ struct Engine : EngineBase {
   bool dense_one_group = false;      // dense and <= 16 cameras: lane = (point, camera) kernels apply
   int nbs_dense = 1;                 // workgroups of k_backsub_dense
   // The lane = (point, camera) kernels (fused linearise + Schur, wide, dense back substitution) cost the DENSE instruction count
-  // whatever the visibility; below this fraction of the N x C slots filled the observation-driven three-pass path takes over.
-  // SBA_DENSE_MIN_VIS overrides it (measurements: profiles/r4_visibility_sweep.txt)
-  double dense_min_vis = 0.35;
+  // whatever the visibility; below this fraction of the N x C slots filled the observation-driven three-pass path would take over.
+  // Rounds 1-3 set it to 0.35 unmeasured.  Round 4 measured it (profiles/r4_visibility_sweep*.txt: 16 / 17 cameras, 10k and 50k points,
+  // fill 0.14 .. 0.45, both dtypes): the one-launch kernels win at EVERY fill a rig can have (two views of 16 cameras = 0.13: fp32
+  // 78 vs 102 us per iteration at 16 x 10k, 111 vs 163 at 17 x 10k, 118 vs 155 at 16 x 50k; fp64 212 vs 245) because the three-pass
+  // path is bound by its launches and pair kernels, not by the observation count.  So the threshold is 0; SBA_DENSE_MIN_VIS restores one.
+  double dense_min_vis = 0.0;
   bool fused_masked = false;         // the fused kernel runs with the visibility mask
   bool lin_pts_ok = false;           // f64, one group: the point linearisation runs inside k_schur_sym (LIN)
   bool masked_ok = false;            // one group, no duplicate (point, camera) pairs, not dense: visibility mask available
@@ -108,6 +111,7 @@ struct Engine : EngineBase {
   bool chol_big_back_one = true;        // SBA_CHOL_BIG_BACK=launches keeps one launch per block (rounds 1-3)
   bool chol_debug = false;
   bool schur_debug = false;
+  int schur_exp = 0;                  // SBA_SCHUR_EXP: timing experiments of k_schur_fused_bf3 (its results are wrong when set)
   int schur_debug_skip = 0;           // SBA_SCHUR_DEBUG=k: stamps of the (k+1)-th fused launch (k >= 1: one with the decision in its prologue)
   // multi-rank (one handle per GPU, points sharded, cameras replicated): RCCL communicator + exchange buffers
   DevBuf<double> raw_uv, raw_w;         // the caller's raw arrays on the device (dense fast path of upload)
@@ -217,6 +221,7 @@ struct Engine : EngineBase {
       chol_old = (std::string(e) == "old"); chol_ll = (std::string(e) != "blocked") && !chol_old; chol_ll_all = (std::string(e) == "ll");
     }
     if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
+    if (const char* e = getenv("SBA_SCHUR_EXP")) schur_exp = atoi(e);
     if (const char* e = getenv("SBA_CHOL_BIG_BACK")) chol_big_back_one = std::string(e) != "launches";
     if (const char* e = getenv("SBA_CHOL_F32")) chol_f32 = atoi(e) != 0;
     if (const char* e = getenv("SBA_CHOL_F32_TAU")) { char* end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0 && v < 1) chol_f32_tau = (float)v; }
@@ -753,7 +758,8 @@ struct Engine : EngineBase {
           hipLaunchKernelGGL(k_schur_fused_bf3, dim3(ksplit), dim3(SCHUR_THREADS), SchurBf3Cfg::LDS_BYTES, stream,
                              ps_lm(), fd, C, uv_pm.p, has_w ? w_pm.p : nullptr, pt_start.p, fused_masked ? vis_mask.p : (const uint16_t*)nullptr,
                              N, ksplit, D2p.p, gp.p, pfac.p,
-                             slabs.p, bpart.p, gdpart.p, cost_part.p, gm_out, (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr);
+                             slabs.p, bpart.p, gdpart.p, cost_part.p, gm_out, (schur_debug && schur_debug_skip == 0) ? schur_dbg.p : nullptr,
+                             schur_exp);
           d_state.p = fd.st_out;
           pending_decide = false;
           gmax_cur = gm_out;

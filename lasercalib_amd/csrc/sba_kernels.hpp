@@ -1798,7 +1798,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
     const float2* __restrict__ uv, const float* __restrict__ w, const int32_t* __restrict__ pt_start,
     const uint16_t* __restrict__ vis, int N, int ksplit, double* __restrict__ D2p, double* __restrict__ gp,
     float* __restrict__ pf, float* __restrict__ slabs, double* __restrict__ bpart, double* __restrict__ gdpart,
-    double* __restrict__ cost_part, double* __restrict__ gmax_part, long long* __restrict__ dbg) {
+    double* __restrict__ cost_part, double* __restrict__ gmax_part, long long* __restrict__ dbg,
+    int exp_flags /* timing experiments only (SBA_SCHUR_EXP; results are WRONG when set): 1 = no m / l planes, 2 = no U_c / g_c accumulation */) {
   extern __shared__ __align__(16) unsigned char smem[];
   using T = float;
   using Cfg = SchurBf3Cfg;
@@ -1996,16 +1997,19 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
             auto lo_f = [](unsigned pkd) -> float { return __builtin_bit_cast(float, pkd << 16); };
             auto hi_f = [](unsigned pkd) -> float { return __builtin_bit_cast(float, pkd & 0xffff0000u); };
             const unsigned h01 = pk(y[0], y[1]), h2 = pk1(y[2]);
-            const float r0 = y[0] - lo_f(h01), r1 = y[1] - hi_f(h01), r2 = y[2] - lo_f(h2);
-            const unsigned m01 = pk(r0, r1), m2 = pk1(r2);
-            const float s0 = r0 - lo_f(m01), s1 = r1 - hi_f(m01), s2 = r2 - lo_f(m2);
-            const unsigned l01 = pk(s0, s1), l2 = pk1(s2);
             unsigned char* dst = pbuf + lane_slot + e * (2 * Cfg::HALF_BYTES);
             *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h2);
-            *reinterpret_cast<uint2*>(dst + Cfg::PLANE * 2) = make_uint2(m01, m2);
-            *reinterpret_cast<uint2*>(dst + 2 * Cfg::PLANE * 2) = make_uint2(l01, l2);
+            if (!(exp_flags & 1)) {
+              const float r0 = y[0] - lo_f(h01), r1 = y[1] - hi_f(h01), r2 = y[2] - lo_f(h2);
+              const unsigned m01 = pk(r0, r1), m2 = pk1(r2);
+              const float s0 = r0 - lo_f(m01), s1 = r1 - hi_f(m01), s2 = r2 - lo_f(m2);
+              const unsigned l01 = pk(s0, s1), l2 = pk1(s2);
+              *reinterpret_cast<uint2*>(dst + Cfg::PLANE * 2) = make_uint2(m01, m2);
+              *reinterpret_cast<uint2*>(dst + 2 * Cfg::PLANE * 2) = make_uint2(l01, l2);
+            }
           });
         }
+        if (!(exp_flags & 2))
         static_for<0, NCP>([&](auto ac) {
           constexpr int a = decltype(ac)::value;
           static_for<a, NCP>([&](auto bc) {

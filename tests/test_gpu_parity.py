@@ -258,7 +258,23 @@ def test_tight_solve_is_an_optimum_the_reference_accepts(golden, tag):
     f9 = golden("f9_tight.npz")
     assert np.array_equal(f9[f"{tag}_uv"], p["uv"]) and np.array_equal(f9[f"{tag}_cams0"], p["cams0"])      # the same rig
     best = float(f9[f"{tag}_cost"])
-    assert best * (1 - 1e-9) <= rep.cost <= best * (1 + 1e-6), (rep.cost, best)
+    if float(f9[f"{tag}_optimality"]) < 1e-4:           # the independent optimisers converged (sparse): two-sided
+        assert best * (1 - 1e-9) <= rep.cost <= best * (1 + 1e-6), (rep.cost, best)
+    else:
+        # the two-camera rig: none of the independent optimisers converges within its cap (1 500 exact trust-region steps reach 23.5494,
+        # MINPACK 23.5232, a dense LM 23.65; stored gradient norm 95) -- their result is an upper bound only, and the pin from below is the
+        # solver-independent certificate: the gradient of the ORACLE's fun (sparse 3-point finite differences) vanishes at the device's point
+        assert rep.cost <= best, (rep.cost, best)
+        from scipy.optimize._numdiff import approx_derivative
+        x = np.hstack((cams.ravel(), pts.ravel()))
+        a = (cams.shape[0], pts.shape[0], p["ci"], p["pi"], p["uv"], 1.0)
+        J = approx_derivative(orc.fun, x, method="3-point", sparsity=orc.sparsity(*a[:4]), args=a)
+        g0 = approx_derivative(orc.fun, np.hstack((p["cams0"].ravel(), p["pts0"].ravel())), method="3-point", sparsity=orc.sparsity(*a[:4]), args=a)
+        x0 = np.hstack((p["cams0"].ravel(), p["pts0"].ravel()))
+        grad, grad0 = J.T @ orc.fun(x, *a), g0.T @ orc.fun(x0, *a)
+        # (1.2e6 at the initial guess, 11 at the device's point.  This rig's valley is long and nearly flat -- the reference's own tight solve
+        #  sits 1.3 % higher in cost with a gradient of 0.12 -- so the gradient is a weak certificate and the cost bound above does the work)
+        assert np.max(np.abs(grad)) <= 1e-4 * np.max(np.abs(grad0)), (np.max(np.abs(grad)), np.max(np.abs(grad0)))
     res, _, _ = orc.bundle_adjust(cams, pts, p["uv"], p["ci"], p["pi"], ftol=1e-8, max_nfev=20)
     assert res.cost >= rep.cost * (1 - 1e-6)            # scipy cannot lower it further
     eng = model.ModelEngine(p["cams0"], p["pts0"], p["uv"], p["ci"], p["pi"])
@@ -266,16 +282,18 @@ def test_tight_solve_is_an_optimum_the_reference_accepts(golden, tag):
     assert abs(rep.cost - out["cost"]) <= 1e-8 * out["cost"]
 
 
-@pytest.mark.parametrize("tag", ["cfg1", "sparse", "var"])
+@pytest.mark.parametrize("tag", ["sparse", "var"])
 def test_tight_optimum_two_sided_against_independent_exact_optimisers(golden, tag):
     """SURVEY 8(d)'s tight bar, two-sided: relative cost difference <= 1e-8 in fp64.  The pin is F9 (tests/golden/f9_tight.npz,
     oracle/make_golden.py f9): the minimum of the REFERENCE'S OWN `fun` found by scipy's TRF with the exact (SVD) trust-region
     subproblem on a dense finite-difference Jacobian and polished by MINPACK's lmder -- nothing of the device algorithm or of
     oracle/lm_schur_model.py is in it.  (The reference's own TRF/LSMR call stalls on ftol above this minimum: f4_solves.npz holds
-    23.7608 / 113.5547 for cfg1 / sparse at ftol 1e-8, the minimum is 23.4586 / 113.4915.)  Gauge-free summaries at 1e-6."""
+    23.7608 / 113.5547 for cfg1 / sparse at ftol 1e-8, the minimum is 23.4586 / 113.4915.)  Gauge-free summaries at 1e-6.
+    The third F9 rig, the two-camera cfg1, is not here: the independent optimisers do not converge on it within their caps (see
+    test_tight_solve_is_an_optimum_the_reference_accepts for what pins it instead)."""
     g = golden("f9_tight.npz")
     p = _f4(g, tag)
-    assert int(g[f"{tag}_status_minpack"]) > 0 or int(g[f"{tag}_status_trf_exact"]) > 0        # the pin itself converged
+    assert float(g[f"{tag}_optimality"]) < 1e-4        # the pin itself is a stationary point of the reference's fun (||J^T r||_inf; 1e5 at the start)
     cams, pts, rep, log = _solve(p, 1e-12, xtol=1e-12, gtol=1e-12)
     best = float(g[f"{tag}_cost"])
     assert rep.status in (1, 2, 3, 4)
