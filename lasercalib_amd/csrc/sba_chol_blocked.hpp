@@ -205,18 +205,24 @@ template <> struct CholNum<float> {
   }
 };
 
+// block layout in LDS: LD = row stride inside a 16 x 16 block, in elements of S
+template <typename S, int LDV = CholNum<S>::LD> struct CholLay {
+  static constexpr int LD = LDV, BS = CB * LDV;
+  static __device__ __forceinline__ int off(int r, int c) { return (r * (r + 1) / 2 + c) * BS; }
+};
+
 // chol16_wave for either scalar type.  a0 (S = float): the 16 diagonal entries of the DAMPED system as they were loaded; the
 // factorisation is refused (returns false) when a pivot L_ii^2 has sunk below tau * a0_i -- at tau ~ 2^-23 the pivot is the rounding
 // noise of its own diagonal entry and the rows behind it carry no information (the caller then factors in f64).
-template <typename S, bool NEWTON>
+template <typename S, bool NEWTON, typename L = CholLay<S>>
 __device__ __forceinline__ bool chol16_wave_t(S* __restrict__ blk, const S* __restrict__ a0 = nullptr, S tau = (S)0) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15;
   const bool ident = lane >= 16;
   S a[CB];
 #pragma unroll
-  for (int j = 0; j < CB; ++j) { const S v = blk[i * CholNum<S>::LD + j]; a[j] = ident ? ((j == i) ? (S)1 : (S)0) : v; }
-  S dg = blk[i * CholNum<S>::LD + i];
+  for (int j = 0; j < CB; ++j) { const S v = blk[i * L::LD + j]; a[j] = ident ? ((j == i) ? (S)1 : (S)0) : v; }
+  S dg = blk[i * L::LD + i];
   __builtin_amdgcn_wave_barrier();
   auto pivot = [](S x) -> S {
     if constexpr (NEWTON) return (S)rsqrt_nr((double)x);
@@ -240,45 +246,45 @@ __device__ __forceinline__ bool chol16_wave_t(S* __restrict__ blk, const S* __re
   }
   if (lane >= 16 && lane < 32) {
 #pragma unroll
-    for (int j = 0; j < CB; ++j) blk[i * CholNum<S>::LD + j] = a[j];     // row i of Linv^T (zero left of the diagonal)
+    for (int j = 0; j < CB; ++j) blk[i * L::LD + j] = a[j];     // row i of Linv^T (zero left of the diagonal)
   }
   bool ok = isfinite(chk) && chk > (S)0;
   if (a0) {                                                    // pivot growth test (wave-uniform pointer)
     __builtin_amdgcn_wave_barrier();
-    const S li = blk[i * CholNum<S>::LD + i];                             // 1 / L_ii
+    const S li = blk[i * L::LD + i];                             // 1 / L_ii
     const bool sunk = lane < 16 && !(((S)1 / (li * li)) >= tau * a0[i]);
     ok = ok && !__any(sunk);
   }
   return ok;
 }
 
-template <typename S>
+template <typename S, typename L = CholLay<S>>
 __device__ __forceinline__ void chol_panel_block_t(S* __restrict__ Ablk, const S* __restrict__ LinvT) {
   const int lane = threadIdx.x & 63;
-  const S* Pa = Ablk + (lane & 15) * CholNum<S>::LD + (lane >> 4);
-  const S* Pl = LinvT + (lane >> 4) * CholNum<S>::LD + (lane & 15);
+  const S* Pa = Ablk + (lane & 15) * L::LD + (lane >> 4);
+  const S* Pl = LinvT + (lane >> 4) * L::LD + (lane & 15);
   typename Mfma<S>::acc_t acc = {0, 0, 0, 0};
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) acc = Mfma<S>::mma(Pa[4 * ks], Pl[4 * ks * CholNum<S>::LD], acc);
+  for (int ks = 0; ks < 4; ++ks) acc = Mfma<S>::mma(Pa[4 * ks], Pl[4 * ks * L::LD], acc);
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) Ablk[Mfma<S>::row_of(lane, rg) * CholNum<S>::LD + (lane & 15)] = acc[rg];
+  for (int rg = 0; rg < 4; ++rg) Ablk[Mfma<S>::row_of(lane, rg) * L::LD + (lane & 15)] = acc[rg];
   __builtin_amdgcn_wave_barrier();
 }
 
 // (see chol_panel_update_diag: the transposed panel product's accumulators are the operands of the downdate; with the f32 MFMA the
 //  accumulator rows are 4 (lane >> 4) + reg instead of (lane >> 4) + 4 reg -- another order of the same sixteen k, used on both sides)
-template <typename S>
+template <typename S, typename L = CholLay<S>>
 __device__ __forceinline__ void chol_panel_update_diag_t(S* __restrict__ Pblk, const S* __restrict__ LinvT, S* __restrict__ Dt) {
   const int lane = threadIdx.x & 63;
-  const S* Pa = Pblk + (lane & 15) * CholNum<S>::LD + (lane >> 4);
-  const S* Pl = LinvT + (lane >> 4) * CholNum<S>::LD + (lane & 15);
+  const S* Pa = Pblk + (lane & 15) * L::LD + (lane >> 4);
+  const S* Pl = LinvT + (lane >> 4) * L::LD + (lane & 15);
   typename Mfma<S>::acc_t d;
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) d[rg] = Dt[Mfma<S>::row_of(lane, rg) * CholNum<S>::LD + (lane & 15)];
+  for (int rg = 0; rg < 4; ++rg) d[rg] = Dt[Mfma<S>::row_of(lane, rg) * L::LD + (lane & 15)];
   typename Mfma<S>::acc_t pt = {0, 0, 0, 0};
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) pt = Mfma<S>::mma(Pl[4 * ks * CholNum<S>::LD], Pa[4 * ks], pt);
+  for (int ks = 0; ks < 4; ++ks) pt = Mfma<S>::mma(Pl[4 * ks * L::LD], Pa[4 * ks], pt);
   __builtin_amdgcn_wave_barrier();
   typename Mfma<S>::acc_t pp = {0, 0, 0, 0};
 #pragma unroll
@@ -286,41 +292,47 @@ __device__ __forceinline__ void chol_panel_update_diag_t(S* __restrict__ Pblk, c
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) d[rg] -= pp[rg];
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) Pblk[(lane & 15) * CholNum<S>::LD + Mfma<S>::row_of(lane, rg)] = pt[rg];
+  for (int rg = 0; rg < 4; ++rg) Pblk[(lane & 15) * L::LD + Mfma<S>::row_of(lane, rg)] = pt[rg];
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) Dt[Mfma<S>::row_of(lane, rg) * CholNum<S>::LD + (lane & 15)] = d[rg];
+  for (int rg = 0; rg < 4; ++rg) Dt[Mfma<S>::row_of(lane, rg) * L::LD + (lane & 15)] = d[rg];
   __builtin_amdgcn_wave_barrier();
 }
 
-// What k_cholesky_blocked shares between its two scalar types (static LDS, the same for both)
-struct CholbShared {
+// What k_cholesky_blocked shares between its scalar types (static LDS).  MAXNB = block rows the kernel is built for: 11 (176 unknowns,
+// both scalar types fit the LDS) or 16 (256 unknowns: the f32 triangle only -- round 4, fp32 rigs of 17 .. 23 cameras).
+template <int MAXNB> struct CholbShared {
   int fail;
-  short rc[CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2];   // block index -> (r << 8 | c)
-  double dd[CHOLB_MAX_NB * CB];                       // lam * D2c (diagonal damping); 0 in the padded tail
-  double x[CHOLB_MAX_NB * CB];                        // rhs in, solution out
+  short rc[MAXNB * (MAXNB + 1) / 2];                  // block index -> (r << 8 | c)
+  double dd[MAXNB * CB];                              // lam * D2c (diagonal damping); 0 in the padded tail
+  double x[MAXNB * CB];                               // rhs in, solution out
 };
-constexpr int CHOLB_BPR = CHOLB_LDS_THREADS / 128;                                  // blocks of the first column per load round (128 threads each)
-constexpr int CHOLB_U0 = (CHOLB_MAX_NB + CHOLB_BPR - 1) / CHOLB_BPR;                // rounds for the first block column
-constexpr int CHOLB_NREM = CHOLB_MAX_NB * (CHOLB_MAX_NB - 1) / 2;                   // 55 other blocks
-constexpr int CHOLB_TREM = CHOLB_LDS_THREADS - 64;                                  // loaded by waves 1..7
-constexpr int CHOLB_U1 = (CHOLB_NREM * 128 + CHOLB_TREM - 1) / CHOLB_TREM;          // 16 rounds
+template <int MAXNB> struct CholbPre {
+  static constexpr int BPR = CHOLB_LDS_THREADS / 128;                      // blocks of the first column per load round (128 threads each)
+  static constexpr int U0 = (MAXNB + BPR - 1) / BPR;                       // rounds for the first block column
+  static constexpr int NREM = MAXNB * (MAXNB - 1) / 2;                     // the other blocks
+  static constexpr int TREM = CHOLB_LDS_THREADS - 64;                      // loaded by waves 1..7
+  static constexpr int U1_ALL = (NREM * 128 + TREM - 1) / TREM;            // rounds that would cover them all (16 at 11 block rows, 35 at 16)
+  static constexpr int U1 = U1_ALL < 16 ? U1_ALL : 16;                     // ... of which this many are prefetched into registers (2 doubles each);
+                                                                           // the blocks beyond them are fetched after the prefetched ones are in LDS
+};
 
 // Factorisation + both substitutions in scalar type S on the block triangle in dynamic LDS.  PREFETCHED: the system's entries are in
 // the c0 / c1 registers the kernel requested in its first instructions; otherwise (second attempt after a refused f32 factorisation)
 // they are read from E here.  Returns the failure flag; the solution is left in sh.x.
-template <typename S, bool NEWTON, bool PREFETCHED>
-__device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, CholbShared& sh, const double* __restrict__ E, const int n,
-                                           double (&c0)[CHOLB_U0][2], double (&c1)[CHOLB_U1][2], const int (&rc1)[CHOLB_U1],
+template <typename S, bool NEWTON, bool PREFETCHED, int MAXNB, typename L = CholLay<S>>
+__device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, CholbShared<MAXNB>& sh, const double* __restrict__ E, const int n,
+                                           double (&c0)[CholbPre<MAXNB>::U0][2], double (&c1)[CholbPre<MAXNB>::U1][2], const int (&rc1)[CholbPre<MAXNB>::U1],
                                            const S tau, long long* __restrict__ dbg, int& nstamp) {
 #define CHOL_STAMP() do { if (dbg && threadIdx.x == 0) dbg[nstamp] = clock64(); ++nstamp; } while (0)
-  constexpr int BPR = CHOLB_BPR, U0 = CHOLB_U0, TREM = CHOLB_TREM, U1 = CHOLB_U1;
+  using Pre = CholbPre<MAXNB>;
+  constexpr int BPR = Pre::BPR, U0 = Pre::U0, TREM = Pre::TREM, U1 = Pre::U1;
   constexpr bool F32 = std::is_same<S, float>::value;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nb = (n + CB - 1) / CB;
   const int n16 = nb * CB;
   const int nblk = nb * (nb + 1) / 2;
   S* Lb = reinterpret_cast<S*>(smem);                          // nblk blocks
-  S* s_y = Lb + nblk * CholNum<S>::BS;                                    // [n16]  rhs -> y -> x
+  S* s_y = Lb + nblk * L::BS;                                    // [n16]  rhs -> y -> x
   S* s_a0 = s_y + n16;                                         // [n16]  damped diagonal as loaded (growth test of the f32 factorisation)
   const int s4 = tid >> 7, ii0 = (tid >> 3) & 15, jp0 = tid & 7;
   auto fix = [&](int I, int J, double& v0, double& v1) {       // padded tail = identity
@@ -338,7 +350,7 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
         const int r = BPR * u + s4;
         if (r < nb) {
           const int I = r * CB + ii, J = 2 * jp;
-          S* dst = Lb + CholNum<S>::off(r, 0) + ii * CholNum<S>::LD + J;
+          S* dst = Lb + L::off(r, 0) + ii * L::LD + J;
           const double v0 = c0[u][0] + ((I == J && I < n) ? sh.dd[I] : 0.0), v1 = c0[u][1] + ((I == J + 1 && I < n) ? sh.dd[I] : 0.0);
           dst[0] = (S)v0;
           dst[1] = (S)v1;
@@ -359,7 +371,7 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
           const int rc = rc1[u];
           const int br = rc >> 8, bc = rc & 255;
           const int ii = (e >> 3) & 15, I = br * CB + ii, J = bc * CB + 2 * (e & 7);
-          S* dst = Lb + CholNum<S>::off(br, bc) + ii * CholNum<S>::LD + 2 * (e & 7);
+          S* dst = Lb + L::off(br, bc) + ii * L::LD + 2 * (e & 7);
           fix(I, J, c1[u][0], c1[u][1]);
           double d0 = 0.0, d1 = 0.0;
           if (br == bc) {              // only a diagonal block carries damping (uniform for the 128 threads of a block)
@@ -372,6 +384,41 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
           if (F32 && br == bc && I == J + 1) s_a0[I] = (S)(c1[u][1] + d1);
         }
       }
+      if constexpr (Pre::U1 < Pre::U1_ALL) {
+        // the blocks the prefetch registers did not cover (more than 11 block rows): two doubles per thread and round, four rounds in flight
+        const int first = U1 * TREM, last = (nblk - nb) * 128;
+        for (int e0 = first + (tid - 64); e0 < last; e0 += 4 * TREM) {
+          double v[4][2];
+          int rcq[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int e = min(e0 + q * TREM, last - 1);
+            const int k = e >> 7;
+            int cc = 1, base = 0;
+            while (k >= base + (nb - cc) && cc < nb) { base += nb - cc; ++cc; }
+            rcq[q] = ((cc + (k - base)) << 8) | cc;
+            const int I = (cc + (k - base)) * CB + ((e >> 3) & 15), J = cc * CB + 2 * (e & 7);
+            const double* qp = E + (size_t)min(I, n - 1) * n + min(J, n - 1);
+            v[q][0] = qp[0]; v[q][1] = qp[(J + 1 < n && I < n) ? 1 : 0];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * TREM;
+            if (e < last) {
+              const int br = rcq[q] >> 8, bc = rcq[q] & 255;
+              const int ii = (e >> 3) & 15, I = br * CB + ii, J = bc * CB + 2 * (e & 7);
+              S* dst = Lb + L::off(br, bc) + ii * L::LD + 2 * (e & 7);
+              fix(I, J, v[q][0], v[q][1]);
+              double d0 = 0.0, d1 = 0.0;
+              if (br == bc) { d0 = (I == J && I < n) ? sh.dd[I] : 0.0; d1 = (I == J + 1 && I < n) ? sh.dd[I] : 0.0; }
+              dst[0] = (S)(v[q][0] + d0);
+              dst[1] = (S)(v[q][1] + d1);
+              if (F32 && br == bc && I == J) s_a0[I] = (S)(v[q][0] + d0);
+              if (F32 && br == bc && I == J + 1) s_a0[I] = (S)(v[q][1] + d1);
+            }
+          }
+        }
+      }
     }
   } else {
     // second attempt: everything once more from E (L2 by now), no overlap with the first tile
@@ -380,14 +427,14 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
       const int ii = (e >> 4) & 15, jj = e & 15, I = br * CB + ii, J = bc * CB + jj;
       double v = (I < n && J < n) ? E[(size_t)I * n + J] : ((I == J) ? 1.0 : 0.0);
       if (I == J && I < n) v += sh.dd[I];
-      Lb[CholNum<S>::off(br, bc) + ii * CholNum<S>::LD + jj] = (S)v;
+      Lb[L::off(br, bc) + ii * L::LD + jj] = (S)v;
       if (F32 && I == J) s_a0[I] = (S)v;
     }
     __syncthreads();
     CHOL_STAMP();
   }
   if (wid == 0) {
-    if (!chol16_wave_t<S, NEWTON>(Lb + CholNum<S>::off(0, 0), F32 ? s_a0 : nullptr, tau)) { if (lane == 0) sh.fail = 1; }
+    if (!chol16_wave_t<S, NEWTON, L>(Lb + L::off(0, 0), F32 ? s_a0 : nullptr, tau)) { if (lane == 0) sh.fail = 1; }
   }
   __syncthreads();
   CHOL_STAMP();
@@ -395,19 +442,19 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
   constexpr int NW = CHOLB_LDS_THREADS / 64;
   for (int jb = 0; jb < nb && !sh.fail; ++jb) {
     const int m = (nb - jb - 1) * CB;              // rows below the diagonal block
-    const S* LinvT = Lb + CholNum<S>::off(jb, jb);
+    const S* LinvT = Lb + L::off(jb, jb);
     // ---- B: L21 = A21 Linv^T block by block; wave 0 takes the block right below the diagonal and downdates the next
     //      diagonal tile with it, the last wave forward-solves the rhs block
     if (wid == 0) {
-      if (jb + 1 < nb) chol_panel_update_diag_t<S>(Lb + CholNum<S>::off(jb + 1, jb), LinvT, Lb + CholNum<S>::off(jb + 1, jb + 1));
+      if (jb + 1 < nb) chol_panel_update_diag_t<S, L>(Lb + L::off(jb + 1, jb), LinvT, Lb + L::off(jb + 1, jb + 1));
     } else {
-      for (int r = jb + 2 + (wid - 1); r < nb; r += NW - 1) chol_panel_block_t<S>(Lb + CholNum<S>::off(r, jb), LinvT);
+      for (int r = jb + 2 + (wid - 1); r < nb; r += NW - 1) chol_panel_block_t<S, L>(Lb + L::off(r, jb), LinvT);
       if (wid == NW - 1) {
         // y_blk = Linv rhs_blk :  y[i] = sum_k LinvT[k][i] rhs[k]   (lane = (part, i): 4 terms each, then 2 swaps)
         const int i = lane & 15, part = lane >> 4;
         S x = 0;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { const int k = part + 4 * kk; x += LinvT[k * CholNum<S>::LD + i] * s_y[jb * CB + k]; }
+        for (int kk = 0; kk < 4; ++kk) { const int k = part + 4 * kk; x += LinvT[k * L::LD + i] * s_y[jb * CB + k]; }
         x = CholNum<S>::xrow(x);
         __builtin_amdgcn_wave_barrier();
         if (part == 0) s_y[jb * CB + i] = x;
@@ -418,7 +465,7 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
     // ---- C: look-ahead factorisation of the next diagonal tile (wave 0) | rhs tail + trailing update (waves 1..7)
     if (wid == 0) {
       if (jb + 1 < nb) {
-        if (!chol16_wave_t<S, NEWTON>(Lb + CholNum<S>::off(jb + 1, jb + 1), F32 ? s_a0 + (jb + 1) * CB : nullptr, tau)) { if (lane == 0) sh.fail = 1; }
+        if (!chol16_wave_t<S, NEWTON, L>(Lb + L::off(jb + 1, jb + 1), F32 ? s_a0 + (jb + 1) * CB : nullptr, tau)) { if (lane == 0) sh.fail = 1; }
       }
     } else {
       // The wave that shares its SIMD with wave 0 (wave 4: waves go round the four SIMDs, tools/micro/hw_id.hip) takes the light
@@ -427,7 +474,7 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
       if (wid == 4) {
         // rhs tail: y_i -= sum_k L21[i][k] y_blk[k]
         for (int t = lane; t < m; t += 64) {
-          const S* row = Lb + CholNum<S>::off(jb + 1 + (t >> 4), jb) + (t & 15) * CholNum<S>::LD;
+          const S* row = Lb + L::off(jb + 1 + (t >> 4), jb) + (t & 15) * L::LD;
           S s0 = 0, s1 = 0;
 #pragma unroll
           for (int k = 0; k < CB; k += 2) { s0 += row[k] * s_y[jb * CB + k]; s1 += row[k + 1] * s_y[jb * CB + k + 1]; }
@@ -450,16 +497,16 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
         if (t < t_hi) {
           const int rc = sh.rc[t];
           int r = jb + 1 + (rc >> 8), c = jb + 1 + (rc & 255);
-          const int po = (lane & 15) * CholNum<S>::LD + (lane >> 4);              // operand pattern: [row lane & 15][k = 4 ks + (lane >> 4)]
-          const int to = Mfma<S>::row_of(lane, 0) * CholNum<S>::LD + (lane & 15);   // accumulator pattern: [row_of(lane, reg)][col lane & 15]
-          constexpr int trs = F32 ? CholNum<S>::LD : 4 * CholNum<S>::LD;                      // ... whose rows are `trs` apart from register to register
+          const int po = (lane & 15) * L::LD + (lane >> 4);              // operand pattern: [row lane & 15][k = 4 ks + (lane >> 4)]
+          const int to = Mfma<S>::row_of(lane, 0) * L::LD + (lane & 15);   // accumulator pattern: [row_of(lane, reg)][col lane & 15]
+          constexpr int trs = F32 ? L::LD : 4 * L::LD;                      // ... whose rows are `trs` apart from register to register
           while (t < t_hi) {
-            const S* Ap = Lb + CholNum<S>::off(r, jb) + po;
+            const S* Ap = Lb + L::off(r, jb) + po;
             S a[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) a[ks] = Ap[4 * ks];
-            S* D = Lb + CholNum<S>::off(r, c) + to;
-            const S* Bp = Lb + CholNum<S>::off(c, jb) + po;
+            S* D = Lb + L::off(r, c) + to;
+            const S* Bp = Lb + L::off(c, jb) + po;
             for (; c <= r && t < t_hi; ++c, ++t) {
               S bq[4];
 #pragma unroll
@@ -471,8 +518,8 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
               for (int ks = 0; ks < 4; ++ks) prod = Mfma<S>::mma(a[ks], bq[ks], prod);
 #pragma unroll
               for (int rg = 0; rg < 4; ++rg) D[rg * trs] = acc[rg] - prod[rg];
-              D += CholNum<S>::BS;
-              Bp += (c + 1) * CholNum<S>::BS;                                      // CholNum<S>::off(c + 1, jb) - CholNum<S>::off(c, jb)
+              D += L::BS;
+              Bp += (c + 1) * L::BS;                                      // L::off(c + 1, jb) - L::off(c, jb)
             }
             ++r;
             c = jb + 1;
@@ -492,7 +539,7 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
     for (int b = nb - 1; b >= 0; --b) {
       if (wid == 0) {
         const int j = lane & 15, part = lane >> 4;
-        const S* LiT = Lb + CholNum<S>::off(b, b) + j * CholNum<S>::LD;    // row j of Linv^T
+        const S* LiT = Lb + L::off(b, b) + j * L::LD;    // row j of Linv^T
         S x = 0;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) { const int i = part + 4 * ii; x += LiT[i] * s_y[b * CB + i]; }
@@ -502,10 +549,10 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
       }
       __syncthreads();
       if (tid < b * CB) {
-        const S* col = Lb + CholNum<S>::off(b, tid >> 4) + (tid & 15);
+        const S* col = Lb + L::off(b, tid >> 4) + (tid & 15);
         S s0 = 0, s1 = 0;
 #pragma unroll
-        for (int i = 0; i < CB; i += 2) { s0 += col[i * CholNum<S>::LD] * s_y[b * CB + i]; s1 += col[(i + 1) * CholNum<S>::LD] * s_y[b * CB + i + 1]; }
+        for (int i = 0; i < CB; i += 2) { s0 += col[i * L::LD] * s_y[b * CB + i]; s1 += col[(i + 1) * L::LD] * s_y[b * CB + i + 1]; }
         s_y[tid] -= s0 + s1;
       }
       __syncthreads();
@@ -523,7 +570,7 @@ __device__ __forceinline__ bool cholb_core(unsigned char* __restrict__ smem, Cho
 // factorisation is almost always followed by a refused f64 one (S carries the 1e-7 rounding of its f32 products either way,
 // tools/chol_f32_model.py), so the repeat costs little; for a caller that hands sba_lm_solve_trial an arbitrary system it is what
 // keeps the answer right (tests/test_gpu_cholesky.py: condition 1e9).
-template <typename T>
+template <typename T, int MAXNB = CHOLB_MAX_NB, int LD32 = 20>
 __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
     const double* __restrict__ E /* summed exchange buffer [S | rhs | diagU | gc | cost] */, int C,
     LMState* __restrict__ st, double* __restrict__ D2c, const ParamSets<T> ps,
@@ -546,7 +593,9 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   const double* dU = rhs + n;
   const double* gct = dU + n;
   const bool pair_ok = (n & 1) == 0;
-  constexpr int BPR = CHOLB_BPR, U0 = CHOLB_U0, TREM = CHOLB_TREM, U1 = CHOLB_U1;
+  using Pre = CholbPre<MAXNB>;
+  using L32 = CholLay<float, LD32>;
+  constexpr int BPR = Pre::BPR, U0 = Pre::U0, TREM = Pre::TREM, U1 = Pre::U1;
   double c0[U0][2];
   const int nlast = n - 1;
   auto addr = [&](int I, int J) { return E + (size_t)min(I, nlast) * n + min(J, nlast - 1 + (pair_ok ? 0 : 1)); };
@@ -603,7 +652,7 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   const int nb = (n + CB - 1) / CB;
   const int n16 = nb * CB;
   const int nblk = nb * (nb + 1) / 2;
-  __shared__ CholbShared sh;
+  __shared__ CholbShared<MAXNB> sh;
   __shared__ double s_scr[4][CHOLB_LDS_THREADS / 64];
   const double lam = st->lam;
   const bool fresh = st->fresh != 0;
@@ -638,24 +687,32 @@ __global__ __launch_bounds__(CHOLB_LDS_THREADS) void k_cholesky_blocked(
   }
   __syncthreads();
   bool fail;
-  if constexpr (std::is_same<T, float>::value) {
+  if constexpr (MAXNB > CHOLB_MAX_NB) {
+    // more than 176 unknowns: only the f32 triangle fits the LDS.  A refused factorisation raises LMState::chol_retry and leaves the
+    // step to the f64 kernel launched behind this one (k_cholesky_ll with only_if_retry), which otherwise returns at once.
+    static_assert(std::is_same<T, float>::value, "the 16-block-row kernel exists for the fp32 engine only");
+    fail = cholb_core<float, false, true, MAXNB, L32>(smem, sh, E, n, c0, c1, rc1, tau32, dbg, nstamp);
+    if (tid == 0) { st->chol_retry = fail ? 1 : 0; if (fail) st->chol_f64_retries += 1; }
+    if (fail) return;                     // (block-uniform) nothing of the step has been written
+  } else if constexpr (std::is_same<T, float>::value) {
     if (use_f32) {
-      fail = cholb_core<float, false, true>(smem, sh, E, n, c0, c1, rc1, tau32, dbg, nstamp);
+      fail = cholb_core<float, false, true, MAXNB, L32>(smem, sh, E, n, c0, c1, rc1, tau32, dbg, nstamp);
       if (fail) {                                 // refused: once more in f64, from E (sh.x still holds the right-hand side)
         __syncthreads();
         if (tid == 0) sh.fail = 0;
         __syncthreads();
-        fail = cholb_core<double, true, false>(smem, sh, E, n, c0, c1, rc1, 0.0, dbg, nstamp);      // (refined pivots: this pass is about the answer, not the time)
+        fail = cholb_core<double, true, false, MAXNB>(smem, sh, E, n, c0, c1, rc1, 0.0, dbg, nstamp);      // (refined pivots: this pass is about the answer, not the time)
         if (tid == 0) atomicAdd(&st->chol_f64_retries, 1);
       }
     } else {
-      fail = cholb_core<double, PIV_NEWTON, true>(smem, sh, E, n, c0, c1, rc1, 0.0, dbg, nstamp);
+      fail = cholb_core<double, PIV_NEWTON, true, MAXNB>(smem, sh, E, n, c0, c1, rc1, 0.0, dbg, nstamp);
     }
   } else {
-    fail = cholb_core<double, PIV_NEWTON, true>(smem, sh, E, n, c0, c1, rc1, 0.0, dbg, nstamp);
+    fail = cholb_core<double, PIV_NEWTON, true, MAXNB>(smem, sh, E, n, c0, c1, rc1, 0.0, dbg, nstamp);
   }
   double pred = 0, dx2 = 0, x2 = 0, gm = 0;
-  __shared__ double s_cnew[CHOLB_MAX_NB * CB];       // the trial cameras once more in LDS: the CamPre rebuild below reads them
+  __shared__ double s_cnew[CHOLB_LDS_THREADS]; // the trial cameras once more in LDS (one per thread: with shared intrinsics there are more camera
+                                               // parameters than system rows -- 24 cameras tie to 195 unknowns but keep 264 parameters): the CamPre rebuild below reads them
   if (tid < ncam) {                                  // from there instead of waiting for its own global stores to come back
     const double d = fail ? 0.0 : sh.x[tie ? tie[tid] : tid];
     delta_c[tid] = d;

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
     LMState* __restrict__ st, double* __restrict__ D2c, const ParamSets<T> ps,
     double* __restrict__ delta_c, int n_sys, const int32_t* __restrict__ tie, const int32_t* __restrict__ first,
     double* __restrict__ W /* nb(nb+1)/2 blocks of 16x16 (cs_blk order): L blocks, Linv^T on the diagonal */,
-    long long* __restrict__ dbg) {
+    long long* __restrict__ dbg,
+    int only_if_retry /* 1: run only when the f32-lane factorisation in front of this launch refused the system (LMState::chol_retry) */) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr bool PIV_NEWTON = !std::is_same<T, float>::value;
   constexpr int NW = CLL_THREADS / 64;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(CLL_THREADS) void k_cholesky_ll(
   const int tclamp = min(tid, nlast);
   double in_d = D2c[tclamp], in_u = dU[tclamp], in_r = rhs[tclamp];
   const double my_g = (tid < n) ? gct[tid] : 0.0;
-  if (st->status >= 0) return;
+  if (st->status >= 0 || (only_if_retry && !st->chol_retry)) return;
   const int cur_ = ps_cur(ps, st);
   const double* __restrict__ cams = ps.cams[cur_];
   double* __restrict__ cams_new = ps.cams[cur_ ^ 1];

@@ -277,6 +277,12 @@ struct Engine : EngineBase {
     //  right-hand side, trial cameras -- comes on top of it and both must fit the 160 KB of a CU)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)((CHOLB_MAX_NB * (CHOLB_MAX_NB + 1) / 2 * CBS + 2 * CHOLB_MAX_NB * CB) * sizeof(double))));
+    if constexpr (sizeof(T) == 4) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T, 16, 20>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)((14 * 15 / 2 * CB * 20 + 2 * 14 * CB) * sizeof(float))));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_blocked<T, 16, 17>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)((16 * 17 / 2 * CB * 17 + 2 * 16 * CB) * sizeof(float))));
+    }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_ll<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
@@ -1439,9 +1445,29 @@ struct Engine : EngineBase {
         const int nb = (n_sys + CB - 1) / CB;
         if (chol_work.n < (size_t)nb * (nb + 1) / 2 * CB * CB) chol_work.alloc((size_t)CLL_MAX_NB * (CLL_MAX_NB + 1) / 2 * CB * CB);
         if (chol_debug && chol_dbg.n < 128) { chol_dbg.alloc(128); chol_dbg.zero(stream); }
+        // fp32 engine (round 4): the right-looking all-in-LDS kernel on f32 lanes in front of it (the f32 triangle of up to 16 block
+        // rows fits the LDS: 20-float rows up to 14 block rows, 17-float rows at 15 and 16); the f64 kernel then only runs when that
+        // factorisation refused the system (LMState::chol_retry)
+        int only_if_retry = 0;
+        if constexpr (sizeof(T) == 4) {
+          if (chol_f32 && !chol_ll_all && n_sys > CHOL_LDS_MAX_N && C * NCP <= CHOLB_LDS_THREADS) {
+            only_if_retry = 1;
+            if (nb <= 14) {
+              const size_t lds32 = ((size_t)(nb * (nb + 1) / 2) * CB * 20 + 2 * (size_t)nb * CB) * sizeof(float);
+              hipLaunchKernelGGL((k_cholesky_blocked<T, 16, 20>), dim3(1), dim3(CHOLB_LDS_THREADS), lds32, stream, Esys, C, d_state.p, D2c.p,
+                                 ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr,
+                                 (long long*)nullptr, 1, chol_f32_tau);
+            } else {
+              const size_t lds32 = ((size_t)(nb * (nb + 1) / 2) * CB * 17 + 2 * (size_t)nb * CB) * sizeof(float);
+              hipLaunchKernelGGL((k_cholesky_blocked<T, 16, 17>), dim3(1), dim3(CHOLB_LDS_THREADS), lds32, stream, Esys, C, d_state.p, D2c.p,
+                                 ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr,
+                                 (long long*)nullptr, 1, chol_f32_tau);
+            }
+          }
+        }
         hipLaunchKernelGGL(k_cholesky_ll<T>, dim3(1), dim3(CLL_THREADS), CLL_LDS_BYTES, stream, Esys, C, d_state.p, D2c.p,
                            ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr, chol_work.p,
-                           chol_debug ? chol_dbg.p : nullptr);
+                           chol_debug ? chol_dbg.p : nullptr, only_if_retry);
         if (chol_debug) {
           std::vector<long long> st(128);
           HIPCHK(hipMemcpyAsync(st.data(), chol_dbg.p, 128 * sizeof(long long), hipMemcpyDeviceToHost, stream));
@@ -1463,7 +1489,7 @@ struct Engine : EngineBase {
           fprintf(stderr, " backsub %lld  epilogue %lld  total %lld\n", st[3 + 2 * nb] - st[2 + 2 * nb], st[4 + 2 * nb] - st[3 + 2 * nb], st[4 + 2 * nb] - st[0]);
           chol_debug = false;
         }
-      } else if (n_sys <= CHOL_LDS_MAX_N && !chol_old) {
+      } else if (n_sys <= CHOL_LDS_MAX_N && !chol_old && C * NCP <= CHOLB_LDS_THREADS) {
         const int nb = (n_sys + CB - 1) / CB;
         const size_t lds = ((size_t)(nb * (nb + 1) / 2) * CBS + 2 * (size_t)nb * CB) * sizeof(double);
         if (chol_debug && chol_dbg.n == 0) { chol_dbg.alloc(64); }

@@ -79,6 +79,7 @@ struct LMState {
   int cur;           // parity of accepted steps (which host-side buffer pair is "current")
   int comm_fail;     // set by k_ipc_gate when a peer rank did not reach an exchange in time (sba_ipc.hpp): the solve stops, the host reports it
   int chol_f64_retries;   // fp32 engine: reduced systems whose f32 factorisation was refused and that were factored again in f64 (k_cholesky_blocked)
+  int chol_retry;         // the f32-lane factorisation of 177 .. 256 unknowns refused this system: the f64 kernel launched behind it takes over
 };
 __device__ inline bool lm_done(const LMState* st) { return st != nullptr && st->status >= 0; }
 template <typename T> __device__ inline int ps_cur(const ParamSets<T>& ps, const LMState* st) { return (ps.base ^ (st ? st->cur : 0)) & 1; }

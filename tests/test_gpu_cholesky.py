@@ -72,8 +72,8 @@ def test_reduced_system_solve_matches_numpy(monkeypatch, C, dtype, mode):
     ref = np.linalg.solve(A, rhs)
     # f64 engine: pivots refined to 4e-15; f32 engine, f64 factorisation (more than 176 unknowns, or SBA_CHOL=ll / SBA_CHOL_F32=0): the
     # 5e-8 hardware estimate of 1/sqrt is used as it is, which perturbs the factored matrix by 1e-7 relative =>
-    # solution error <= cond * 1e-7; f32 engine up to 176 unknowns (round 4): the factorisation runs on f32 lanes, cond * 1e-6
-    f32_lanes = dtype == "f32" and n <= 176 and mode != "ll"
+    # solution error <= cond * 1e-7; f32 engine up to 256 unknowns (round 4): the factorisation runs on f32 lanes, cond * 1e-6
+    f32_lanes = dtype == "f32" and ((n <= 176 and mode != "ll") or (176 < n <= 256 and mode == "default"))
     tol = 1e-9 if dtype == "f64" else 1e3 * (1e-6 if f32_lanes else 2e-7)
     assert np.max(np.abs(step - ref)) <= tol * np.max(np.abs(ref)), np.max(np.abs(step - ref)) / np.max(np.abs(ref))
 
@@ -132,6 +132,37 @@ def test_f32_lane_factorisation_of_the_fp32_engine(monkeypatch, C):
     step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
     ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
     assert retries == 0 and np.max(np.abs(step - ref)) <= 1e4 * 2e-7 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("C", [17, 20, 23])
+def test_f32_lane_factorisation_between_177_and_256_unknowns(monkeypatch, C):
+    """fp32 engine, 17 .. 23 cameras: the same right-looking kernel built for 16 block rows (only the f32 triangle fits the LDS: 20-float
+    rows up to 14 block rows, 17-float rows beyond) runs in front of k_cholesky_ll, which then only runs when the f32 factorisation
+    refused the system (LMState::chol_retry).  Bars: error <= cond * 1e-6 for cond <= 1e5 without a repeat; at cond 1e9 and for an
+    indefinite system the repeat is taken (the latter still ends as a zero step)."""
+    monkeypatch.delenv("SBA_CHOL", raising=False)
+    monkeypatch.delenv("SBA_CHOL_F32", raising=False)
+    rng = np.random.default_rng(400 + C)
+    n = 11 * C
+    rhs = rng.standard_normal(n)
+    dU = np.ones(n)
+    for cond in (1e2, 1e4, 1e5):
+        S = _spd(n, rng, cond=cond)
+        step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+        ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
+        err = np.max(np.abs(step - ref)) / np.max(np.abs(ref))
+        assert retries == 0 and err <= cond * 1e-6, (cond, retries, err)
+    S = _spd(n, rng, cond=1e9)
+    step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+    assert retries == 1 and np.all(np.isfinite(step))
+    S[n - 5, n - 5] = -1.0
+    step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+    assert retries == 1 and np.all(step == 0.0)
+    monkeypatch.setenv("SBA_CHOL_F32", "0")
+    S = _spd(n, rng, cond=1e3)
+    step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+    ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
+    assert retries == 0 and np.max(np.abs(step - ref)) <= 1e3 * 2e-7 * np.max(np.abs(ref))
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
