@@ -1800,10 +1800,17 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_fused_bf3(
     const uint16_t* __restrict__ vis, int N, int ksplit, double* __restrict__ D2p, double* __restrict__ gp,
     float* __restrict__ pf, float* __restrict__ slabs, double* __restrict__ bpart, double* __restrict__ gdpart,
     double* __restrict__ cost_part, double* __restrict__ gmax_part, long long* __restrict__ dbg,
-    int exp_flags /* timing experiments only (SBA_SCHUR_EXP; results are WRONG when set): 1 = no m / l planes, 2 = no U_c / g_c accumulation */) {
+    int exp_arg /* timing experiments, only in a build with -DSBA_SCHUR_EXP_BUILD (make EXTRA=-DSBA_SCHUR_EXP_BUILD; SBA_SCHUR_EXP=1: no m / l planes,
+                   2: no U_c / g_c accumulation; results are WRONG when set -- docs/EXPERIMENTS.md, profiles/r4_fused_bf3_sensitivity.txt) */) {
   extern __shared__ __align__(16) unsigned char smem[];
   using T = float;
   using Cfg = SchurBf3Cfg;
+#ifdef SBA_SCHUR_EXP_BUILD
+  const int exp_flags = exp_arg;
+#else
+  constexpr int exp_flags = 0;          // the production kernel carries none of the experiment's branches
+  (void)exp_arg;
+#endif
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS, UPKB = Cfg::UPKB, UPKS = Cfg::UPKS;
   const bool stamp_wg = dbg && blockIdx.x == 0;
   if (stamp_wg && threadIdx.x == 0) dbg[48] = clock64();

@@ -348,7 +348,7 @@ def test_weighted_solve_matches_oracle():
                                     pi=rig["point_ind"]), 1e-8, weights=w)
     # above: the reference's call at the same tolerance; below: the minimum itself, by the independent exact optimisers of
     # oracle.tight_optimum started from the device's solution (see test_tight_optimum_two_sided_...)
-    best, _ = orc.tight_optimum(cams, pts, rig["points_2d"], rig["camera_ind"], rig["point_ind"], weights=w.reshape(-1, 1), max_nfev=(40, 20))
+    best, _ = orc.tight_optimum(cams, pts, rig["points_2d"], rig["camera_ind"], rig["point_ind"], weights=w.reshape(-1, 1), max_nfev=(25, 10))
     assert rep.cost <= res.cost * (1 + 1e-9) and best * (1 - 1e-9) <= rep.cost <= best * (1 + 1e-5), (rep.cost, best, res.cost)
     again, _, _ = orc.bundle_adjust(cams, pts, rig["points_2d"], rig["camera_ind"], rig["point_ind"],
                                     weights=w.reshape(-1, 1), ftol=1e-8, max_nfev=20)
