@@ -250,7 +250,8 @@ int sba_comm_init(sba_handle* h, const uint8_t* id /*SBA_COMM_ID_BYTES*/, int32_
  * flags and adds the n_ranks copies in rank order: the same bits on every rank, two or three small launches per exchange
  * instead of an RCCL collective.  Works between processes sharing ONE device (how tests/test_gpu_ipc.py runs the in-library
  * sharded loop on a one-GPU box), between handles of ONE process (ranks as threads: the library finds same-process areas
- * in a table instead of opening their handles) and between peer GPUs of one node (EXPERIMENTAL: never run across devices,
+ * in a table instead of opening their handles; every rank's stream then needs a hardware queue of its own -- a gate kernel must
+ * never be queued in front of the publish it waits for: GPU_MAX_HW_QUEUES >= 2 x the ranks of the process, set before HIP starts) and between peer GPUs of one node (EXPERIMENTAL: never run across devices,
  * see DESIGN.md section 6).  Exclusive with sba_comm_init, both ways.  The area is uncached device memory; where that
  * cannot be allocated sba_ipc_export fails (SBA_IPC_ALLOW_CACHED=1 accepts cached memory, valid on one device only).
  * A caller must not destroy a handle while a peer may still be reading its area (barrier first). */

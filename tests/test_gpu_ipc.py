@@ -130,3 +130,4 @@ def test_in_library_sharded_loop_17_cameras_f64_wide_kernel():
     with _native.Problem(*a, dtype="f64") as prob:
         _, _, rep, _ = prob.solve_lm(prob.make_opts(ftol=1e-4))
     assert abs(rep.cost - r0[2]) <= 1e-9 * rep.cost
+

@@ -164,3 +164,86 @@ def test_config_4_shape_sharded_matches_the_reference_optimum():
     x = np.hstack((r0[4].ravel(), pts_all.ravel()))
     f = orc.fun(x, 64, a[1].shape[0], a[3], a[4], a[2], 1.0)
     assert abs(0.5 * float(f @ f) - r0[2]) <= 1e-9 * r0[2]          # the job-wide cost the ranks agreed on IS the reference's fun at the returned x
+
+
+def _housekeeping_worker(q):
+    """Runs in a fresh process (its own HIP runtime with one hardware queue per stream, see _worker)."""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ["SBA_IPC_TIMEOUT_S"] = "0.5"
+    import time
+    try:
+        from lasercalib_amd import _native, dist
+        from lasercalib_amd.synth import make_rig
+        rig = make_rig(8, 400, seed=5)
+        shards = [dist.make_shard(rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], None, 2, r) for r in range(2)]
+        out = {}
+        probs = [_native.Problem(rig["cams0"], s["pts"], s["uv"], s["ci"], s["pi_local"], dtype="f64") for s in shards]
+        try:
+            handles = [p.ipc_export(2) for p in probs]
+
+            def refused(fn):
+                try:
+                    fn()
+                except _native.SbaError as e:
+                    return str(e)
+                return None
+            out["comm_init_after_export"] = refused(lambda: probs[0].comm_init(b"\0" * _native.COMM_ID_BYTES, 0, 1))
+            out["second_export"] = refused(lambda: probs[0].ipc_export(2))
+            for r, p in enumerate(probs):
+                p.ipc_attach(r, handles)                                # both peers live in this process: no hipIpcOpenMemHandle involved
+            out["second_attach"] = refused(lambda: probs[0].ipc_attach(0, handles))
+            t0 = time.perf_counter()                                    # rank 1 never joins: rank 0's first exchange (lm_begin) gives up
+            out["peer_absent"] = refused(lambda: probs[0].solve_lm(probs[0].make_opts(ftol=1e-4)))
+            out["peer_absent_seconds"] = time.perf_counter() - t0
+            out["after_timeout"] = refused(lambda: probs[0].solve_lm(probs[0].make_opts(ftol=1e-4)))
+        finally:
+            for p in probs:
+                p.close()
+        # the same two ranks, both solving (two threads): bit-identical, and the single-rank trajectory
+        probs = [_native.Problem(rig["cams0"], s["pts"], s["uv"], s["ci"], s["pi_local"], dtype="f64") for s in shards]
+        try:
+            handles = [p.ipc_export(2) for p in probs]
+            for r, p in enumerate(probs):
+                p.ipc_attach(r, handles)
+            res = [None, None]
+
+            def run(k):
+                res[k] = probs[k].solve_lm(probs[k].make_opts(ftol=1e-4))
+            th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"]) as solo:
+                _, _, rep, _ = solo.solve_lm(solo.make_opts(ftol=1e-4))
+            out["pair"] = (res[0] is not None and res[1] is not None and bool(np.array_equal(res[0][0], res[1][0])),
+                           res[0][2].cost, res[1][2].cost, int(res[0][2].status), int(res[0][2].nfev), rep.cost, int(rep.nfev))
+        finally:
+            for p in probs:
+                p.close()
+        q.put(out)
+    except BaseException as e:      # noqa: BLE001
+        q.put({"error": repr(e)})
+        raise
+
+
+def test_exchange_setup_rules_and_bounded_wait():
+    """The one-shot exchange's housekeeping (round 4): peers inside ONE process are found in the library's table of local areas
+    (hipIpcOpenMemHandle refuses the exporting process); the two exchanges exclude each other in both directions; a second export or
+    attach is refused; a peer that never arrives costs SBA_IPC_TIMEOUT_S (0.5 s here), not a hang, and leaves the handle unusable for
+    further exchanges; two ranks of one process that both solve agree bit for bit and follow the single-rank trajectory."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_housekeeping_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert "error" not in out, out
+    assert out["comm_init_after_export"] and "exclusive" in out["comm_init_after_export"]
+    assert out["second_export"] and out["second_attach"]
+    assert out["peer_absent"] and "did not reach the exchange" in out["peer_absent"] and out["peer_absent_seconds"] < 5.0
+    assert out["after_timeout"] and "timed out" in out["after_timeout"]
+    same, c0, c1, status, nfev, c_solo, nfev_solo = out["pair"]
+    assert same and c0 == c1 and status == 2 and nfev == nfev_solo and abs(c0 - c_solo) <= 1e-9 * c_solo
