@@ -503,6 +503,26 @@ struct Engine : EngineBase {
       int ks = std::max(1, (target + wg_per_ks - 1) / wg_per_ks);
       const int maxks = std::max(1, (N + SCHUR_PTS - 1) / SCHUR_PTS);
       ksplit = std::min(ks, maxks);
+      // Round 4: several camera groups -- the launches run in ROUNDS of one workgroup per CU, and a last round that is half empty costs
+      // as much as a full one (64 cameras, k-split 64: 384 off-diagonal workgroups = 1.5 rounds).  Measured (profiles/r4_ksplit_sweep.txt):
+      // 64 x 200k 3 674 -> 3 330 us per iteration with twice the k-split (512 + 768 workgroups: whole rounds, and a finer tail), 128 x 125k
+      // with 13 parameters 10.67 -> 9.98 ms, 32 x 50k 470 -> 435 us.  So: aim at two rounds for the smaller launch, then pick, in a window
+      // around that, the k-split with the smallest modelled makespan  sum over the two launches of  rounds x points per workgroup
+      // (an off-diagonal workgroup builds two panels and 121 tiles: weight 2).  SBA_SCHUR_WGS pins the target and skips the search.
+      if (ngroups > 1 && !getenv("SBA_SCHUR_WGS")) {
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        const int ks0 = std::max(1, (2 * ncu + wg_per_ks - 1) / wg_per_ks);
+        double best = 1e300;
+        int best_ks = ks0;
+        for (int k = std::max(1, ks0 * 3 / 4); k <= ks0 * 3 / 2; ++k) {
+          const double per = std::ceil((double)N / k);
+          const double cost = std::ceil((double)wg_diag * k / ncu) * per + (wg_off > 0 ? 2.0 * std::ceil((double)wg_off * k / ncu) * per : 0.0);
+          if (cost < best * (1 - 1e-9)) { best = cost; best_ks = k; }
+        }
+        ksplit = std::min(best_ks, maxks);
+      }
     }
 
     up_lap("blocks + camera-major copies");
