@@ -44,6 +44,7 @@ struct Engine : EngineBase {
   DevBuf<uint16_t> grp_mask;         // several camera groups: k_group_index tables [ngroups][N] (Schur producers)
   DevBuf<int32_t> grp_start;
   bool grp_indexed = false;
+  bool pairs_fold_u = false;         // multi-group fp32: k_schur_diag_bf3 accumulates the camera blocks itself (no k_linearize_cams in the loop)
   bool no_bf3_pairs = false;         // SBA_NO_BF3_PAIRS=1: f32-input MFMA kernels for every group pair (A/B, equivalence test)
   bool no_bf3_offdiag = false;       // SBA_NO_BF3_OFFDIAG=1: ... for the off-diagonal pairs only
   bool fused_ok = false;             // dense, one camera group, f32: the linearisation runs inside the Schur kernel
@@ -618,6 +619,10 @@ struct Engine : EngineBase {
     backsub_masked = masked_ok && C <= GROUP_CAMS && N > 0 && (double)M >= dense_min_vis * (double)N * C && !getenv("SBA_NO_DENSE");
     if (fused_masked || (lin_pts_ok && !dense_one_group) || (fused_wide && C <= GROUP_CAMS && !dense) || backsub_masked) vis_mask.upload(vmask, stream);
     if (fused_ok) gdpart.alloc((size_t)ksplit * 2 * (fused_wide ? WIDE_ROWS : GROUP_ROWS));
+    // several camera groups on the bf16 pair kernels (round 4): the diagonal pairs also accumulate U_c / g_c (SBA_PAIRS_LINC=1 keeps
+    // k_linearize_cams + k_reduce_cams)
+    pairs_fold_u = sizeof(T) == 4 && ngroups > 1 && grp_indexed && !no_bf3_pairs && !fused_ok && !getenv("SBA_PAIRS_LINC");
+    if (pairs_fold_u) gdpart.alloc((size_t)ngroups * ksplit * 2 * GROUP_ROWS);
     cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1)); gmax_alt.alloc(std::max(std::max(nblk, ksplit), 1));
     // (k_backsub_dense writes one partial row per WORKGROUP: nbs_dense of them, which exceeds the number of point-aligned blocks on
     //  dense rigs with few cameras -- 8 x 1000: 63 vs 32; sized for nblk alone the rows used to run over into the next buffer)
@@ -923,7 +928,7 @@ struct Engine : EngineBase {
     if (diag_pairs_bf3()) {
       hipLaunchKernelGGL(k_schur_diag_bf3, dim3(ksplit, ngroups), dim3(SCHUR_THREADS), SchurPairCfg::LDS_BYTES, stream,
                          ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, grp_mask.p, grp_start.p, N, pfac.p, pair_ga.p, 0, ksplit,
-                         slabs.p, bpart.p);
+                         slabs.p, bpart.p, pairs_fold_u ? gdpart.p : (double*)nullptr);
     } else
     hipLaunchKernelGGL((k_schur<T, true, PARTIAL>), dim3(ksplit, ngroups, CfgD::TS), dim3(CfgD::THREADS), CfgD::LDS_BYTES,
                        stream, ps_lm(), d_state.p, C, uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, N,
@@ -1373,7 +1378,7 @@ struct Engine : EngineBase {
       launch_linearize_points(d_state.p);
       prof_end(KP_LINP);
     }
-    if (h_state->free_cams) { prof_begin(KP_LINC); launch_linearize_cams(d_state.p); prof_end(KP_LINC); }
+    if (h_state->free_cams && !(pairs_fold_u && diag_pairs_bf3())) { prof_begin(KP_LINC); launch_linearize_cams(d_state.p); prof_end(KP_LINC); }
     return SBA_OK;
   }
 
@@ -1404,7 +1409,7 @@ struct Engine : EngineBase {
       const int nblocks = (fc ? 4 * nt_launch * np_arg + (n + 15) / 16 : 0) + 1;
       hipLaunchKernelGGL(k_build_exchange<T>, dim3(nblocks), dim3(1024), 0, stream, slabs.p, bpart.p, ksplit, pair_ga.p,
                          pair_gb.p, np_arg, U.p, gc.p, cost_part.p, n_lin_parts(), C, fc, E, d_state.p,
-                         fused() ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_wide) ? 3 : (fused() && fused_bf3 && sizeof(T) == 4) ? 1 : (diag_pairs_bf3() ? (offdiag_pairs_bf3() ? 1 : 2) : 0),
+                         (fused() || (pairs_fold_u && diag_pairs_bf3())) ? gdpart.p : (const double*)nullptr, Pk, (fused() && fused_wide) ? 3 : (fused() && fused_bf3 && sizeof(T) == 4) ? 1 : (diag_pairs_bf3() ? (offdiag_pairs_bf3() ? 1 : 2) : 0),
                          nt_launch);
     }
     prof_end(KP_REDUCE);

@@ -2187,11 +2187,17 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
     const ParamSets<float> ps, const LMState* __restrict__ st, int C,
     const float2* __restrict__ uv, const float* __restrict__ w, const uint16_t* __restrict__ gmask, const int32_t* __restrict__ gstart,
     int N, const float* __restrict__ pf, const int32_t* __restrict__ pair_ga, int pair0, int ksplit,
-    float* __restrict__ slabs, double* __restrict__ bpart) {
+    float* __restrict__ slabs, double* __restrict__ bpart,
+    double* __restrict__ gdpart /* round 4: [group][ksplit][2][GROUP_ROWS] partial g_c / diag U rows.  The producers evaluate Jc anyway, so they also
+                                    accumulate the group's camera blocks U_c = sum Jc^T Jc and g_c = sum Jc^T r (the fused kernel's 77 / 104 per-lane
+                                    register accumulators); U_c is subtracted on the tiles' camera diagonals (the slab then holds Schur partials - U),
+                                    bpart becomes b - g_c, and k_linearize_cams + k_reduce_cams are not launched.  NULL: the round-3 behaviour */) {
   extern __shared__ __align__(16) unsigned char smem[];
   using T = float;
   using Cfg = SchurPairCfg;
   constexpr int THREADS = Cfg::THREADS, NPROD = Cfg::NPROD, TPW = Cfg::TPW, PTS = Cfg::PTS;
+  constexpr int UPKB = UPK + NCP, UPKS = UPKB | 1;                     // U (upper triangle) + g + b per lane; odd row stride in the hand-over area
+  static_assert(2 * (size_t)Cfg::BUF_BYTES >= (size_t)(NPROD + GROUP_CAMS) * UPKS * sizeof(float), "the accumulator hand-over reuses the panel buffers");
   if (st->status >= 0) return;
   const int cur_ = ps_cur(ps, st);
   const T* __restrict__ ptsT = ps.ptsT[cur_];
@@ -2201,7 +2207,19 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
   const uint16_t* __restrict__ gm = gmask + (size_t)ga * N;
   const int32_t* __restrict__ gs = gstart + (size_t)ga * N;
   T* s_cam = reinterpret_cast<T*>(smem + 2 * Cfg::BUF_BYTES);            // [16][CAMPRE]
-  T* s_B = reinterpret_cast<T*>(smem);                                   // [256][NCP] once the panels are done with
+  T* s_B = reinterpret_cast<T*>(smem);                                   // [256][NCP] once the panels are done with (gdpart == NULL)
+  T* s_U = reinterpret_cast<T*>(smem);                                   // [256][UPKS] once the panels are done with (gdpart != NULL)
+  T* s_Ured = s_U + NPROD * UPKS;                                        // [16][UPKB]
+  const bool fold_u = gdpart != nullptr;                                 // (a kernel argument: uniform)
+  auto fold_lanes = [&]() {                                             // the 16 lanes (points of a chunk) that served camera c fold their accumulators
+    for (int o = threadIdx.x; o < nA * UPKB; o += THREADS) {
+      const int c = o / UPKB, kk = o - c * UPKB;
+      T sum = 0;
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) sum += s_U[(qq * 16 + c) * UPKS + kk];
+      s_Ured[o] = sum;
+    }
+  };
   {   // zero both panel buffers: the rows of cameras >= nA are never written
     uint4* z4 = reinterpret_cast<uint4*>(smem);
     for (int i = threadIdx.x; i < 2 * Cfg::BUF_BYTES / 16; i += THREADS) z4[i] = make_uint4(0, 0, 0, 0);
@@ -2222,6 +2240,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
     T bacc[NCP];
 #pragma unroll
     for (int e = 0; e < NCP; ++e) bacc[e] = (T)0;
+    T Uacc[UPK];                                                         // U_c upper triangle + g_c (only touched when fold_u)
+    static_for<0, UPK>([&](auto kc) { Uacc[decltype(kc)::value] = (T)0; });
     float2 n_uv = make_float2(0.f, 0.f);
     T n_w = 1, n_X[3] = {0, 0, 0}, n_f[PF];
 #pragma unroll
@@ -2309,19 +2329,41 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
             *reinterpret_cast<uint2*>(dst + 2 * Cfg::PLANE * 2) = make_uint2(l01, l2);
           });
         }
+        if (fold_u) {
+          // the camera's own block and gradient, as in k_schur_fused_bf3 (a lane without an observation has Jc = 0, r = 0)
+          static_for<0, NCP>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            static_for<a, NCP>([&](auto bc) {
+              constexpr int b = decltype(bc)::value;
+              constexpr int kk = a * NCP - (a * (a - 1)) / 2 + (b - a);
+              Uacc[kk] = __builtin_fmaf(Jc[1][a], Jc[1][b], __builtin_fmaf(Jc[0][a], Jc[0][b], Uacc[kk]));
+            });
+            constexpr int kg = NCP * (NCP + 1) / 2 + a;
+            Uacc[kg] = __builtin_fmaf(Jc[1][a], r[1], __builtin_fmaf(Jc[0][a], r[0], Uacc[kg]));
+          });
+        }
       }
       __syncthreads();
     }
     __syncthreads();                       // the consumers have read the last panel: the buffers become the hand-over area
+    if (fold_u) {
+      static_for<0, UPK>([&](auto kc) { constexpr int kk = decltype(kc)::value; s_U[threadIdx.x * UPKS + kk] = Uacc[kk]; });
 #pragma unroll
-    for (int e = 0; e < NCP; ++e) s_B[threadIdx.x * NCP + e] = bacc[e];
-    __syncthreads();
-    if ((int)threadIdx.x < GROUP_ROWS) {
-      const int cc = threadIdx.x / NCP, e = threadIdx.x - cc * NCP;
-      double sum = 0;
+      for (int e = 0; e < NCP; ++e) s_U[threadIdx.x * UPKS + UPK + e] = bacc[e];
+      __syncthreads();
+      fold_lanes();
+      __syncthreads();
+    } else {
 #pragma unroll
-      for (int qq = 0; qq < 16; ++qq) sum += (double)s_B[(qq * 16 + cc) * NCP + e];
-      bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + threadIdx.x] = (cc < nA) ? sum : 0.0;
+      for (int e = 0; e < NCP; ++e) s_B[threadIdx.x * NCP + e] = bacc[e];
+      __syncthreads();
+      if ((int)threadIdx.x < GROUP_ROWS) {
+        const int cc = threadIdx.x / NCP, e = threadIdx.x - cc * NCP;
+        double sum = 0;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) sum += (double)s_B[(qq * 16 + cc) * NCP + e];
+        bpart[((size_t)ga * ksplit + blockIdx.x) * GROUP_ROWS + threadIdx.x] = (cc < nA) ? sum : 0.0;
+      }
     }
   } else {
     const int cw = wid - NPROD / 64;
@@ -2395,6 +2437,37 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_diag_bf3(
     }
     __syncthreads();                       // matches the producers' barrier in front of the hand-over
     __syncthreads();                       // (and the one behind it)
+    if (fold_u) {
+      fold_lanes();
+      __syncthreads();
+      // parameter-major rows: tile (R, Tc) holds parameters (R, Tc) of every camera pair of the group; the camera's own block U_c sits on
+      // the tile's diagonal (row camera == column camera): at most one of a lane's four registers (k_schur_fused_bf3's epilogue)
+      static_for<0, Cfg::NV>([&](auto vc) {
+        constexpr int V = decltype(vc)::value;
+        if (cw == V) {
+          constexpr int T0 = schur_lo(Cfg::NTILE, Cfg::NV, V), T1 = schur_lo(Cfg::NTILE, Cfg::NV, V + 1);
+          static_for<T0, T1>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int R = schur_tile_R(true, t), Tc = schur_tile_T(true, t);
+            const int cj_ = lane & 15, rgm = cj_ - 4 * (lane >> 4);
+            const T u = (rgm >= 0 && rgm < 4 && cj_ < nA) ? s_Ured[cj_ * UPKB + (R * NCP - (R * (R - 1)) / 2 + (Tc - R))] : (T)0;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) acc[t - T0][rg] -= (rg == rgm) ? u : (T)0;
+          });
+        }
+      });
+      const int ct = threadIdx.x - NPROD;
+      if (ct < GROUP_ROWS) {
+        const int c = ct / NCP, e = ct - c * NCP;
+        const double gpart = (c < nA) ? (double)s_Ured[c * UPKB + NCP * (NCP + 1) / 2 + e] : 0.0;
+        const double dpart = (c < nA) ? (double)s_Ured[c * UPKB + (e * NCP - (e * (e - 1)) / 2)] : 0.0;
+        const double bsum = (c < nA) ? (double)s_Ured[c * UPKB + UPK + e] : 0.0;
+        const size_t slot = (size_t)ga * ksplit + blockIdx.x;
+        bpart[slot * GROUP_ROWS + ct] = bsum - gpart;                         // rhs = sum (b - g_c) over the workgroups
+        gdpart[(slot * 2 + 0) * GROUP_ROWS + ct] = gpart;
+        gdpart[(slot * 2 + 1) * GROUP_ROWS + ct] = dpart;
+      }
+    }
     T* slab = slabs + ((size_t)pair * ksplit + blockIdx.x) * (size_t)(GROUP_TILES * GROUP_TILES) * 256;
     schur_store_v<Cfg>(cw, slab, lane, acc);
   }

@@ -144,8 +144,8 @@ __global__ __launch_bounds__(1024) void k_build_exchange(
       const int rstride = wide ? WIDE_ROWS : GROUP_ROWS;
       const int grp = wide ? 0 : i / GROUP_ROWS, rho = i - grp * GROUP_ROWS;
       const double* src = bpart + (size_t)grp * ksplit * GROUP_ROWS + rho;
-      if (gdpart) {        // fused linearisation: g_c and diag(U) are per-workgroup partial rows laid out like bpart (one group)
-        const double* gs_ = gdpart + rho;
+      if (gdpart) {        // fused linearisation: g_c and diag(U) are per-workgroup partial rows laid out like bpart ([group][k-split][2][rows])
+        const double* gs_ = gdpart + (size_t)grp * ksplit * 2 * GROUP_ROWS + rho;
         for (int k = gr; k < ksplit; k += RG) {
           b0 += src[(size_t)k * rstride];
           g0 += gs_[(size_t)k * 2 * rstride];
