@@ -600,10 +600,12 @@ struct Engine : EngineBase {
     dense_one_group = dense && C <= GROUP_CAMS && N > 0 && !getenv("SBA_NO_DENSE");
     // 17 .. 23 cameras, dense or group-indexed and dense enough (the rigs of the wide fused kernels): the same back substitution
     // with a point per 32-lane wave half
-    backsub_wide = C > GROUP_CAMS && C <= 23 && N > 0 && (dense || (grp_indexed && (double)M >= dense_min_vis * (double)N * C)) &&
+    backsub_wide = C > GROUP_CAMS && C <= 32 && N > 0 && (dense || (grp_indexed && (double)M >= dense_min_vis * (double)N * C)) &&
                    !getenv("SBA_NO_DENSE") && !getenv("SBA_NO_WIDE");
     backsub_pack = backsub_wide && 3 * C <= 64 && !getenv("SBA_WIDE_PW2");       // three points per wave (17 .. 21 cameras)
-    const int bs_ppc = backsub_pack ? 12 : backsub_wide ? 8 : 16;
+    // 33 .. 128 cameras (round 4): a point per wave, up to two cameras per lane (k_backsub_dense<T, 64>)
+    backsub_wave = C > 32 && N > 0 && (dense || (grp_indexed && (double)M >= dense_min_vis * (double)N * C)) && !getenv("SBA_NO_DENSE") && !getenv("SBA_NO_WIDE");
+    const int bs_ppc = backsub_wave ? 4 : backsub_pack ? 12 : backsub_wide ? 8 : 16;
     nbs_dense = std::max(1, std::min((N + bs_ppc - 1) / bs_ppc, getenv("SBA_BS_WGS") ? atoi(getenv("SBA_BS_WGS")) : (sizeof(T) == 4 ? 768 : 512)));
     // the fused linearise+Schur kernel also serves sparse one-group rigs through the visibility mask; its producer cost
     // does not shrink with the number of observations, so below ~35 % visibility the three-pass path is used
@@ -961,12 +963,19 @@ struct Engine : EngineBase {
   bool backsub_masked = false;       // sparse one-group rig dense enough for the lane = (point, camera) back substitution (visibility mask)
   bool backsub_wide = false;         // 17 .. 23 cameras: k_backsub_dense<T, 32> / <T, 0>
   bool backsub_pack = false;
-  bool backsub_dense() const { return dense_one_group || backsub_masked || backsub_wide; }
+  bool backsub_wave = false;         // 33 .. 128 cameras: k_backsub_dense<T, 64>
+  bool backsub_dense() const { return dense_one_group || backsub_masked || backsub_wide || backsub_wave; }
   int n_trial_parts() const { return backsub_dense() ? nbs_dense : nblk; }
   void launch_backsub_trial() {
     if (nblk == 0) return;
     if (backsub_pack) {
       hipLaunchKernelGGL((k_backsub_dense<T, 0>), dim3(nbs_dense), dim3(PM_BLOCK), 0, stream, ps_lm(), C, uv_pm.p,
+                         has_w ? w_pm.p : nullptr, N, pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nbs_dense,
+                         dense ? (const uint16_t*)nullptr : grp_mask.p, dense ? (const int32_t*)nullptr : grp_start.p);
+      return;
+    }
+    if (backsub_wave) {
+      hipLaunchKernelGGL((k_backsub_dense<T, 64>), dim3(nbs_dense), dim3(PM_BLOCK), 0, stream, ps_lm(), C, uv_pm.p,
                          has_w ? w_pm.p : nullptr, N, pfac.p, gp.p, D2p.p, delta_c.p, d_state.p, trial_part.p, nbs_dense,
                          dense ? (const uint16_t*)nullptr : grp_mask.p, dense ? (const int32_t*)nullptr : grp_start.p);
       return;

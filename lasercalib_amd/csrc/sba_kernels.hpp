@@ -739,6 +739,14 @@ __device__ __forceinline__ float half32_sum(float v) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
   return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
+// sum over all 64 lanes, result in every lane (a point per wave: k_backsub_dense<T, 64>)
+__device__ __forceinline__ float wave64_sum(float v) {
+  v = half32_sum(v);
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ double wave64_sum(double v) { return wave_sum(v); }
 __device__ __forceinline__ double half32_sum(double v) {
   v = row16_sum(v);
   unsigned lo0 = __double2loint(v), hi0 = __double2hiint(v), lo1 = lo0, hi1 = hi0;

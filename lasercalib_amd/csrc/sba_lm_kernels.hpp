@@ -570,7 +570,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_trial_scalars(const double* 
 // Same arithmetic as k_backsub_trial, laid out like k_schur_fused: lane (q, c) = (point of a 16-point chunk, camera),
 // so W_p^T delta_c is a DPP row sum instead of an LDS staging pass with two barriers, the workgroup is persistent
 // (camera tables staged once, chunks strided over the grid) and each partial row holds a whole workgroup's share.
-// LW = lanes per point: 16 (one DPP row: up to 16 cameras) or 32 (a wave half: 17 .. 23 cameras, the rigs of k_schur_fused_wide --
+// LW = lanes per point: 16 (one DPP row: up to 16 cameras), 64 (a whole wave, two cameras per lane: 33 .. 128 cameras, round 4) or 32 (a wave half: 17 .. 32 cameras, the rigs of k_schur_fused_wide and, since round 4, 24 .. 32 --
 // sums over the half, 8 points per chunk; 17 of 32 lanes work at 17 cameras, so it only draws level with k_backsub_trial there
 // (17 x 50k: 166.8 us per iteration either way) and gains from 20 cameras on (20 x 50k 218 -> 213.8 us).  LW = 0 (17 .. 21 cameras):
 // three points per wave, packed -- 17 x 50k 166.8 -> 162.5 us per iteration in fp32, 273.0 -> 268.8 in fp64, 20 x 50k 213.8 -> 209.6.
@@ -586,7 +586,10 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
   // LW = 0: PACKED -- three points per wave, lane l -> point l / C, camera l % C (17 .. 21 cameras: 51 .. 63 of the 64 lanes work
   // instead of 34 .. 42 with a point per half); the sums over a point's cameras = segment differences of a wave-wide prefix scan
   constexpr bool PACK = LW == 0;
-  constexpr int MAXC = LW == 16 ? GROUP_CAMS : 24, PPC = PACK ? 3 * (PM_BLOCK / 64) : PM_BLOCK / (PACK ? 1 : LW);       // cameras the tables hold, points per chunk
+  // LW = 64 (round 4): a point per WAVE and up to two cameras per lane (c, c + 64): 33 .. 128 cameras, i.e. BASELINE configs 4 and 5, which
+  // used to take the point-aligned k_backsub_trial (LDS staging of W^T dc, two barriers per block)
+  constexpr int CPL = LW == 64 ? 2 : 1;                                                                                 // cameras per lane
+  constexpr int MAXC = LW == 16 ? GROUP_CAMS : LW == 64 ? 128 : 32, PPC = PACK ? 3 * (PM_BLOCK / 64) : PM_BLOCK / (PACK ? 1 : LW);       // cameras the tables hold, points per chunk
   __shared__ T s_cam01[2][MAXC * CAMPRE], s_dc[MAXC * NCP];
   __shared__ double s_scr[PM_BLOCK / 64];
   // both camera tables are needed whichever is current: they and the camera step are requested before the state record's round trip
@@ -609,10 +612,11 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
   const int q = PACK ? 3 * (int)(threadIdx.x >> 6) + min(hseg, 2) : (int)threadIdx.x / (PACK ? 1 : LW);
   const int c = PACK ? lane_ - hseg * C : (int)threadIdx.x % (PACK ? 1 : LW);
   const bool cam_ok = PACK ? hseg < 3 : c < C;
-  const int grp = (cam_ok ? c : 0) >> 4, cc = c & 15;
+  const int cc = c & 15;
   auto lane_sum = [&](T v) -> T {
     if constexpr (LW == 16) return row16_sum(v);
     else if constexpr (LW == 32) return half32_sum(v);
+    else if constexpr (LW == 64) return wave64_sum(v);
     else {
       const T sc = wave_scan(v);
       const T e0 = lane_bcast(sc, C - 1), e1 = lane_bcast(sc, 2 * C - 1), e2 = lane_bcast(sc, 3 * C - 1);
@@ -630,13 +634,23 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
     const int p = ch * PPC + q;
     const bool pt_ok = p < N;
     const size_t pp = (size_t)(pt_ok ? p : 0);
-    unsigned mask = 0xffffu;
-    size_t o = pp * C + c;
-    if (vis) { mask = vis[(size_t)grp * N + pp]; o = (size_t)pt_start[(size_t)grp * N + pp] + __builtin_popcount(mask & ((1u << cc) - 1u)); }
-    const bool valid = pt_ok && cam_ok && ((mask >> cc) & 1u);
-    typename Vec2<T>::type m; m.x = 0; m.y = 0;
-    T ww = (T)1;
-    if (valid) { m = uv[o]; if (w) ww = w[o]; }
+    // (the lane's first camera c; with CPL = 2 its second one, c + 64, goes through the same steps with index 1)
+    bool valid[CPL];
+    typename Vec2<T>::type m[CPL];
+    T ww[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int cj = c + 64 * j;
+      const bool cam_j = j == 0 ? cam_ok : cj < C;
+      const int gj = (cam_j ? cj : 0) >> 4;
+      unsigned mask = 0xffffu;
+      size_t o = pp * C + cj;
+      if (vis) { mask = vis[(size_t)gj * N + pp]; o = (size_t)pt_start[(size_t)gj * N + pp] + __builtin_popcount(mask & ((1u << cc) - 1u)); }
+      valid[j] = pt_ok && cam_j && ((mask >> cc) & 1u);
+      m[j].x = 0; m[j].y = 0;
+      ww[j] = (T)1;
+      if (valid[j]) { m[j] = uv[o]; if (w) ww[j] = w[o]; }
+    }
     // every lane of the row reads the point's data (same addresses: one transaction) and solves for its step
     // redundantly.  (Requesting the next chunk's operands one chunk ahead was measured: no gain, the kernel is
     // issue-bound at three workgroups per CU and the extra registers cost one of them.)
@@ -647,14 +661,23 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
     const double dd0 = fmax_pos(D2p[pp * 3]), dd1 = fmax_pos(D2p[pp * 3 + 1]), dd2 = fmax_pos(D2p[pp * 3 + 2]);
     const double X0 = pts[pp * 3], X1 = pts[pp * 3 + 1], X2 = pts[pp * 3 + 2];
     T t0 = 0, t1 = 0, t2 = 0;
-    if (free_cams && valid) {
-      // W^T dc of this observation = Jp^T (Jc dc): the point block and the directional derivative along the camera step
-      T r[2], Jp[2][3], sj[2];
-      obs_jp_jvp<T>(cp, ptsT[pp * 3], ptsT[pp * 3 + 1], ptsT[pp * 3 + 2], m.x, m.y, ww, dc, r, Jp, sj);
-      if (ps.loss_delta > 0.f) robust_apply_jvp<T>(ps.loss(), r, Jp, sj);
-      t0 = Jp[0][0] * sj[0] + Jp[1][0] * sj[1];
-      t1 = Jp[0][1] * sj[0] + Jp[1][1] * sj[1];
-      t2 = Jp[0][2] * sj[0] + Jp[1][2] * sj[1];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      if (free_cams && valid[j]) {
+        // W^T dc of this observation = Jp^T (Jc dc): the point block and the directional derivative along the camera step
+        T r[2], Jp[2][3], sj[2];
+        if (j == 0) obs_jp_jvp<T>(cp, ptsT[pp * 3], ptsT[pp * 3 + 1], ptsT[pp * 3 + 2], m[j].x, m[j].y, ww[j], dc, r, Jp, sj);
+        else {
+          T dcj[NCP];
+#pragma unroll
+          for (int e = 0; e < NCP; ++e) dcj[e] = s_dc[(c + 64 * j) * NCP + e];
+          obs_jp_jvp<T>(s_cam + (c + 64 * j) * CAMPRE, ptsT[pp * 3], ptsT[pp * 3 + 1], ptsT[pp * 3 + 2], m[j].x, m[j].y, ww[j], dcj, r, Jp, sj);
+        }
+        if (ps.loss_delta > 0.f) robust_apply_jvp<T>(ps.loss(), r, Jp, sj);
+        t0 += Jp[0][0] * sj[0] + Jp[1][0] * sj[1];
+        t1 += Jp[0][1] * sj[0] + Jp[1][1] * sj[1];
+        t2 += Jp[0][2] * sj[0] + Jp[1][2] * sj[1];
+      }
     }
     const double T0 = (double)lane_sum(t0), T1 = (double)lane_sum(t1), T2 = (double)lane_sum(t2);
     double e0 = 0, e1 = 0, e2 = 0;
@@ -675,11 +698,14 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
       dx2 += e0 * e0 + e1 * e1 + e2 * e2;
       if (!pt_fixed(ps, pp)) x2 += X0 * X0 + X1 * X1 + X2 * X2;      // a fixed point is not part of x
     }
-    if (valid) {
-      T u, v;
-      obs_project<T>(cpn, (T)n0, (T)n1, (T)n2, u, v);
-      const T r0 = ww * (u - m.x), r1 = ww * (v - m.y);
-      sq += (ps.loss_delta > 0.f) ? (double)robust_cost<T>(ps.loss(), r0, r1) : (double)r0 * r0 + (double)r1 * r1;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      if (valid[j]) {
+        T u, v;
+        obs_project<T>(j == 0 ? cpn : s_camn + (c + 64 * j) * CAMPRE, (T)n0, (T)n1, (T)n2, u, v);
+        const T r0 = ww[j] * (u - m[j].x), r1 = ww[j] * (v - m[j].y);
+        sq += (ps.loss_delta > 0.f) ? (double)robust_cost<T>(ps.loss(), r0, r1) : (double)r0 * r0 + (double)r1 * r1;
+      }
     }
   }
   const double c_new = block_sum(sq, s_scr);
