@@ -606,6 +606,8 @@ struct Engine : EngineBase {
     // 33 .. 128 cameras (round 4): a point per wave, up to two cameras per lane (k_backsub_dense<T, 64>)
     backsub_wave = C > 32 && N > 0 && (dense || (grp_indexed && (double)M >= dense_min_vis * (double)N * C)) && !getenv("SBA_NO_DENSE") && !getenv("SBA_NO_WIDE");
     const int bs_ppc = backsub_wave ? 4 : backsub_pack ? 12 : backsub_wide ? 8 : 16;
+    linp_lw = getenv("SBA_LINP_BLOCKS") ? 0 : backsub_wave ? 64 : (backsub_wide && C > 23) ? 32 : 0;
+    nlinp = linp_lw ? std::max(1, std::min((N + (PM_BLOCK / linp_lw) - 1) / (PM_BLOCK / linp_lw), 1024)) : 0;
     nbs_dense = std::max(1, std::min((N + bs_ppc - 1) / bs_ppc, getenv("SBA_BS_WGS") ? atoi(getenv("SBA_BS_WGS")) : (sizeof(T) == 4 ? 768 : 512)));
     // the fused linearise+Schur kernel also serves sparse one-group rigs through the visibility mask; its producer cost
     // does not shrink with the number of observations, so below ~35 % visibility the three-pass path is used
@@ -625,7 +627,7 @@ struct Engine : EngineBase {
     // k_linearize_cams + k_reduce_cams)
     pairs_fold_u = sizeof(T) == 4 && ngroups > 1 && grp_indexed && !no_bf3_pairs && !fused_ok && !getenv("SBA_PAIRS_LINC");
     if (pairs_fold_u) gdpart.alloc((size_t)ngroups * ksplit * 2 * GROUP_ROWS);
-    cost_part.alloc((size_t)std::max(std::max(std::max(nblk, nres_blocks), ksplit), 1)); gmax_part.alloc(std::max(std::max(nblk, ksplit), 1)); gmax_alt.alloc(std::max(std::max(nblk, ksplit), 1));
+    cost_part.alloc((size_t)std::max(std::max(std::max(std::max(nblk, nres_blocks), ksplit), nlinp), 1)); gmax_part.alloc(std::max(std::max(std::max(nblk, ksplit), nlinp), 1)); gmax_alt.alloc(std::max(std::max(std::max(nblk, ksplit), nlinp), 1));
     // (k_backsub_dense writes one partial row per WORKGROUP: nbs_dense of them, which exceeds the number of point-aligned blocks on
     //  dense rigs with few cameras -- 8 x 1000: 63 vs 32; sized for nblk alone the rows used to run over into the next buffer)
     trial_part.alloc((size_t)4 * std::max(std::max(nblk, nbs_dense), 1));
@@ -686,6 +688,17 @@ struct Engine : EngineBase {
   // terminated or when the last step was rejected and nothing has to be re-linearized
   void launch_linearize_points(const LMState* st) {
     if (nblk == 0) return;
+    if (linp_lw) {
+      const uint16_t* tm = dense ? (const uint16_t*)nullptr : grp_mask.p;
+      const int32_t* ts = dense ? (const int32_t*)nullptr : grp_start.p;
+      if (linp_lw == 64)
+        hipLaunchKernelGGL((k_linearize_points_wave<T, 64>), dim3(nlinp), dim3(PM_BLOCK), 0, stream, st ? ps_lm() : ps_now(), st, C, uv_pm.p,
+                           has_w ? w_pm.p : nullptr, N, tm, ts, V.p, gp.p, D2p.p, cost_part.p, gmax_part.p);
+      else
+        hipLaunchKernelGGL((k_linearize_points_wave<T, 32>), dim3(nlinp), dim3(PM_BLOCK), 0, stream, st ? ps_lm() : ps_now(), st, C, uv_pm.p,
+                           has_w ? w_pm.p : nullptr, N, tm, ts, V.p, gp.p, D2p.p, cost_part.p, gmax_part.p);
+      return;
+    }
     const size_t lds = (size_t)PM_BLOCK * 9 * sizeof(double) + lds_cams();
     hipLaunchKernelGGL(k_linearize_points<T>, dim3(nblk), dim3(PM_BLOCK), lds, stream, st ? ps_lm() : ps_now(), st, C,
                        uv_pm.p, has_w ? w_pm.p : nullptr, ci_pm.p, pi_pm.p, pt_start.p, blk_desc.p, V.p, gp.p, D2p.p,
@@ -700,7 +713,7 @@ struct Engine : EngineBase {
   // the linearisation is folded into the Schur kernel (k_schur_fused) whenever the cameras are free
   bool fused() const { return fused_ok && h_state && h_state->free_cams; }
   bool lin_pts() const { return lin_pts_ok && h_state && h_state->free_cams; }   // f64: points linearised inside k_schur_sym
-  int n_lin_parts() const { return (fused() || lin_pts()) ? ksplit : nblk; }       // entries of cost_part / gmax_part
+  int n_lin_parts() const { return (fused() || lin_pts()) ? ksplit : n_linp_blocks(); }       // entries of cost_part / gmax_part
   void launch_schur() {
     if constexpr (sizeof(T) == 4) {
       if (fused() && fused_wide) { launch_schur_wide(); return; }
@@ -964,6 +977,9 @@ struct Engine : EngineBase {
   bool backsub_wide = false;         // 17 .. 23 cameras: k_backsub_dense<T, 32> / <T, 0>
   bool backsub_pack = false;
   bool backsub_wave = false;         // 33 .. 128 cameras: k_backsub_dense<T, 64>
+  int linp_lw = 0;                   // 24 .. 128 cameras with (point, camera) tables: k_linearize_points_wave<T, 32 / 64>; 0 = k_linearize_points
+  int nlinp = 0;                     // ... its (persistent) workgroups = entries of cost_part / gmax_part
+  int n_linp_blocks() const { return linp_lw ? nlinp : nblk; }
   bool backsub_dense() const { return dense_one_group || backsub_masked || backsub_wide || backsub_wave; }
   int n_trial_parts() const { return backsub_dense() ? nbs_dense : nblk; }
   void launch_backsub_trial() {
@@ -1708,13 +1724,14 @@ struct Engine : EngineBase {
     launch_linearize_points(nullptr);
     double gmax = 0;
     // the small results land in pinned memory: [gmax partials | cost partials | camera gradient | cameras]
-    const size_t need = 2 * (size_t)nblk + 2 * (size_t)n;
+    const int nlp = nblk ? n_linp_blocks() : 0;          // partials of the linearisation launched above
+    const size_t need = 2 * (size_t)nlp + 2 * (size_t)n;
     std::vector<double> land_v(need > LAND_DOUBLES ? need : 0);
     double* land = land_v.empty() ? h_land : land_v.data();
-    double *gm = land, *cp = land + nblk, *gch = land + 2 * (size_t)nblk, *cams_l = gch + n;
-    if (nblk) {
-      HIPCHK(hipMemcpyAsync(gm, gmax_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipMemcpyAsync(cp, cost_part.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, stream));
+    double *gm = land, *cp = land + nlp, *gch = land + 2 * (size_t)nlp, *cams_l = gch + n;
+    if (nlp) {
+      HIPCHK(hipMemcpyAsync(gm, gmax_part.p, sizeof(double) * nlp, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(cp, cost_part.p, sizeof(double) * nlp, hipMemcpyDeviceToHost, stream));
     }
     if (h_state->free_cams) {
       launch_linearize_cams(nullptr);
@@ -1733,7 +1750,7 @@ struct Engine : EngineBase {
     HIPCHK(hipGetLastError());
     if (cams_out) std::memcpy(cams_out, cams_l, sizeof(double) * n);
     double cost = 0;
-    for (int i = 0; i < nblk; ++i) { gmax = std::max(gmax, gm[i]); cost += cp[i]; }
+    for (int i = 0; i < nlp; ++i) { gmax = std::max(gmax, gm[i]); cost += cp[i]; }
     if (multi()) {       // whole-job figures: cost and camera gradient are sums over the ranks, the point-gradient maximum a max
       std::vector<double> v(n + 1);
       for (int i = 0; i < n; ++i) v[i] = gch[i];

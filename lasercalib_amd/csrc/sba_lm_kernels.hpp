@@ -720,6 +720,84 @@ __global__ __launch_bounds__(PM_BLOCK) void k_backsub_dense(
   }
 }
 
+// ------------------------------------------------------------------ K3a with lane = (point, camera): 24 .. 128 cameras (round 4)
+// k_linearize_points (lane = observation, the nine per-point sums through an LDS pass in doubles, one workgroup per point-aligned
+// block) laid out like k_backsub_dense<T, 32 / 64>: a point per wave half (24 .. 32 cameras) or per wave with up to two cameras per
+// lane (33 .. 128), the sums V_p (6) and g_p (3) as DPP / row-swap lane sums, persistent workgroups (camera table staged once) and
+// one cost / max|g_p| partial per workgroup instead of one per 256 observations (k_decide folded 50 000 of them at 64 x 200k).
+template <typename T, int LW>
+__global__ __launch_bounds__(PM_BLOCK) void k_linearize_points_wave(
+    const ParamSets<T> ps, const LMState* __restrict__ st, int C, const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w, int N,
+    const uint16_t* __restrict__ vis /* [groups][N] visibility masks, or NULL: dense (observation (p, c) at p C + c) */,
+    const int32_t* __restrict__ pt_start /* [groups][N] first observation of the point in the group */,
+    double* __restrict__ V, double* __restrict__ gp, double* __restrict__ D2p, double* __restrict__ cost_part, double* __restrict__ gmax_part) {
+  static_assert(LW == 32 || LW == 64, "a point per wave half or per wave");
+  constexpr int CPL = LW == 64 ? 2 : 1, MAXC = LW == 64 ? 128 : 32, PPC = PM_BLOCK / LW;
+  __shared__ T s_cam[MAXC * CAMPRE];
+  __shared__ double s_scr[PM_BLOCK / 64];
+  if (st && (st->status >= 0 || !st->need_lin)) return;
+  const int cur_ = ps_cur(ps, st);
+  const T* __restrict__ ptsT = ps.ptsT[cur_];
+  stage_campre(ps.campre[cur_], s_cam, C);
+  __syncthreads();
+  const int q = (int)threadIdx.x / LW, c = (int)threadIdx.x % LW, cc = c & 15;
+  const bool cam_ok = c < C;
+  auto lane_sum = [&](T v) -> T {
+    if constexpr (LW == 32) return half32_sum(v);
+    else return wave64_sum(v);
+  };
+  double sq = 0, gmax = 0;
+  const int nch = (N + PPC - 1) / PPC;
+  for (int ch = blockIdx.x; ch < nch; ch += gridDim.x) {
+    const int p = ch * PPC + q;
+    const bool pt_ok = p < N;
+    const size_t pp = (size_t)(pt_ok ? p : 0);
+    const T X0 = ptsT[pp * 3], X1 = ptsT[pp * 3 + 1], X2 = ptsT[pp * 3 + 2];
+    T v[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) v[e] = (T)0;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int cj = c + 64 * j;
+      const bool cam_j = j == 0 ? cam_ok : cj < C;
+      const int gj = (cam_j ? cj : 0) >> 4;
+      unsigned mask = 0xffffu;
+      size_t o = pp * C + cj;
+      if (vis) { mask = vis[(size_t)gj * N + pp]; o = (size_t)pt_start[(size_t)gj * N + pp] + __builtin_popcount(mask & ((1u << cc) - 1u)); }
+      if (pt_ok && cam_j && ((mask >> cc) & 1u)) {
+        const auto m = uv[o];
+        const T ww = w ? w[o] : (T)1;
+        T r[2], Jc[2][NCP], Jp[2][3];
+        obs_resjac<T>(s_cam + cj * CAMPRE, X0, X1, X2, m.x, m.y, ww, r, Jc, Jp);
+        if (ps.loss_delta > 0.f) sq += (double)robust_apply<T>(ps.loss(), r, Jc, Jp);
+        else sq += (double)r[0] * r[0] + (double)r[1] * r[1];
+        v[0] += Jp[0][0] * Jp[0][0] + Jp[1][0] * Jp[1][0];
+        v[1] += Jp[0][0] * Jp[0][1] + Jp[1][0] * Jp[1][1];
+        v[2] += Jp[0][0] * Jp[0][2] + Jp[1][0] * Jp[1][2];
+        v[3] += Jp[0][1] * Jp[0][1] + Jp[1][1] * Jp[1][1];
+        v[4] += Jp[0][1] * Jp[0][2] + Jp[1][1] * Jp[1][2];
+        v[5] += Jp[0][2] * Jp[0][2] + Jp[1][2] * Jp[1][2];
+        v[6] += Jp[0][0] * r[0] + Jp[1][0] * r[1];
+        v[7] += Jp[0][1] * r[0] + Jp[1][1] * r[1];
+        v[8] += Jp[0][2] * r[0] + Jp[1][2] * r[1];
+      }
+    }
+    double S[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) S[e] = (double)lane_sum(v[e]);
+    if (pt_ok && c == 0) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) V[pp * 6 + e] = S[e];
+      D2p[pp * 3] = fmax(D2p[pp * 3], S[0]); D2p[pp * 3 + 1] = fmax(D2p[pp * 3 + 1], S[3]); D2p[pp * 3 + 2] = fmax(D2p[pp * 3 + 2], S[5]);
+      gp[pp * 3] = S[6]; gp[pp * 3 + 1] = S[7]; gp[pp * 3 + 2] = S[8];
+      if (!pt_fixed(ps, pp)) gmax = fmax(gmax, fmax(fabs(S[6]), fmax(fabs(S[7]), fabs(S[8]))));      // a fixed point is not an unknown
+    }
+  }
+  const double cs = block_sum(sq, s_scr);
+  const double gm = block_max(gmax, s_scr);
+  if (threadIdx.x == 0) { cost_part[blockIdx.x] = 0.5 * cs; gmax_part[blockIdx.x] = gm; }
+}
+
 // ------------------------------------------------------------------ start of a solve
 // What lm_begin has to reset on the device, in one launch instead of three memsets and two copies (each a separate enqueue of a few
 // microseconds on the host): the monotone column scalings and the camera step are cleared, the trial camera buffers start as copies of
