@@ -110,6 +110,10 @@ struct Engine : EngineBase {
   DevBuf<unsigned> chol_flags;          // k_chol_big_back_all: x_b published (value = the launch's epoch)
   unsigned chol_epoch = 0;
   bool chol_big_back_one = true;        // SBA_CHOL_BIG_BACK=launches keeps one launch per block (rounds 1-3)
+  DevBuf<unsigned> chol_dag_flags;      // k_chol_big_dag: Mimg_j / W(r,c) published (value = the launch's epoch)
+  DevBuf<double> chol_Mimg;             // k_chol_big_dag: the factored diagonal blocks and their inverses, as they lie in LDS
+  unsigned chol_dag_epoch = 0;
+  bool chol_big_dag = true;             // SBA_CHOL_BIG=launches keeps one launch per block column (rounds 1-3)
   bool chol_debug = false;
   bool schur_debug = false;
   int schur_exp = 0;                  // SBA_SCHUR_EXP: timing experiments of k_schur_fused_bf3 (its results are wrong when set)
@@ -224,6 +228,7 @@ struct Engine : EngineBase {
     if (getenv("SBA_CHOL_DEBUG")) chol_debug = true;
     if (const char* e = getenv("SBA_SCHUR_EXP")) schur_exp = atoi(e);
     if (const char* e = getenv("SBA_CHOL_BIG_BACK")) chol_big_back_one = std::string(e) != "launches";
+    if (const char* e = getenv("SBA_CHOL_BIG")) chol_big_dag = std::string(e) != "launches";
     if (const char* e = getenv("SBA_CHOL_F32")) chol_f32 = atoi(e) != 0;
     if (const char* e = getenv("SBA_CHOL_F32_TAU")) { char* end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0 && v < 1) chol_f32_tau = (float)v; }
     if (const char* e = getenv("SBA_CHOL_BIG_MIN_N")) {      // diagnostic: route smaller systems through the big path too
@@ -287,6 +292,7 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_ll<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_dag), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residual<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -1452,16 +1458,39 @@ struct Engine : EngineBase {
     hipLaunchKernelGGL(k_chol_big_prepare, dim3(nbr * (nbr + 1) / 2), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p,
                        chol_W.p, npad, chol_info.p);
     const size_t lds = (size_t)48 * CBS * sizeof(double);
-    for (int j = 0; j < nbr; ++j) {
-      const int q = nbr - 1 - j;
-      hipLaunchKernelGGL(k_chol_big_step, dim3(std::max(1, q * (q + 1) / 2)), dim3(CHOLBIG_THREADS), lds, stream, chol_W.p, npad, j,
-                         chol_Minv.p, chol_Ld.p, chol_info.p, d_state.p);
+    const bool dag = chol_big_dag && chol_big_back_one && nbr <= CHOLDAG_MAX_NBR;     // (the per-block back substitution reads the dense copies)
+    if (dag) {
+      // the whole factorisation in one launch: workgroup = tile, columns handed over through flags (sba_chol_big.hpp)
+      if (chol_dag_flags.n == 0) { chol_dag_flags.alloc(choldag_nflags(CHOLDAG_MAX_NBR)); chol_dag_flags.zero(stream); }
+      if (chol_Mimg.n < (size_t)nbr * CHOLDAG_IMG) chol_Mimg.alloc((size_t)CHOLDAG_MAX_NBR * CHOLDAG_IMG);
+      if (chol_debug) { chol_dbg.alloc(8 * (CHOLDAG_MAX_NBR + 1)); chol_dbg.zero(stream); }
+      hipLaunchKernelGGL(k_chol_big_dag, dim3(1 + nbr * (nbr + 1) / 2), dim3(CHOLBIG_THREADS), lds, stream, chol_W.p, npad, chol_Mimg.p,
+                         chol_dag_flags.p, ++chol_dag_epoch, chol_info.p, d_state.p, chol_debug ? chol_dbg.p : nullptr);
+      if (chol_debug) {
+        std::vector<long long> sv(8 * (CHOLDAG_MAX_NBR + 1));
+        HIPCHK(hipMemcpyAsync(sv.data(), chol_dbg.p, sv.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));
+        sync();
+        fprintf(stderr, "[chol_dag, the walker, x10 ns: wait for W(c,c-1), W(c,c) | load | panel | downdate | factor+inverse | image stored | flag]\n");
+        for (int cc = 0; cc < nbr; ++cc) {
+          const long long* v = sv.data() + 8 * cc;
+          fprintf(stderr, "  c=%2d at %6lld:", cc, v[4] - sv[0]);
+          if (cc > 0) fprintf(stderr, " wait %4lld | load %4lld | panel %4lld | downdate %4lld |", v[1] - sv[8 * (cc - 1) + 7], v[2] - v[1], v[3] - v[2], v[4] - v[3]);
+          fprintf(stderr, " factor %4lld | image %4lld | flag %4lld | column %5lld\n", v[5] - v[4], v[6] - v[5], v[7] - v[6], cc > 0 ? v[7] - sv[8 * (cc - 1) + 7] : v[7] - v[0]);
+        }
+        chol_debug = false;
+      }
+    } else {
+      for (int j = 0; j < nbr; ++j) {
+        const int q = nbr - 1 - j;
+        hipLaunchKernelGGL(k_chol_big_step, dim3(std::max(1, q * (q + 1) / 2)), dim3(CHOLBIG_THREADS), lds, stream, chol_W.p, npad, j,
+                           chol_Minv.p, chol_Ld.p, chol_info.p, d_state.p);
+      }
     }
     if (chol_big_back_one) {
       // the whole back substitution in one launch: block row = workgroup, x_b handed over through flags (sba_chol_big.hpp)
       if (chol_flags.n == 0) { chol_flags.alloc(64); chol_flags.zero(stream); }
       hipLaunchKernelGGL(k_chol_big_back_all, dim3(nbx), dim3(256), 0, stream, chol_W.p, npad, n_sys, chol_Ld.p, chol_Minv.p, chol_yv.p,
-                         chol_flags.p, ++chol_epoch, chol_sol.p, chol_info.p, d_state.p);
+                         chol_flags.p, ++chol_epoch, chol_sol.p, chol_info.p, d_state.p, dag ? chol_Mimg.p : (const double*)nullptr);
       return;
     }
     hipLaunchKernelGGL(k_chol_big_back_init, dim3((npad + 255) / 256), dim3(256), 0, stream, chol_W.p, npad, n_sys, chol_Ld.p,
