@@ -27,43 +27,70 @@ namespace SBA_NS {
 constexpr int BB = 64;                      // block edge of the big factorisation
 constexpr int BSUB = BB / CB;               // 4 sub-blocks of 16 per edge
 constexpr int CHOLBIG_THREADS = 512;
+constexpr int CHOLBIG_LDS_BLOCKS = 54;       // k_chol_big_step / k_chol_big_dag: diagonal block + inverse (16), two tiles (32), chol_big_factor64's scratch (6)
 constexpr double CHOLBIG_RHS_DIAG = 1e300;  // diagonal entry of the appended rhs row: keeps the augmented matrix PD
+constexpr float CHOLBIG_RHS_DIAG_F32 = 1e30f;   // ... on f32 lanes (k_chol_big_dag<float>)
 
 __host__ __device__ inline int cholbig_rhs_row(int n) { return ((n + CB - 1) / CB) * CB; }
 __host__ __device__ inline int cholbig_npad(int n) { return ((cholbig_rhs_row(n) + 1 + BB - 1) / BB) * BB; }
 
-// one 16x16x16 product on LDS sub-blocks (17-double rows): acc += sign * op(A) * op(B)
+// Everything below works on 16 x 16 sub-blocks in LDS in either scalar type: S = double (17-double rows, v_mfma_f64_16x16x4: 64
+// cycles on gfx950) or S = float (20-float rows, v_mfma_f32_16x16x4: 32 cycles; the fp32 engine's k_chol_big_dag).  CholLay<S>
+// (sba_chol_blocked.hpp) carries the row stride LD, the block size BS and the packed lower-triangle numbering off(r, c).
+
+// one 16x16x16 product on LDS sub-blocks: acc += sign * op(A) * op(B)
 //   AT: A is read transposed (A[k][row]),  BT: B is read transposed (B[col][k])
-template <bool AT, bool BT>
-__device__ __forceinline__ Mfma<double>::acc_t mm16(const double* __restrict__ A, const double* __restrict__ B,
-                                                    Mfma<double>::acc_t acc, double sign) {
+template <bool AT, bool BT, typename S = double>
+__device__ __forceinline__ typename Mfma<S>::acc_t mm16(const S* __restrict__ A, const S* __restrict__ B, typename Mfma<S>::acc_t acc,
+                                                        S sign = (S)1) {
+  using L = CholLay<S>;
   const int lane = threadIdx.x & 63;
   const int rc = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int k = 4 * ks + kq;
-    const double a = AT ? A[k * CLD + rc] : A[rc * CLD + k];
-    const double b = BT ? B[rc * CLD + k] : B[k * CLD + rc];
-    acc = Mfma<double>::mma(sign * a, b, acc);
+    const S a = AT ? A[k * L::LD + rc] : A[rc * L::LD + k];
+    const S b = BT ? B[rc * L::LD + k] : B[k * L::LD + rc];
+    acc = Mfma<S>::mma(sign * a, b, acc);
   }
   return acc;
 }
-__device__ __forceinline__ void store16(double* __restrict__ blk, const Mfma<double>::acc_t& acc) {
+template <typename S = double>
+__device__ __forceinline__ void store16(S* __restrict__ blk, const typename Mfma<S>::acc_t& acc) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) blk[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] = acc[rg];
+  for (int rg = 0; rg < 4; ++rg) blk[Mfma<S>::row_of(lane, rg) * CholLay<S>::LD + (lane & 15)] = acc[rg];
+}
+template <typename S = double>
+__device__ __forceinline__ typename Mfma<S>::acc_t load16(const S* __restrict__ blk) {
+  const int lane = threadIdx.x & 63;
+  typename Mfma<S>::acc_t acc;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) acc[rg] = blk[Mfma<S>::row_of(lane, rg) * CholLay<S>::LD + (lane & 15)];
+  return acc;
+}
+// D -= Pa Pb^T for one 16x16 tile by the calling wave (see chol_update_tile)
+template <typename S>
+__device__ __forceinline__ void chol_update_tile_t(S* __restrict__ Dt, const S* __restrict__ Pa_blk, const S* __restrict__ Pb_blk) {
+  typename Mfma<S>::acc_t prod = {0, 0, 0, 0};
+  const typename Mfma<S>::acc_t acc = load16<S>(Dt);
+  prod = mm16<false, true, S>(Pa_blk, Pb_blk, prod);
+  store16<S>(Dt, acc - prod);
+  __builtin_amdgcn_wave_barrier();
 }
 
-// 64x64 block of W (rows r0.., columns c0..) -> 4x4 sub-blocks in LDS ((sr*4 + sc) * CBS); lower_only: sub-blocks with
-// sc > sr are skipped and the destination uses the packed lower numbering cb_off(sr, sc)
-template <bool LOWER_ONLY>
-__device__ __forceinline__ void load_block64(const double* __restrict__ W, int npad, int r0, int c0, double* __restrict__ dst) {
-  double2 v[BB * BB / 2 / CHOLBIG_THREADS];
+// 64x64 block of W (rows r0.., columns c0..) -> 4x4 sub-blocks in LDS ((sr*4 + sc) * BS); lower_only: sub-blocks with
+// sc > sr are skipped and the destination uses the packed lower numbering off(sr, sc)
+template <bool LOWER_ONLY, typename S = double>
+__device__ __forceinline__ void load_block64(const S* __restrict__ W, int npad, int r0, int c0, S* __restrict__ dst) {
+  using L = CholLay<S>;
+  using V2 = typename Vec2<S>::type;
+  V2 v[BB * BB / 2 / CHOLBIG_THREADS];
 #pragma unroll
   for (int u = 0; u < BB * BB / 2 / CHOLBIG_THREADS; ++u) {
     const int e = threadIdx.x + u * CHOLBIG_THREADS;
     const int row = e >> 5, col = (e & 31) * 2;
-    v[u] = *reinterpret_cast<const double2*>(W + (size_t)(r0 + row) * npad + c0 + col);
+    v[u] = *reinterpret_cast<const V2*>(W + (size_t)(r0 + row) * npad + c0 + col);
   }
 #pragma unroll
   for (int u = 0; u < BB * BB / 2 / CHOLBIG_THREADS; ++u) {
@@ -71,77 +98,131 @@ __device__ __forceinline__ void load_block64(const double* __restrict__ W, int n
     const int row = e >> 5, col = (e & 31) * 2;
     const int sr = row >> 4, sc = col >> 4;
     if (LOWER_ONLY && sc > sr) continue;
-    double* d = dst + (LOWER_ONLY ? cb_off(sr, sc) : (sr * BSUB + sc) * CBS) + (row & 15) * CLD + (col & 15);
+    S* d = dst + (LOWER_ONLY ? L::off(sr, sc) : (sr * BSUB + sc) * L::BS) + (row & 15) * L::LD + (col & 15);
     d[0] = v[u].x; d[1] = v[u].y;
   }
 }
 
 // ------------------------------------------------------------------ the 64 x 64 diagonal block, by one workgroup of 512 threads
-// Dg: its 10 lower sub-blocks (packed, cb_off) -> the factor's sub-blocks below the diagonal and T = Linv^T of the diagonal sub-blocks;
-// Mi: the 6 strictly-lower sub-blocks of the inverse of the factor.  *s_fail is set when a pivot is not positive.
-__device__ __forceinline__ double* chol_big_mi_blk(double* Mi, int a, int b) { return Mi + (a * (a - 1) / 2 + b) * CBS; }
+// Dg: its 10 lower sub-blocks (packed, off) -> the factor's sub-blocks below the diagonal and T = Linv^T of the diagonal sub-blocks;
+// Mi: the 6 strictly-lower sub-blocks of the inverse of the factor.  *s_fail is set when a pivot is not positive (S = float: or has
+// sunk below tau * a0: chol16_wave_t).
+template <typename S>
+__device__ __forceinline__ S* chol_big_mi_blk(S* Mi, int a, int b) { return Mi + (a * (a - 1) / 2 + b) * CholLay<S>::BS; }
 struct CholBigNoHook { __device__ __forceinline__ void operator()() const {} };
-// The 64 pivots are the chain (wave 0: chol16_wave four times); everything else hangs off it.  The inverse's sub-blocks are formed
-// as soon as their inputs are final, by waves the panel / downdate phases leave idle, so that after the last pivot only the
-// bottom row Minv(3, 0..2) is left -- three independent blocks on three waves.  11 barriers (15 with the inverse as a
-// separate pass).  `hook` is called by waves 4..7 while wave 0 works on the last diagonal sub-block (nothing else runs then):
-// k_chol_big_dag's walker fetches its next two tiles there.
-template <typename Hook = CholBigNoHook>
-__device__ __forceinline__ void chol_big_factor64(double* __restrict__ Dg, double* __restrict__ Mi, int* __restrict__ s_fail,
-                                                  Hook&& hook = Hook()) {
+// (A T)^T for one sub-block as MFMA accumulators -- exactly the operand layout of the products that follow (chol_panel_update_diag_t)
+template <typename S>
+__device__ __forceinline__ typename Mfma<S>::acc_t chol_big_panel_T(const S* __restrict__ Ablk, const S* __restrict__ LinvT) {
+  using L = CholLay<S>;
+  const int lane = threadIdx.x & 63;
+  const S* Pa = Ablk + (lane & 15) * L::LD + (lane >> 4);
+  const S* Pl = LinvT + (lane >> 4) * L::LD + (lane & 15);
+  typename Mfma<S>::acc_t pt = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) pt = Mfma<S>::mma(Pl[4 * ks * L::LD], Pa[4 * ks], pt);
+  return pt;
+}
+template <typename S>
+__device__ __forceinline__ void chol_big_store_T(S* __restrict__ blk, const typename Mfma<S>::acc_t& pt) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) blk[(lane & 15) * CholLay<S>::LD + Mfma<S>::row_of(lane, rg)] = pt[rg];
+}
+template <typename S>
+__device__ __forceinline__ typename Mfma<S>::acc_t chol_big_abT(const typename Mfma<S>::acc_t& pa, const typename Mfma<S>::acc_t& pb) {
+  typename Mfma<S>::acc_t pp = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) pp = Mfma<S>::mma(pa[ks], pb[ks], pp);
+  return pp;
+}
+// The 64 pivots are the chain: wave 0 runs chol16_wave four times and, between two of them, only forms the next sub-diagonal
+// block L(jb+1,jb) and downdates the next diagonal sub-block (accumulators of the one product are the operands of the other: no
+// LDS round trip) -- ONE barrier per sub-block column.  The other waves downdate the rest of the trailing sub-blocks behind it,
+// each forming the two panel blocks it needs itself (nothing to wait for but T_jb), and build the inverse's sub-blocks as their
+// inputs become final: after the last pivot only the bottom row Minv(3, 0..2) is left, three independent blocks on three waves.
+// The factor's sub-blocks are collected in Lo (6 sub-blocks of scratch: the blocks of A they come from stay readable for the
+// other waves) and copied into Dg at the end.  5 barriers (15 in round 3's version).
+// Waves 4..7 have nothing to do from sub-block column 1 on: they call `issue` while wave 0 works on the third diagonal sub-block
+// and `commit` while it works on the last -- k_chol_big_dag's walker requests its next two tiles in the one and puts them into LDS
+// in the other.  The barriers wait for LDS only (lds_barrier), so the requests stay in flight across them.
+template <typename S = double, typename Issue = CholBigNoHook, typename Commit = CholBigNoHook>
+__device__ __forceinline__ void chol_big_factor64(S* __restrict__ Dg, S* __restrict__ Mi, S* __restrict__ Lo, int* __restrict__ s_fail,
+                                                  const S* __restrict__ a0 = nullptr, S tau = (S)0,
+                                                  Issue&& issue = Issue(), Commit&& commit = Commit()) {
+  using L = CholLay<S>;
+  using acc_t = typename Mfma<S>::acc_t;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  auto lo = [&](int a, int b) { return Lo + (a * (a - 1) / 2 + b) * L::BS; };
   // Minv(a,b) = -T_a^T * sum_{k=b}^{a-1} L(a,k) Minv(k,b)   (the diagonal sub-blocks hold T = Linv^T; Minv(b,b) = T_b^T)
   auto inv_blk = [&](int a, int b) {
-    Mfma<double>::acc_t p = {0, 0, 0, 0};
-    p = mm16<false, true>(Dg + cb_off(a, b), Dg + cb_off(b, b), p, 1.0);          // L(a,b) * T_b^T
-    for (int k = b + 1; k < a; ++k) p = mm16<false, false>(Dg + cb_off(a, k), chol_big_mi_blk(Mi, k, b), p, 1.0);
-    double* dst = chol_big_mi_blk(Mi, a, b);
-    store16(dst, p);
+    acc_t p = {0, 0, 0, 0};
+    p = mm16<false, true, S>(lo(a, b), Dg + L::off(b, b), p);                     // L(a,b) * T_b^T
+    for (int k = b + 1; k < a; ++k) p = mm16<false, false, S>(lo(a, k), chol_big_mi_blk<S>(Mi, k, b), p);
+    S* dst = chol_big_mi_blk<S>(Mi, a, b);
+    store16<S>(dst, p);
     __builtin_amdgcn_wave_barrier();
-    Mfma<double>::acc_t m = {0, 0, 0, 0};
-    m = mm16<true, false>(Dg + cb_off(a, a), dst, m, -1.0);                       // -(T_a)^T * P
+    acc_t m = {0, 0, 0, 0};
+    m = mm16<true, false, S>(Dg + L::off(a, a), dst, m, (S)-1);                   // -(T_a)^T * P
     __builtin_amdgcn_wave_barrier();
-    store16(dst, m);
+    store16<S>(dst, m);
   };
-  auto pivots = [&](int jb) { if (!chol16_wave(Dg + cb_off(jb, jb))) { if (lane == 0) *s_fail = 1; } };
-  auto upd = [&](int jb, int a, int b) { chol_update_tile(Dg + cb_off(jb + 1 + a, jb + 1 + b), Dg + cb_off(jb + 1 + a, jb), Dg + cb_off(jb + 1 + b, jb)); };
-  // ---- sub-block column 0
+  auto pivots = [&](int jb) {
+    const bool ok = chol16_wave_t<S, sizeof(S) == 8, L>(Dg + L::off(jb, jb), a0 ? a0 + jb * CB : nullptr, tau);
+    if (!ok && lane == 0) *s_fail = 1;
+  };
+  // wave 0 between two diagonal sub-blocks: L(jb+1,jb) -> Lo, A(jb+1,jb+1) -= L L^T
+  auto next_diag = [&](int jb) {
+    const acc_t pt = chol_big_panel_T<S>(Dg + L::off(jb + 1, jb), Dg + L::off(jb, jb));
+    const acc_t d = load16<S>(Dg + L::off(jb + 1, jb + 1)) - chol_big_abT<S>(pt, pt);
+    chol_big_store_T<S>(lo(jb + 1, jb), pt);
+    store16<S>(Dg + L::off(jb + 1, jb + 1), d);
+    __builtin_amdgcn_wave_barrier();
+  };
+  // another wave: A(a,b) -= L(a,jb) L(b,jb)^T with both panel blocks formed here; keep: L(a,jb) -> Lo
+  auto tile = [&](int jb, int a, int b, bool keep) {
+    const acc_t pa = chol_big_panel_T<S>(Dg + L::off(a, jb), Dg + L::off(jb, jb));
+    const acc_t pb = (a == b) ? pa : chol_big_panel_T<S>(Dg + L::off(b, jb), Dg + L::off(jb, jb));
+    const acc_t d = load16<S>(Dg + L::off(a, b)) - chol_big_abT<S>(pa, pb);
+    store16<S>(Dg + L::off(a, b), d);
+    if (keep) chol_big_store_T<S>(lo(a, jb), pa);
+  };
   if (wid == 0) pivots(0);
-  __syncthreads();
-  if (wid < 3) chol_panel_block(Dg + cb_off(1 + wid, 0), Dg + cb_off(0, 0));
-  __syncthreads();
-  if (wid < 6) {
-    int a = 0;
-    while ((a + 1) * (a + 2) / 2 <= wid) ++a;
-    upd(0, a, wid - a * (a + 1) / 2);
-  }
-  __syncthreads();
-  // ---- sub-block column 1
-  if (wid == 0) pivots(1);
-  __syncthreads();
-  if (wid < 2) chol_panel_block(Dg + cb_off(2 + wid, 1), Dg + cb_off(1, 1));
-  else if (wid == 2) inv_blk(1, 0);
-  __syncthreads();
-  if (wid < 3) {
-    const int a = (wid == 0) ? 0 : 1;
-    upd(1, a, wid - a * (a + 1) / 2);
-  }
-  __syncthreads();
-  // ---- sub-block column 2
-  if (wid == 0) pivots(2);
-  __syncthreads();
-  if (wid == 0) chol_panel_block(Dg + cb_off(3, 2), Dg + cb_off(2, 2));
+  lds_barrier();
+  // ---- behind T_0
+  if (wid == 0) { next_diag(0); pivots(1); }
+  else if (wid == 1) tile(0, 2, 1, true);
+  else if (wid == 2) tile(0, 2, 2, false);
+  else if (wid == 3) tile(0, 3, 1, true);
+  else if (wid == 4) tile(0, 3, 2, false);
+  else if (wid == 5) tile(0, 3, 3, false);
+  lds_barrier();
+  // ---- behind T_1
+  if (wid == 0) { next_diag(1); pivots(2); }
+  else if (wid == 1) tile(1, 3, 2, true);
+  else if (wid == 2) tile(1, 3, 3, false);
+  else if (wid == 3) inv_blk(1, 0);
+  else issue();
+  lds_barrier();
+  // ---- behind T_2
+  if (wid == 0) { next_diag(2); pivots(3); }
   else if (wid == 1) inv_blk(2, 1);
-  __syncthreads();
-  if (wid == 0) upd(2, 0, 0);
-  else if (wid == 1) inv_blk(2, 0);
-  __syncthreads();
-  // ---- sub-block column 3
-  if (wid == 0) pivots(3);
-  else if (wid >= 4) hook();
-  __syncthreads();
+  else if (wid == 2) inv_blk(2, 0);
+  else if (wid >= 4) commit();
+  lds_barrier();
+  // ---- behind T_3: the inverse's bottom row; the factor's sub-blocks go to their places
   if (wid < 3) inv_blk(3, wid);
-  __syncthreads();
+  else {
+    for (int q = wid - 3; q < 6; q += 5) {
+      int a = 1;
+      while (a * (a + 1) / 2 <= q) ++a;
+      const int b = q - a * (a - 1) / 2;
+      const S* src = Lo + q * L::BS;
+      S* dst = Dg + L::off(a, b);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = lane + 64 * u; dst[(e >> 4) * L::LD + (e & 15)] = src[(e >> 4) * L::LD + (e & 15)]; }
+    }
+  }
+  lds_barrier();
 }
 // dense copies for the consumers and the back substitution: Minv (lower, row-major) and the factor's strictly-lower sub-blocks
 template <bool MINV = true, bool LD = true>
@@ -151,7 +232,7 @@ __device__ __forceinline__ void chol_big_publish_factor(const double* __restrict
     const int i = e >> 6, k = e & 63, si = i >> 4, sk = k >> 4;
     double mv = 0, lv = 0;
     if (si == sk) mv = Dg[cb_off(si, si) + (k & 15) * CLD + (i & 15)];           // Linv[i][k] = T[k][i]
-    else if (si > sk) { mv = chol_big_mi_blk(Mi, si, sk)[(i & 15) * CLD + (k & 15)]; lv = Dg[cb_off(si, sk) + (i & 15) * CLD + (k & 15)]; }
+    else if (si > sk) { mv = chol_big_mi_blk<double>(Mi, si, sk)[(i & 15) * CLD + (k & 15)]; lv = Dg[cb_off(si, sk) + (i & 15) * CLD + (k & 15)]; }
     if (MINV) Mg[e] = mv;
     if (LD) Lg[e] = lv;
   }
@@ -216,7 +297,7 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_step(double* __res
     if (c != r) load_block64<false>(W, npad, c * BB, j * BB, Ac);
   }
   __syncthreads();
-  chol_big_factor64(Dg, Mi, &s_fail);
+  chol_big_factor64(Dg, Mi, Ac + 16 * CBS, &s_fail);
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0 && s_fail) atomicOr(info, 1);
     chol_big_publish_factor(Dg, Mi, Minv_ws + (size_t)j * BB * BB, Ld_ws + (size_t)j * BB * BB);
@@ -265,35 +346,88 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_step(double* __res
 
 // ------------------------------------------------------------------ the factorisation in ONE launch: the tile DAG (round 4)
 // One launch per block column pays, per column, a launch boundary, the cold loads behind it and a factorisation of the diagonal
-// block repeated by every workgroup: 19.4 us per column at n = 704, of which the chain that cannot be avoided -- the 64 pivots of
-// the diagonal block, its inverse, one panel block and one downdate -- is about 13.  Here the whole factorisation is one launch:
+// block repeated by every workgroup: 19.4 us per column at n = 704.  Here the whole factorisation -- and k_chol_big_prepare's work
+// in front of it -- is one launch:
 //   workgroup 0, the WALKER, goes down the diagonal: it factors block (c,c) in LDS, inverts the factor, publishes both as one
-//     image (Mimg_c: the 10 + 6 sub-blocks exactly as they lie in LDS), then takes W(c+1,c) and the partial W(c+1,c+1), forms
-//     L(c+1,c) and the downdate itself -- the serial chain of the factorisation never leaves its LDS;
-//   workgroup 1 + t OWNS tile t = (r, c), c <= r, of the lower block triangle (numbered column by column).  It keeps the tile in
-//     its accumulators and applies the columns j as they become available (wait W(r,j), W(c,j) final -> wait Mimg_j ->
-//     L(r,j) = W(r,j) Minv_j^T, L(c,j) likewise -> tile -= L(r,j) L(c,j)^T): j < c below the diagonal, after which it publishes
-//     the final W(r,c) and, once Mimg_c is there, L(r,c) into the upper block (c, r) for the back substitution;  j < c - 1 on the
-//     diagonal, after which it hands the partial tile to the walker.
+//     image (Mimg_c: the 10 + 6 sub-blocks exactly as they lie in LDS), then takes W(c+1,c) and the partial W(c+1,c+1) (fetched
+//     by its idle waves while the last 16 pivots run), forms L(c+1,c) and the downdate itself -- the serial chain of the
+//     factorisation never leaves its LDS;
+//   workgroup 1 + t OWNS tile t = (r, c), c <= r, of the lower block triangle (numbered column by column).  It forms the tile of
+//     the damped system from E, keeps it in its accumulators and applies the columns j as they become available (wait W(r,j),
+//     W(c,j) final -> wait Mimg_j -> L(r,j) = W(r,j) Minv_j^T, L(c,j) likewise -> tile -= L(r,j) L(c,j)^T): j < c below the
+//     diagonal, after which it publishes the final W(r,c) and, once Mimg_c is there, L(r,c) into the upper block (c, r) for the
+//     back substitution;  j < c - 1 on the diagonal, after which it hands the partial tile to the walker.
+// Tiles nobody has written yet (column 0, tile (1,1)) are formed from E by whoever needs them.
+// Scalar type S: double, or float for the fp32 engine (f32 pivots: ~155 cycles per pivot instead of ~275, f32 MFMAs: 32 cycles
+// instead of 64, half the bytes handed over): a factorisation that fails or whose pivots sink below tau * (their diagonal entry)
+// raises LMState::chol_retry, and the f64 instance launched behind it (only_if_retry) does the solve again from E.
 // Hand-overs are epoch flags (one per diagonal block, one per tile) set by a release after a barrier; every wait is bounded
 // (CHOLBIG_WAIT_TICKS, then info |= 2: a rejected LM step) and a timed-out workgroup raises an abort flag the others watch.
 // Progress does not need the whole launch to be resident (a card shared with other processes), only in-order dispatch: the
 // walker is dispatched first, and what it needs to publish Mimg_j are tiles (j, j-1) and (j, j), which are numbered below every
 // tile that waits for Mimg_j.  Up to CHOLDAG_MAX_NBR block rows the launch is resident as a whole (254 workgroups, one per CU).
 constexpr int CHOLDAG_MAX_NBR = 22;
-constexpr int CHOLDAG_IMG = 16 * CBS;                      // doubles per published diagonal block: Dg (10 sub-blocks) + Mi (6)
 constexpr long long CHOLBIG_WAIT_TICKS = 200000000LL;      // 2 s of the 100 MHz clock
+constexpr long long CHOLBIG_X_EMPTY = 0x7ff8dead5ba0e111LL; // k_chol_big_back_all: "x_b not there yet" (a NaN payload no computation produces)
+template <typename S> __host__ __device__ constexpr int choldag_img() { return 16 * CB * (sizeof(S) == 8 ? CLD : 20); }   // Dg (10 sub-blocks) + Mi (6)
 __host__ __device__ inline int choldag_nflags(int nbr) { return nbr + nbr * nbr + 1; }
 // entries of the image: Minv[i][k] (lower) and the factor's strictly-lower sub-blocks L[i][k]
-__device__ __forceinline__ double choldag_img_minv(const double* __restrict__ img, int i, int k) {
+template <typename S>
+__device__ __forceinline__ double choldag_img_minv(const S* __restrict__ img, int i, int k) {
+  using L = CholLay<S>;
   const int si = i >> 4, sk = k >> 4;
-  if (si == sk) return img[cb_off(si, si) + (k & 15) * CLD + (i & 15)];                              // Linv[i][k] = T[k][i]
-  if (si > sk) return img[10 * CBS + (si * (si - 1) / 2 + sk) * CBS + (i & 15) * CLD + (k & 15)];
+  if (si == sk) return (double)img[L::off(si, si) + (k & 15) * L::LD + (i & 15)];                              // Linv[i][k] = T[k][i]
+  if (si > sk) return (double)img[10 * L::BS + (si * (si - 1) / 2 + sk) * L::BS + (i & 15) * L::LD + (k & 15)];
   return 0.0;
 }
-__device__ __forceinline__ double choldag_img_l(const double* __restrict__ img, int i, int k) {
+template <typename S>
+__device__ __forceinline__ double choldag_img_l(const S* __restrict__ img, int i, int k) {
+  using L = CholLay<S>;
   const int si = i >> 4, sk = k >> 4;
-  return (si > sk) ? img[cb_off(si, sk) + (i & 15) * CLD + (k & 15)] : 0.0;
+  return (si > sk) ? (double)img[L::off(si, sk) + (i & 15) * L::LD + (k & 15)] : 0.0;
+}
+
+// the damped, augmented system the factorisation works on (what k_chol_big_prepare writes into W)
+struct CholDagSys {
+  const double* E; int n, R; double lam; bool fresh; const double* D2c; const double* dU; const double* rhs; double big;
+  // lam * (camera scaling): monotone max of the squared column norms (x_scale='jac', scipy trf.py:424,545)
+  __device__ __forceinline__ double damping(int i) const {
+    const double d = D2c[i];
+    return lam * fmax_pos(fresh ? fmax(d, dU[i]) : d);
+  }
+  // entry (i, j), j <= i, outside the camera system proper: the rhs row R, its diagonal entry, identity padding
+  __device__ __forceinline__ double border(int i, int j) const {
+    if (i == R) return (j == R) ? big : (j < n ? rhs[j] : 0.0);
+    return (i == j) ? 1.0 : 0.0;
+  }
+  __device__ __forceinline__ double diag(int i) const { return i < n ? E[(size_t)i * n + i] + damping(i) : border(i, i); }
+};
+// block (br, bc), bc <= br, of the system -> 4 x 4 sub-blocks in LDS (LOWER_ONLY: the packed lower sub-blocks), by NTHR threads
+// numbered tid.  Everything a thread needs from memory is requested in one batch (clamped addresses): its entries of E and, on a
+// diagonal block, the damping of its column (a thread owns one column, so at most one diagonal entry); borders are patched in after.
+template <bool LOWER_ONLY, typename S, int NTHR>
+__device__ __noinline__ void choldag_block_from_sys(const CholDagSys sys, int br, int bc, S* __restrict__ dst, int tid) {
+  using L = CholLay<S>;
+  constexpr int U = BB * BB / NTHR;
+  double v[U];
+  const int col = tid & 63, j = bc * BB + col;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = br * BB + ((tid + u * NTHR) >> 6);
+    v[u] = sys.E[(i < sys.n && j < sys.n) ? (size_t)i * sys.n + j : 0];
+  }
+  double damp = 0;
+  if (br == bc) damp = sys.damping(j < sys.n ? j : 0);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int row = (tid + u * NTHR) >> 6, sr = row >> 4, sc = col >> 4;
+    const int i = br * BB + row;
+    double x = v[u];
+    if (!(i < sys.n && j < sys.n)) x = (j <= i) ? sys.border(i, j) : 0.0;
+    else if (i == j) x += damp;
+    if (LOWER_ONLY && sc > sr) continue;
+    dst[(LOWER_ONLY ? L::off(sr, sc) : (sr * BSUB + sc) * L::BS) + (row & 15) * L::LD + (col & 15)] = (S)x;
+  }
 }
 
 // wave 0 polls up to two flags (lanes 0 and 1) until both carry the epoch; everybody leaves through a barrier and an acquire fence
@@ -325,106 +459,133 @@ __device__ __forceinline__ void choldag_publish(unsigned* flag, unsigned epoch) 
 }
 // one output block of a panel:  Lp(ri, CI) = sum_{k < CI} Ap(ri,k) Minv(CI,k)^T + Ap(ri,CI) T_CI, operands fetched ahead of the MFMAs.
 // F is the image of the diagonal block: T = Linv^T on the diagonal of Dg, the inverse's lower sub-blocks in Mi
-template <int CI>
-__device__ __forceinline__ Mfma<double>::acc_t choldag_panel_out(const double* __restrict__ Aprow, const double* __restrict__ F) {
+template <int CI, typename S>
+__device__ __forceinline__ typename Mfma<S>::acc_t choldag_panel_out(const S* __restrict__ Aprow, const S* __restrict__ F) {
+  using L = CholLay<S>;
   const int lane = threadIdx.x & 63, rc = lane & 15, kq = lane >> 4;
-  const double* Mi = F + 10 * CBS;
-  double a[(CI + 1) * 4], b[(CI + 1) * 4];
+  const S* Mi = F + 10 * L::BS;
+  S a[(CI + 1) * 4], b[(CI + 1) * 4];
 #pragma unroll
   for (int k = 0; k <= CI; ++k) {
-    const double* Bk = (k < CI) ? Mi + (CI * (CI - 1) / 2 + k) * CBS : F + cb_off(CI, CI);
+    const S* Bk = (k < CI) ? Mi + (CI * (CI - 1) / 2 + k) * L::BS : F + L::off(CI, CI);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      a[4 * k + ks] = Aprow[k * CBS + rc * CLD + 4 * ks + kq];
-      b[4 * k + ks] = (k < CI) ? Bk[rc * CLD + 4 * ks + kq] : Bk[(4 * ks + kq) * CLD + rc];   // Minv(CI,k) read transposed, T_CI as it is
+      a[4 * k + ks] = Aprow[k * L::BS + rc * L::LD + 4 * ks + kq];
+      b[4 * k + ks] = (k < CI) ? Bk[rc * L::LD + 4 * ks + kq] : Bk[(4 * ks + kq) * L::LD + rc];   // Minv(CI,k) read transposed, T_CI as it is
     }
   }
-  Mfma<double>::acc_t acc = {0, 0, 0, 0};
+  typename Mfma<S>::acc_t acc = {0, 0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < (CI + 1) * 4; ++i) acc = Mfma<double>::mma(a[i], b[i], acc);
+  for (int i = 0; i < (CI + 1) * 4; ++i) acc = Mfma<S>::mma(a[i], b[i], acc);
   return acc;
 }
 // a whole panel, in place: the calling wave forms all four blocks of sub-block row ri in registers; the caller puts a barrier between
 // this and choldag_panel_store (other waves may still be reading the row)
-struct CholdagRow { Mfma<double>::acc_t o[BSUB]; };
-__device__ __forceinline__ CholdagRow choldag_panel_row(const double* __restrict__ Ap, const double* __restrict__ F, int ri) {
-  CholdagRow r;
-  const double* row = Ap + ri * BSUB * CBS;
-  r.o[3] = choldag_panel_out<3>(row, F);
-  r.o[2] = choldag_panel_out<2>(row, F);
-  r.o[1] = choldag_panel_out<1>(row, F);
-  r.o[0] = choldag_panel_out<0>(row, F);
+template <typename S> struct CholdagRow { typename Mfma<S>::acc_t o[BSUB]; };
+template <typename S>
+__device__ __forceinline__ CholdagRow<S> choldag_panel_row(const S* __restrict__ Ap, const S* __restrict__ F, int ri) {
+  CholdagRow<S> r;
+  const S* row = Ap + ri * BSUB * CholLay<S>::BS;
+  r.o[3] = choldag_panel_out<3, S>(row, F);
+  r.o[2] = choldag_panel_out<2, S>(row, F);
+  r.o[1] = choldag_panel_out<1, S>(row, F);
+  r.o[0] = choldag_panel_out<0, S>(row, F);
   return r;
 }
-__device__ __forceinline__ void choldag_panel_store(double* __restrict__ Ap, int ri, const CholdagRow& r) {
+template <typename S>
+__device__ __forceinline__ void choldag_panel_store(S* __restrict__ Ap, int ri, const CholdagRow<S>& r) {
 #pragma unroll
-  for (int ci = 0; ci < BSUB; ++ci) store16(Ap + (ri * BSUB + ci) * CBS, r.o[ci]);
+  for (int ci = 0; ci < BSUB; ++ci) store16<S>(Ap + (ri * BSUB + ci) * CholLay<S>::BS, r.o[ci]);
 }
 // the same with the four blocks of a row shared by two waves (half 0: blocks 3 and 0, half 1: blocks 2 and 1 -- five products each)
-struct CholdagHalfRow { Mfma<double>::acc_t o[2]; };
-__device__ __forceinline__ CholdagHalfRow choldag_panel_half(const double* __restrict__ Ap, const double* __restrict__ F, int ri, int half) {
-  CholdagHalfRow r;
-  const double* row = Ap + ri * BSUB * CBS;
-  if (half == 0) { r.o[0] = choldag_panel_out<3>(row, F); r.o[1] = choldag_panel_out<0>(row, F); }
-  else { r.o[0] = choldag_panel_out<2>(row, F); r.o[1] = choldag_panel_out<1>(row, F); }
+template <typename S> struct CholdagHalfRow { typename Mfma<S>::acc_t o[2]; };
+template <typename S>
+__device__ __forceinline__ CholdagHalfRow<S> choldag_panel_half(const S* __restrict__ Ap, const S* __restrict__ F, int ri, int half) {
+  CholdagHalfRow<S> r;
+  const S* row = Ap + ri * BSUB * CholLay<S>::BS;
+  if (half == 0) { r.o[0] = choldag_panel_out<3, S>(row, F); r.o[1] = choldag_panel_out<0, S>(row, F); }
+  else { r.o[0] = choldag_panel_out<2, S>(row, F); r.o[1] = choldag_panel_out<1, S>(row, F); }
   return r;
 }
-__device__ __forceinline__ void choldag_panel_half_store(double* __restrict__ Ap, int ri, int half, const CholdagHalfRow& r) {
-  store16(Ap + (ri * BSUB + (half == 0 ? 3 : 2)) * CBS, r.o[0]);
-  store16(Ap + (ri * BSUB + (half == 0 ? 0 : 1)) * CBS, r.o[1]);
+template <typename S>
+__device__ __forceinline__ void choldag_panel_half_store(S* __restrict__ Ap, int ri, int half, const CholdagHalfRow<S>& r) {
+  store16<S>(Ap + (ri * BSUB + (half == 0 ? 3 : 2)) * CholLay<S>::BS, r.o[0]);
+  store16<S>(Ap + (ri * BSUB + (half == 0 ? 0 : 1)) * CholLay<S>::BS, r.o[1]);
 }
 // sum_k A(ri,k) B(ci,k)^T over the four sub-blocks of a row, operands fetched ahead of the 16 MFMAs
-__device__ __forceinline__ Mfma<double>::acc_t choldag_abt(const double* __restrict__ Arow, const double* __restrict__ Brow) {
+template <typename S>
+__device__ __forceinline__ typename Mfma<S>::acc_t choldag_abt(const S* __restrict__ Arow, const S* __restrict__ Brow) {
+  using L = CholLay<S>;
   const int lane = threadIdx.x & 63, rc = lane & 15, kq = lane >> 4;
-  double a[16], b[16];
+  S a[16], b[16];
 #pragma unroll
   for (int k = 0; k < BSUB; ++k)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      a[4 * k + ks] = Arow[k * CBS + rc * CLD + 4 * ks + kq];
-      b[4 * k + ks] = Brow[k * CBS + rc * CLD + 4 * ks + kq];
+      a[4 * k + ks] = Arow[k * L::BS + rc * L::LD + 4 * ks + kq];
+      b[4 * k + ks] = Brow[k * L::BS + rc * L::LD + 4 * ks + kq];
     }
-  Mfma<double>::acc_t p = {0, 0, 0, 0};
+  typename Mfma<S>::acc_t p = {0, 0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < 16; ++i) p = Mfma<double>::mma(a[i], b[i], p);
+  for (int i = 0; i < 16; ++i) p = Mfma<S>::mma(a[i], b[i], p);
   return p;
 }
-__device__ __forceinline__ void choldag_copy_img(double* __restrict__ dst, const double* __restrict__ src) {
-  for (int e = threadIdx.x; e < CHOLDAG_IMG / 2; e += CHOLBIG_THREADS)
-    reinterpret_cast<double2*>(dst)[e] = reinterpret_cast<const double2*>(src)[e];
+template <typename S>
+__device__ __forceinline__ void choldag_copy_img(S* __restrict__ dst, const S* __restrict__ src) {
+  using V2 = typename Vec2<S>::type;
+  for (int e = threadIdx.x; e < choldag_img<S>() / 2; e += CHOLBIG_THREADS)
+    reinterpret_cast<V2*>(dst)[e] = reinterpret_cast<const V2*>(src)[e];
 }
 // 64 x 64 block in LDS (4 x 4 sub-blocks) -> W block (br, bc)
-__device__ __forceinline__ void choldag_store_block(double* __restrict__ W, int npad, int br, int bc, const double* __restrict__ A) {
+template <typename S>
+__device__ __forceinline__ void choldag_store_block(S* __restrict__ W, int npad, int br, int bc, const S* __restrict__ A) {
+  using L = CholLay<S>;
   for (int e = threadIdx.x; e < BB * BB; e += CHOLBIG_THREADS) {
     const int i = e >> 6, k = e & 63;
-    W[(size_t)(br * BB + i) * npad + bc * BB + k] = A[((i >> 4) * BSUB + (k >> 4)) * CBS + (i & 15) * CLD + (k & 15)];
+    W[(size_t)(br * BB + i) * npad + bc * BB + k] = A[((i >> 4) * BSUB + (k >> 4)) * L::BS + (i & 15) * L::LD + (k & 15)];
   }
 }
 
-// grid = 1 + nbr (nbr + 1) / 2; 512 threads; dynamic LDS = 48 sub-blocks (the same as k_chol_big_step)
-__global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(double* __restrict__ W, int npad, double* __restrict__ Mimg_ws,
-                                                                  unsigned* __restrict__ flags, unsigned epoch,
-                                                                  int* __restrict__ info, const LMState* __restrict__ st,
+// grid = 1 + nbr (nbr + 1) / 2; 512 threads; dynamic LDS = CHOLBIG_LDS_BLOCKS sub-blocks of S
+template <typename S>
+__global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(const double* __restrict__ E, int n, LMState* __restrict__ st,
+                                                                  double* __restrict__ D2c, S* __restrict__ W, int npad,
+                                                                  S* __restrict__ Mimg_ws, unsigned* __restrict__ flags, unsigned epoch,
+                                                                  int* __restrict__ info, int only_if_retry, S tau,
                                                                   long long* __restrict__ dbg) {
+  using L = CholLay<S>;
+  using acc_t = typename Mfma<S>::acc_t;
+  constexpr bool F32 = sizeof(S) == 4;
+  constexpr int IMG = choldag_img<S>();
   extern __shared__ __align__(16) unsigned char smem[];
-  if (st->status >= 0) return;                           // (the same record on every workgroup: nobody is left waiting)
-  double* F = reinterpret_cast<double*>(smem);           // image of a diagonal block: Dg (10 sub-blocks) + Mi (6)
-  double* Ar = F + 16 * CBS;                             // W(r,j) -> L(r,j)
-  double* Ac = Ar + 16 * CBS;                            // W(c,j) -> L(c,j);  the walker: the next diagonal tile
+  if (st->status >= 0 || (only_if_retry && !st->chol_retry)) return;     // (the same record on every workgroup: nobody is left waiting)
+  S* F = reinterpret_cast<S*>(smem);                     // image of a diagonal block: Dg (10 sub-blocks) + Mi (6)
+  S* Ar = F + 16 * L::BS;                                // W(r,j) -> L(r,j)
+  S* Ac = Ar + 16 * L::BS;                               // W(c,j) -> L(c,j);  the walker: the next diagonal tile
   __shared__ int s_fail, s_late, s_pref[4];
+  __shared__ S s_a0[2][BB];                               // the damped diagonal of the walker's block (pivot test on f32 lanes), this block / the next
   const int nbr = npad / BB;
   unsigned* flagM = flags;
   unsigned* flagW = flags + nbr;
   unsigned* abortf = flags + nbr + nbr * nbr;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  CholDagSys sys;
+  sys.E = E; sys.n = n; sys.R = cholbig_rhs_row(n); sys.lam = st->lam; sys.fresh = st->fresh != 0; sys.D2c = D2c;
+  sys.rhs = E + (size_t)n * n; sys.dU = sys.rhs + n; sys.big = F32 ? (double)CHOLBIG_RHS_DIAG_F32 : CHOLBIG_RHS_DIAG;
   if (threadIdx.x == 0) { s_fail = 0; s_late = 0; }
   if (blockIdx.x == 0) {
     // ================================================================ the walker
     // SBA_CHOL_DEBUG: stamps of the 100 MHz clock at the links of the chain
     auto stamp = [&](int c, int k) { if (dbg && threadIdx.x == 0) dbg[c * 8 + k] = wall_clock64(); };
     stamp(0, 0);
-    double* Mi = F + 10 * CBS;
-    load_block64<true>(W, npad, 0, 0, F);
+    if (threadIdx.x == 0) { st->cost = E[(size_t)n * n + 3 * n]; *info = 0; }
+    S* Mi = F + 10 * L::BS;
+    choldag_block_from_sys<true, S, CHOLBIG_THREADS>(sys, 0, 0, F, threadIdx.x);
+    if (nbr > 1) {                                        // (nobody writes column 0 or tile (1,1): the walker's first two tiles come from E as well)
+      choldag_block_from_sys<false, S, CHOLBIG_THREADS>(sys, 1, 0, Ar, threadIdx.x);
+      choldag_block_from_sys<false, S, CHOLBIG_THREADS>(sys, 1, 1, Ac, threadIdx.x);
+    }
+    if (threadIdx.x < BB) s_a0[0][threadIdx.x] = (S)sys.diag(threadIdx.x);
     __syncthreads();
     for (int c = 0; c < nbr; ++c) {
       stamp(c, 4);
@@ -433,51 +594,73 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(double* __rest
       const unsigned* fa = flagW + (c + 1) * nbr + c;
       const unsigned* fb = flagW + (c + 1) * nbr + c + 1;
       if (threadIdx.x < 4) s_pref[threadIdx.x] = 0;
-      chol_big_factor64(F, Mi, &s_fail, [&]() {
+      using V2 = typename Vec2<S>::type;
+      V2 va[8], vb[8];
+      bool got = false;
+      const int ftid = threadIdx.x - 256;
+      auto issue = [&]() {
         if (!more) return;
+        if (F32 && ftid < BB) s_a0[(c + 1) & 1][ftid] = (S)sys.diag((c + 1) * BB + ftid);
+        if (c == 0) return;                               // (fetched in front of the loop)
+        if (!F32) return;                                 // (f64: the last 16 pivots take long enough for the whole fetch, see commit)
         bool ready = true;
-        if (c >= 1 && lane < 2) ready = __hip_atomic_load(lane == 0 ? fa : fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+        if (lane < 2) ready = __hip_atomic_load(lane == 0 ? fa : fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
         if (!__all(ready)) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const int tid = threadIdx.x - 256;
-        double2 va[8], vb[8];
+        got = true;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int e = tid + u * 256, row = e >> 5, col = (e & 31) * 2;
-          va[u] = *reinterpret_cast<const double2*>(W + (size_t)((c + 1) * BB + row) * npad + c * BB + col);
-          vb[u] = *reinterpret_cast<const double2*>(W + (size_t)((c + 1) * BB + row) * npad + (c + 1) * BB + col);
+          const int e = ftid + u * 256, row = e >> 5, col = (e & 31) * 2;
+          va[u] = *reinterpret_cast<const V2*>(W + (size_t)((c + 1) * BB + row) * npad + c * BB + col);
+          vb[u] = *reinterpret_cast<const V2*>(W + (size_t)((c + 1) * BB + row) * npad + (c + 1) * BB + col);
         }
+      };
+      auto commit = [&]() {
+        if (!more) return;
+        if (c > 0) {
+          if (!got) {                                     // not there yet when `issue` looked: one more look, now or after the factorisation
+            bool ready = true;
+            if (lane < 2) ready = __hip_atomic_load(lane == 0 ? fa : fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+            if (!__all(ready)) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int e = tid + u * 256, row = e >> 5, col = (e & 31) * 2;
-          const int o = ((row >> 4) * BSUB + (col >> 4)) * CBS + (row & 15) * CLD + (col & 15);
-          Ar[o] = va[u].x; Ar[o + 1] = va[u].y;
-          Ac[o] = vb[u].x; Ac[o + 1] = vb[u].y;
+            for (int u = 0; u < 8; ++u) {
+              const int e = ftid + u * 256, row = e >> 5, col = (e & 31) * 2;
+              va[u] = *reinterpret_cast<const V2*>(W + (size_t)((c + 1) * BB + row) * npad + c * BB + col);
+              vb[u] = *reinterpret_cast<const V2*>(W + (size_t)((c + 1) * BB + row) * npad + (c + 1) * BB + col);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = ftid + u * 256, row = e >> 5, col = (e & 31) * 2;
+            const int o = ((row >> 4) * BSUB + (col >> 4)) * L::BS + (row & 15) * L::LD + (col & 15);
+            Ar[o] = va[u].x; Ar[o + 1] = va[u].y;
+            Ac[o] = vb[u].x; Ac[o + 1] = vb[u].y;
+          }
         }
         if (lane == 0) s_pref[wid - 4] = 1;
-      });
+      };
+      chol_big_factor64<S>(F, Mi, Ac + 16 * L::BS, &s_fail, F32 ? s_a0[c & 1] : (const S*)nullptr, tau, issue, commit);
       stamp(c, 5);
-      choldag_copy_img(Mimg_ws + (size_t)c * CHOLDAG_IMG, F);
+      choldag_copy_img<S>(Mimg_ws + (size_t)c * IMG, F);
       stamp(c, 6);
       choldag_publish(flagM + c, epoch);
       stamp(c, 7);
       if (!more) break;
       const bool fetched = s_pref[0] && s_pref[1] && s_pref[2] && s_pref[3];     // (read after the barrier inside choldag_publish)
       if (!fetched) {
-        if (c >= 1) {                                     // (column 0 and tile (1,1) are final as k_chol_big_prepare wrote them)
-          choldag_wait(fa, fb, epoch, abortf, &s_late);
-          if (s_late) break;
-        }
+        choldag_wait(fa, fb, epoch, abortf, &s_late);     // (c >= 1 here: at c = 0 the fetch cannot fail)
+        if (s_late) break;
         stamp(c + 1, 1);
-        load_block64<false>(W, npad, (c + 1) * BB, c * BB, Ar);
-        load_block64<false>(W, npad, (c + 1) * BB, (c + 1) * BB, Ac);
+        load_block64<false, S>(W, npad, (c + 1) * BB, c * BB, Ar);
+        load_block64<false, S>(W, npad, (c + 1) * BB, (c + 1) * BB, Ac);
         __syncthreads();
       } else stamp(c + 1, 1);
       stamp(c + 1, 2);
       {
-        const CholdagHalfRow pr = choldag_panel_half(Ar, F, wid & 3, wid >> 2);
+        const CholdagHalfRow<S> pr = choldag_panel_half<S>(Ar, F, wid & 3, wid >> 2);
         __syncthreads();
-        choldag_panel_half_store(Ar, wid & 3, wid >> 2, pr);
+        choldag_panel_half_store<S>(Ar, wid & 3, wid >> 2, pr);
       }
       __syncthreads();
       stamp(c + 1, 3);
@@ -486,26 +669,22 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(double* __rest
         int ri = 0;
         while ((ri + 1) * (ri + 2) / 2 <= wid) ++ri;
         const int ci = wid - ri * (ri + 1) / 2;
-        const Mfma<double>::acc_t p0 = choldag_abt(Ar + ri * BSUB * CBS, Ar + ci * BSUB * CBS);
-        const int t1 = wid + 8, ri1 = 3, ci1 = t1 - 6;     // sub-tiles 8, 9 = (3,2), (3,3): waves 0 and 1
-        Mfma<double>::acc_t p1 = {0, 0, 0, 0};
-        if (wid < 2) p1 = choldag_abt(Ar + ri1 * BSUB * CBS, Ar + ci1 * BSUB * CBS);
-        Mfma<double>::acc_t a;
-        const double* Nt = Ac + (ri * BSUB + ci) * CBS;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) a[rg] = Nt[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] - p0[rg];
-        store16(F + cb_off(ri, ci), a);
-        if (wid < 2) {
-          const double* Nt1 = Ac + (ri1 * BSUB + ci1) * CBS;
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) a[rg] = Nt1[((lane >> 4) + 4 * rg) * CLD + (lane & 15)] - p1[rg];
-          store16(F + cb_off(ri1, ci1), a);
-        }
+        const acc_t p0 = choldag_abt<S>(Ar + ri * BSUB * L::BS, Ar + ci * BSUB * L::BS);
+        const int ri1 = 3, ci1 = wid + 2;                  // sub-tiles 8, 9 = (3,2), (3,3): waves 0 and 1
+        acc_t p1 = {0, 0, 0, 0};
+        if (wid < 2) p1 = choldag_abt<S>(Ar + ri1 * BSUB * L::BS, Ar + ci1 * BSUB * L::BS);
+        store16<S>(F + L::off(ri, ci), load16<S>(Ac + (ri * BSUB + ci) * L::BS) - p0);
+        if (wid < 2) store16<S>(F + L::off(ri1, ci1), load16<S>(Ac + (ri1 * BSUB + ci1) * L::BS) - p1);
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0 && s_fail) atomicOr(info, 1);
-    if (s_late && threadIdx.x == 0) atomicOr(info, 2);
+    if (threadIdx.x == 0) {
+      if (F32) { st->chol_retry = s_fail ? 1 : 0; if (s_fail) st->chol_f64_retries += 1; }
+      else if (s_fail) atomicOr(info, 1);
+      if (s_late) atomicOr(info, 2);
+    }
+    // the camera scaling the damping used, for k_chol_epilogue and the next trial (monotone max: writing it twice is harmless)
+    if (sys.fresh) for (int i = threadIdx.x; i < n; i += CHOLBIG_THREADS) D2c[i] = fmax(D2c[i], sys.dU[i]);
     return;
   }
   // ================================================================ a tile
@@ -515,76 +694,79 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(double* __rest
   const int ncol = (r == c) ? c - 1 : c;                  // columns this workgroup applies (the walker applies the last one on the diagonal)
   if (r == c && c < 2) return;
   // the own tile: 16 sub-tiles, two per wave, in the accumulators from here to the end
-  Mfma<double>::acc_t acc[2];
+  acc_t acc[2];
+  choldag_block_from_sys<false, S, CHOLBIG_THREADS>(sys, r, c, Ar, threadIdx.x);
+  __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int tt = wid + 8 * h, ri = tt >> 2, ci = tt & 3;
-    const double* Cg = W + (size_t)(r * BB + ri * CB) * npad + c * BB + ci * CB;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) acc[h][rg] = Cg[(size_t)((lane >> 4) + 4 * rg) * npad + (lane & 15)];
+    acc[h] = load16<S>(Ar + (ri * BSUB + ci) * L::BS);
   }
   __syncthreads();
   for (int j = 0; j < ncol; ++j) {
-    if (j > 0) {                                          // (column 0 is final as k_chol_big_prepare wrote it)
+    if (j > 0) {
       choldag_wait(flagW + r * nbr + j, flagW + c * nbr + j, epoch, abortf, &s_late);
       if (s_late) break;
+      load_block64<false, S>(W, npad, r * BB, j * BB, Ar);
+      if (c != r) load_block64<false, S>(W, npad, c * BB, j * BB, Ac);
+    } else {                                              // (column 0 comes from E)
+      choldag_block_from_sys<false, S, CHOLBIG_THREADS>(sys, r, 0, Ar, threadIdx.x);
+      if (c != r) choldag_block_from_sys<false, S, CHOLBIG_THREADS>(sys, c, 0, Ac, threadIdx.x);
     }
-    load_block64<false>(W, npad, r * BB, j * BB, Ar);
-    if (c != r) load_block64<false>(W, npad, c * BB, j * BB, Ac);
     choldag_wait(flagM + j, flagM + j, epoch, abortf, &s_late);
     if (s_late) break;
-    choldag_copy_img(F, Mimg_ws + (size_t)j * CHOLDAG_IMG);
+    choldag_copy_img<S>(F, Mimg_ws + (size_t)j * IMG);
     __syncthreads();
     if (c != r) {
-      double* Ap = (wid < BSUB) ? Ar : Ac;
-      const CholdagRow pr = choldag_panel_row(Ap, F, wid & 3);
+      S* Ap = (wid < BSUB) ? Ar : Ac;
+      const CholdagRow<S> pr = choldag_panel_row<S>(Ap, F, wid & 3);
       __syncthreads();
-      choldag_panel_store(Ap, wid & 3, pr);
+      choldag_panel_store<S>(Ap, wid & 3, pr);
     } else {
-      const CholdagHalfRow pr = choldag_panel_half(Ar, F, wid & 3, wid >> 2);
+      const CholdagHalfRow<S> pr = choldag_panel_half<S>(Ar, F, wid & 3, wid >> 2);
       __syncthreads();
-      choldag_panel_half_store(Ar, wid & 3, wid >> 2, pr);
+      choldag_panel_half_store<S>(Ar, wid & 3, wid >> 2, pr);
     }
     __syncthreads();
-    const double* Lr = Ar;
-    const double* Lc = (c != r) ? Ac : Ar;
+    const S* Lr = Ar;
+    const S* Lc = (c != r) ? Ac : Ar;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int tt = wid + 8 * h, ri = tt >> 2, ci = tt & 3;
-      const Mfma<double>::acc_t p = choldag_abt(Lr + ri * BSUB * CBS, Lc + ci * BSUB * CBS);
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) acc[h][rg] -= p[rg];
+      acc[h] -= choldag_abt<S>(Lr + ri * BSUB * L::BS, Lc + ci * BSUB * L::BS);
     }
     __syncthreads();
   }
   if (s_late) { if (threadIdx.x == 0) atomicOr(info, 2); return; }
+  // the tile is final (below the diagonal) or ready for the walker (on it): straight from the accumulators to W, then the flag
+  if (c > 0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int tt = wid + 8 * h, ri = tt >> 2, ci = tt & 3;
+      S* Cg = W + (size_t)(r * BB + ri * CB) * npad + c * BB + ci * CB;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) Cg[(size_t)Mfma<S>::row_of(lane, rg) * npad + (lane & 15)] = acc[h][rg];
+    }
+    choldag_publish(flagW + r * nbr + c, epoch);
+  }
+  if (r == c) return;
+  // ---- below the diagonal: L(r,c) for the back substitution, once Mimg_c is there
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int tt = wid + 8 * h, ri = tt >> 2, ci = tt & 3;
-    store16(Ar + (ri * BSUB + ci) * CBS, acc[h]);
-  }
-  __syncthreads();
-  if (r == c) {                                           // the partial diagonal tile goes to the walker
-    choldag_store_block(W, npad, r, c, Ar);
-    choldag_publish(flagW + r * nbr + c, epoch);
-    return;
-  }
-  // ---- below the diagonal: the final W(r,c) for the tiles to the right, then L(r,c) for the back substitution
-  if (c > 0) {
-    choldag_store_block(W, npad, r, c, Ar);
-    choldag_publish(flagW + r * nbr + c, epoch);
+    store16<S>(Ar + (ri * BSUB + ci) * L::BS, acc[h]);
   }
   choldag_wait(flagM + c, flagM + c, epoch, abortf, &s_late);
   if (s_late) { if (threadIdx.x == 0) atomicOr(info, 2); return; }
-  choldag_copy_img(F, Mimg_ws + (size_t)c * CHOLDAG_IMG);
+  choldag_copy_img<S>(F, Mimg_ws + (size_t)c * IMG);
   __syncthreads();
   {
-    const CholdagHalfRow pr = choldag_panel_half(Ar, F, wid & 3, wid >> 2);
+    const CholdagHalfRow<S> pr = choldag_panel_half<S>(Ar, F, wid & 3, wid >> 2);
     __syncthreads();
-    choldag_panel_half_store(Ar, wid & 3, wid >> 2, pr);
+    choldag_panel_half_store<S>(Ar, wid & 3, wid >> 2, pr);
   }
   __syncthreads();
-  choldag_store_block(W, npad, c, r, Ar);
+  choldag_store_block<S>(W, npad, c, r, Ar);
 }
 
 // ------------------------------------------------------------------ back substitution
@@ -642,14 +824,14 @@ __global__ __launch_bounds__(256) void k_chol_big_back(const double* __restrict_
 // boundary: the L(b,t) block a workgroup needs next is already in its registers when x_b arrives.  The waits are bounded
 // (CHOLBIG_WAIT_TICKS of the 100 MHz clock, then the solve is flagged as failed: a rejected LM step) and every workgroup of
 // the launch is resident at once -- the rule of sba_ipc.hpp.  Flags carry the launch's epoch, so they are never reset.
-__global__ __launch_bounds__(256) void k_chol_big_back_all(const double* __restrict__ W, int npad, int n, const double* __restrict__ Ld_ws,
-                                                           const double* __restrict__ Minv_ws, double* __restrict__ xv /* [npad] */,
-                                                           unsigned* __restrict__ flags /* [block rows] */, unsigned epoch,
-                                                           double* __restrict__ sol, int* __restrict__ info, const LMState* __restrict__ st,
-                                                           const double* __restrict__ Mimg_ws /* k_chol_big_dag's images, or null: the dense copies */) {
-  __shared__ double s_y[BB], s_x[BB], s_p[4][BB], s_M[BB * BB];
-  __shared__ int s_late;
-  if (st->status >= 0) return;                      // (the same record on every workgroup: nobody is left waiting)
+template <typename S>
+__device__ __forceinline__ void chol_big_back_all_body(const S* __restrict__ W, int npad, int n, const double* __restrict__ Ld_ws,
+                                                       const double* __restrict__ Minv_ws, double* __restrict__ xv, unsigned* __restrict__ flags,
+                                                       unsigned epoch, double* __restrict__ sol, int* __restrict__ info,
+                                                       const S* __restrict__ Mimg_ws, double* __restrict__ s_y, double* __restrict__ s_x,
+                                                       double (*__restrict__ s_p)[BB], double* __restrict__ s_M, int& s_late,
+                                                       double* __restrict__ s_sol /* block row 0 keeps the whole solution (for the epilogue) */) {
+  constexpr int IMG = choldag_img<S>();
   const int nbx = (n + BB - 1) / BB;
   const int t = blockIdx.x, i = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int R = cholbig_rhs_row(n), Rb = R / BB, Rl = R % BB;
@@ -657,23 +839,29 @@ __global__ __launch_bounds__(256) void k_chol_big_back_all(const double* __restr
   double yk = 0;
   if (threadIdx.x < BB) {
     const int k = t * BB + threadIdx.x;
-    if (k < n) yk = (t < Rb) ? W[(size_t)(t * BB + Rl) * npad + Rb * BB + threadIdx.x]
-                             : (Mimg_ws ? choldag_img_l(Mimg_ws + (size_t)Rb * CHOLDAG_IMG, Rl, threadIdx.x) : Ld_ws[(size_t)Rb * BB * BB + Rl * BB + threadIdx.x]);
+    if (k < n) yk = (t < Rb) ? (double)W[(size_t)(t * BB + Rl) * npad + Rb * BB + threadIdx.x]
+                             : (Mimg_ws ? choldag_img_l<S>(Mimg_ws + (size_t)Rb * IMG, Rl, threadIdx.x) : Ld_ws[(size_t)Rb * BB * BB + Rl * BB + threadIdx.x]);
   }
   const double* Mg = Minv_ws + (size_t)t * BB * BB;
   double mreg[BB * BB / 256];
 #pragma unroll
   for (int u = 0; u < BB * BB / 256; ++u) {
     const int e = threadIdx.x + 256 * u;
-    mreg[u] = Mimg_ws ? choldag_img_minv(Mimg_ws + (size_t)t * CHOLDAG_IMG, e >> 6, e & 63) : Mg[e];
+    mreg[u] = Mimg_ws ? choldag_img_minv<S>(Mimg_ws + (size_t)t * IMG, e >> 6, e & 63) : Mg[e];
   }
   double lreg[BB / 4];                               // L(b,t)[k][i], k = part + 4 u
   auto fetch_L = [&](int b) {
-    const double* Lb = W + (size_t)(t * BB) * npad + b * BB;
+    const S* Lb = W + (size_t)(t * BB) * npad + b * BB;
 #pragma unroll
-    for (int u = 0; u < BB / 4; ++u) lreg[u] = Lb[(size_t)(part + 4 * u) * npad + i];
+    for (int u = 0; u < BB / 4; ++u) lreg[u] = (double)Lb[(size_t)(part + 4 * u) * npad + i];
   };
   if (nbx - 1 > t) fetch_L(nbx - 1);
+  // x travels as its own flag: xv has one copy per parity of the epoch, filled with a NaN nobody computes (CHOLBIG_X_EMPTY) until the
+  // owner of a block row stores its x there; a waiting thread polls the very word it needs -- one trip through memory per hand-over
+  // instead of two (flag, then data).  Every workgroup empties its slice of the OTHER copy for the next launch.
+  double* xcur = xv + (size_t)(epoch & 1) * npad;
+  double* xnext = xv + (size_t)((epoch + 1) & 1) * npad;
+  if (threadIdx.x < BB) xnext[t * BB + threadIdx.x] = __longlong_as_double(CHOLBIG_X_EMPTY);
   if (threadIdx.x == 0) s_late = 0;
   if (threadIdx.x < BB) s_y[threadIdx.x] = yk;
 #pragma unroll
@@ -683,12 +871,17 @@ __global__ __launch_bounds__(256) void k_chol_big_back_all(const double* __restr
     if (threadIdx.x < BB) {                          // wave 0 waits for x_b and brings it in
       const long long t0 = wall_clock64();
       bool late = false;
-      while (__hip_atomic_load(flags + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-        if (wall_clock64() - t0 > CHOLBIG_WAIT_TICKS) { late = true; break; }
+      long long bits;
+      int it = 0;
+      while (true) {
+        bits = __hip_atomic_load(reinterpret_cast<const long long*>(xcur + b * BB + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(bits != CHOLBIG_X_EMPTY)) break;
+        if ((++it & 31) == 0 && __any(wall_clock64() - t0 > CHOLBIG_WAIT_TICKS)) { late = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
       if (late) s_late = 1;
-      s_x[threadIdx.x] = late ? 0.0 : __builtin_nontemporal_load(xv + b * BB + threadIdx.x);
+      s_x[threadIdx.x] = late ? 0.0 : __longlong_as_double(bits);
+      if (t == 0) s_sol[b * BB + threadIdx.x] = s_x[threadIdx.x];
     }
     __syncthreads();
     if (s_late) break;
@@ -701,22 +894,47 @@ __global__ __launch_bounds__(256) void k_chol_big_back_all(const double* __restr
     if (part == 0) s_y[i] -= (s_p[0][i] + s_p[1][i]) + (s_p[2][i] + s_p[3][i]);
     __syncthreads();
   }
-  if (s_late) { if (threadIdx.x == 0) atomicOr(info, 2); return; }     // (this workgroup's flag stays down: the rows above time out too)
+  if (s_late) { if (threadIdx.x == 0) atomicOr(info, 2); return; }     // (this workgroup's x stays empty: the rows above time out too)
   // x_t = Minv_t^T y_t   (Minv is lower: entries k < i are stored zeros)
   double s = 0;
   for (int k = part; k < BB; k += 4) s += s_M[k * BB + i] * s_y[k];
   s_p[part][i] = s;
   __syncthreads();
   if (part == 0) {
-    const double x = (s_p[0][i] + s_p[1][i]) + (s_p[2][i] + s_p[3][i]);
-    __builtin_nontemporal_store(x, xv + t * BB + i);
+    double x = (s_p[0][i] + s_p[1][i]) + (s_p[2][i] + s_p[3][i]);
+    if (__double_as_longlong(x) == CHOLBIG_X_EMPTY) x = __longlong_as_double(0x7ff8000000000000LL);
+    __hip_atomic_store(reinterpret_cast<long long*>(xcur + t * BB + i), __double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t * BB + i < n) sol[t * BB + i] = x;
+    if (t == 0) s_sol[i] = x;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    __hip_atomic_store(flags + t, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
+}
+// W / Mimg_ws: doubles (the per-column launches, k_chol_big_dag<double>) or floats (f32_data: k_chol_big_dag<float>, unless its
+// factorisation was refused and the f64 instance behind it did the work: LMState::chol_retry).
+// Block row 0 is the last to finish and has seen every x_b on its way: it keeps them in LDS and runs the LM epilogue on them
+// (chol_epilogue_body: the trial cameras, the predicted reduction, the failure flag) -- one launch less per trial.
+constexpr int CHOLBIG_MAX_NBX = 27;         // 1728 unknowns: 128 cameras x 13 parameters + the padding
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_big_back_all(const void* __restrict__ W, int npad, int n, const double* __restrict__ Ld_ws,
+                                                           const double* __restrict__ Minv_ws,
+                                                           double* __restrict__ xv /* [2][npad], CHOLBIG_X_EMPTY before the first launch */,
+                                                           unsigned epoch, double* __restrict__ sol, int* __restrict__ info,
+                                                           LMState* __restrict__ st,
+                                                           const void* __restrict__ Mimg_ws /* k_chol_big_dag's images, or null: the dense copies */,
+                                                           int f32_data, const double* __restrict__ E, int C, const double* __restrict__ D2c,
+                                                           const ParamSets<T> ps, double* __restrict__ delta_c,
+                                                           const int32_t* __restrict__ tie, const int32_t* __restrict__ first) {
+  __shared__ double s_y[BB], s_x[BB], s_p[4][BB], s_M[BB * BB], s_sol[CHOLBIG_MAX_NBX * BB], s_scr[16];
+  __shared__ int s_late, s_flag;
+  if (st->status >= 0) return;                      // (the same record on every workgroup: nobody is left waiting)
+  if (f32_data && !st->chol_retry)
+    chol_big_back_all_body<float>(static_cast<const float*>(W), npad, n, Ld_ws, Minv_ws, xv, nullptr, epoch, sol, info,
+                                  static_cast<const float*>(Mimg_ws), s_y, s_x, s_p, s_M, s_late, s_sol);
+  else
+    chol_big_back_all_body<double>(static_cast<const double*>(W), npad, n, Ld_ws, Minv_ws, xv, nullptr, epoch, sol, info,
+                                   static_cast<const double*>(Mimg_ws), s_y, s_x, s_p, s_M, s_late, s_sol);
+  if (blockIdx.x != 0) return;
+  __syncthreads();                                  // (a timed-out substitution has raised info: the epilogue then rejects the step)
+  chol_epilogue_body<T>(E, C, n, st, D2c, ps, delta_c, s_sol, info, tie, first, s_scr, &s_flag);
 }
 
 }  // namespace SBA_NS

@@ -291,8 +291,8 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_ll<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLL_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_dag), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * CBS * (int)sizeof(double)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, CHOLBIG_LDS_BLOCKS * CBS * (int)sizeof(double)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_dag<double>), hipFuncAttributeMaxDynamicSharedMemorySize, CHOLBIG_LDS_BLOCKS * CBS * (int)sizeof(double)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residual<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -1448,29 +1448,40 @@ struct Engine : EngineBase {
   }
 
   // A = S + lam D (n_sys x n_sys, in E) -> chol_sol = A^-1 rhs, chol_info != 0 when A is not positive definite
-  void launch_chol_big(double* Esys, int n_sys) {
+  // factorisation, both substitutions and the LM epilogue (k_chol_epilogue's work) of a large reduced system
+  void launch_chol_big(double* Esys, int n_sys, bool tied) {
     const int npad = cholbig_npad(n_sys), nbr = npad / BB, nbx = (n_sys + BB - 1) / BB;
     if (chol_W.n < (size_t)npad * npad) {
       chol_W.alloc((size_t)npad * npad); chol_Minv.alloc((size_t)nbr * BB * BB); chol_Ld.alloc((size_t)nbr * BB * BB);
-      chol_yv.alloc(npad);
+      chol_yv.alloc(2 * (size_t)npad);      // k_chol_big_back_all: x, one copy per parity of its epoch, "empty" until stored
+      std::vector<long long> empty(2 * (size_t)npad, CHOLBIG_X_EMPTY);
+      HIPCHK(hipMemcpyAsync(chol_yv.p, empty.data(), empty.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
+      sync();
     }
     if (chol_sol.n < (size_t)n_sys) { chol_sol.alloc(n_sys); chol_info.alloc(1); }
-    hipLaunchKernelGGL(k_chol_big_prepare, dim3(nbr * (nbr + 1) / 2), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p,
-                       chol_W.p, npad, chol_info.p);
-    const size_t lds = (size_t)48 * CBS * sizeof(double);
-    const bool dag = chol_big_dag && chol_big_back_one && nbr <= CHOLDAG_MAX_NBR;     // (the per-block back substitution reads the dense copies)
+    const size_t lds = (size_t)CHOLBIG_LDS_BLOCKS * CBS * sizeof(double);
+    const bool dag = chol_big_dag && chol_big_back_one && nbr <= CHOLDAG_MAX_NBR && nbx <= CHOLBIG_MAX_NBX;     // (the per-block back substitution reads the dense copies)
+    const bool dag32 = dag && sizeof(T) == 4 && chol_f32;
     if (dag) {
-      // the whole factorisation in one launch: workgroup = tile, columns handed over through flags (sba_chol_big.hpp)
+      // factorisation (and k_chol_big_prepare's work) in one launch: a walker workgroup on the diagonal, workgroup = tile behind it,
+      // columns handed over through flags (sba_chol_big.hpp).  fp32 engine: on f32 lanes first, the f64 instance behind it only
+      // runs when that one refused the system (LMState::chol_retry)
       if (chol_dag_flags.n == 0) { chol_dag_flags.alloc(choldag_nflags(CHOLDAG_MAX_NBR)); chol_dag_flags.zero(stream); }
-      if (chol_Mimg.n < (size_t)nbr * CHOLDAG_IMG) chol_Mimg.alloc((size_t)CHOLDAG_MAX_NBR * CHOLDAG_IMG);
+      if (chol_Mimg.n == 0) chol_Mimg.alloc((size_t)CHOLDAG_MAX_NBR * choldag_img<double>());
       if (chol_debug) { chol_dbg.alloc(8 * (CHOLDAG_MAX_NBR + 1)); chol_dbg.zero(stream); }
-      hipLaunchKernelGGL(k_chol_big_dag, dim3(1 + nbr * (nbr + 1) / 2), dim3(CHOLBIG_THREADS), lds, stream, chol_W.p, npad, chol_Mimg.p,
-                         chol_dag_flags.p, ++chol_dag_epoch, chol_info.p, d_state.p, chol_debug ? chol_dbg.p : nullptr);
+      const dim3 grid(1 + nbr * (nbr + 1) / 2);
+      if (dag32)
+        hipLaunchKernelGGL(k_chol_big_dag<float>, grid, dim3(CHOLBIG_THREADS), (size_t)CHOLBIG_LDS_BLOCKS * CholLay<float>::BS * sizeof(float), stream,
+                           Esys, n_sys, d_state.p, D2c.p, reinterpret_cast<float*>(chol_W.p), npad, reinterpret_cast<float*>(chol_Mimg.p),
+                           chol_dag_flags.p, ++chol_dag_epoch, chol_info.p, 0, chol_f32_tau, chol_debug ? chol_dbg.p : nullptr);
+      hipLaunchKernelGGL(k_chol_big_dag<double>, grid, dim3(CHOLBIG_THREADS), lds, stream, Esys, n_sys, d_state.p, D2c.p, chol_W.p, npad,
+                         chol_Mimg.p, chol_dag_flags.p, ++chol_dag_epoch, chol_info.p, dag32 ? 1 : 0, 0.0,
+                         (chol_debug && !dag32) ? chol_dbg.p : nullptr);
       if (chol_debug) {
         std::vector<long long> sv(8 * (CHOLDAG_MAX_NBR + 1));
         HIPCHK(hipMemcpyAsync(sv.data(), chol_dbg.p, sv.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));
         sync();
-        fprintf(stderr, "[chol_dag, the walker, x10 ns: wait for W(c,c-1), W(c,c) | load | panel | downdate | factor+inverse | image stored | flag]\n");
+        fprintf(stderr, "[chol_dag%s, the walker, x10 ns: wait for W(c,c-1), W(c,c) | load | panel | downdate | factor+inverse | image stored | flag]\n", dag32 ? " on f32 lanes" : "");
         for (int cc = 0; cc < nbr; ++cc) {
           const long long* v = sv.data() + 8 * cc;
           fprintf(stderr, "  c=%2d at %6lld:", cc, v[4] - sv[0]);
@@ -1480,17 +1491,19 @@ struct Engine : EngineBase {
         chol_debug = false;
       }
     } else {
+      hipLaunchKernelGGL(k_chol_big_prepare, dim3(nbr * (nbr + 1) / 2), dim3(256), 0, stream, Esys, n_sys, d_state.p, D2c.p,
+                         chol_W.p, npad, chol_info.p);
       for (int j = 0; j < nbr; ++j) {
         const int q = nbr - 1 - j;
         hipLaunchKernelGGL(k_chol_big_step, dim3(std::max(1, q * (q + 1) / 2)), dim3(CHOLBIG_THREADS), lds, stream, chol_W.p, npad, j,
                            chol_Minv.p, chol_Ld.p, chol_info.p, d_state.p);
       }
     }
-    if (chol_big_back_one) {
-      // the whole back substitution in one launch: block row = workgroup, x_b handed over through flags (sba_chol_big.hpp)
-      if (chol_flags.n == 0) { chol_flags.alloc(64); chol_flags.zero(stream); }
-      hipLaunchKernelGGL(k_chol_big_back_all, dim3(nbx), dim3(256), 0, stream, chol_W.p, npad, n_sys, chol_Ld.p, chol_Minv.p, chol_yv.p,
-                         chol_flags.p, ++chol_epoch, chol_sol.p, chol_info.p, d_state.p, dag ? chol_Mimg.p : (const double*)nullptr);
+    if (chol_big_back_one && nbx <= CHOLBIG_MAX_NBX) {
+      // the whole back substitution in one launch: block row = workgroup, x_b handed over as its own flag; block row 0 runs the epilogue
+      hipLaunchKernelGGL(k_chol_big_back_all<T>, dim3(nbx), dim3(256), 0, stream, (const void*)chol_W.p, npad, n_sys, chol_Ld.p, chol_Minv.p,
+                         chol_yv.p, ++chol_epoch, chol_sol.p, chol_info.p, d_state.p, dag ? (const void*)chol_Mimg.p : (const void*)nullptr,
+                         dag32 ? 1 : 0, Esys, C, D2c.p, ps_lm(), delta_c.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       return;
     }
     hipLaunchKernelGGL(k_chol_big_back_init, dim3((npad + 255) / 256), dim3(256), 0, stream, chol_W.p, npad, n_sys, chol_Ld.p,
@@ -1498,6 +1511,8 @@ struct Engine : EngineBase {
     for (int b = nbx - 1; b >= 0; --b)
       hipLaunchKernelGGL(k_chol_big_back, dim3(b + 1), dim3(256), 0, stream, chol_W.p, npad, b, n_sys, chol_Minv.p, chol_yv.p,
                          chol_sol.p, d_state.p);
+    hipLaunchKernelGGL(k_chol_epilogue<T>, dim3(1), dim3(1024), 0, stream, Esys, C, n_sys, d_state.p, D2c.p, ps_lm(), delta_c.p,
+                       chol_sol.p, chol_info.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
   }
 
   // scal == nullptr: single rank, the partials are folded inside k_decide and no scalar exchange is needed
@@ -1593,9 +1608,7 @@ struct Engine : EngineBase {
                            ps_lm(), delta_c.p, n_sys, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
       } else if (n_sys > chol_big_min_n && !chol_old) {
         // 47+ cameras: multi-workgroup right-looking factorisation, one launch per 64-wide block column (sba_chol_big.hpp)
-        launch_chol_big(Esys, n_sys);
-        hipLaunchKernelGGL(k_chol_epilogue<T>, dim3(1), dim3(1024), 0, stream, Esys, C, n_sys, d_state.p, D2c.p, ps_lm(), delta_c.p,
-                           chol_sol.p, chol_info.p, tied ? tie_map.p : nullptr, tied ? tie_first.p : nullptr);
+        launch_chol_big(Esys, n_sys, tied);
       } else if (n_sys <= CS_MAX_NB * CB && !chol_old) {
         // 17 .. 46 cameras: one workgroup, left-looking, finished block columns streamed through L2
         const int nb = (n_sys + CB - 1) / CB;

@@ -381,13 +381,12 @@ __global__ void k_chol_prepare(double* __restrict__ E, int n, LMState* __restric
   if (blockIdx.x == 0 && threadIdx.x == 0) st->cost = E[(size_t)n * n + 3 * n];
 }
 
+// (a device function: k_chol_big_back_all's last workgroup runs it on the solution it holds in LDS instead of a launch of its own)
 template <typename T>
-__global__ __launch_bounds__(1024) void k_chol_epilogue(
+__device__ __forceinline__ void chol_epilogue_body(
     const double* __restrict__ E, int C, int n, LMState* __restrict__ st, const double* __restrict__ D2c,
-    const ParamSets<T> ps, double* __restrict__ delta_c, const double* __restrict__ sol, const int* __restrict__ info,
-    const int32_t* __restrict__ tie, const int32_t* __restrict__ first) {
-  __shared__ double s_scr[16];
-  if (st->status >= 0) return;
+    const ParamSets<T>& ps, double* __restrict__ delta_c, const double* sol, const int* __restrict__ info,
+    const int32_t* __restrict__ tie, const int32_t* __restrict__ first, double* __restrict__ s_scr /* [16] */, int* __restrict__ s_flag) {
   const int cur_ = ps_cur(ps, st);
   const double* __restrict__ cams = ps.cams[cur_];
   double* __restrict__ cams_new = ps.cams[cur_ ^ 1];
@@ -400,10 +399,9 @@ __global__ __launch_bounds__(1024) void k_chol_epilogue(
   double bad = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) if (!isfinite(sol[i])) bad = 1;
   bad = block_max(bad, s_scr);
-  __shared__ int s_fail;
-  if (threadIdx.x == 0) s_fail = (fail || bad > 0) ? 1 : 0;
+  if (threadIdx.x == 0) *s_flag = (fail || bad > 0) ? 1 : 0;
   __syncthreads();
-  fail = s_fail != 0;
+  fail = *s_flag != 0;
   double pred = 0, dx2 = 0, x2 = 0, gm = 0;
   for (int i = threadIdx.x; i < ncam; i += blockDim.x) {
     const double d = fail ? 0.0 : sol[tie ? tie[i] : i];
@@ -428,7 +426,17 @@ __global__ __launch_bounds__(1024) void k_chol_epilogue(
     st->fresh = 0;
   }
   __syncthreads();
-  if ((int)threadIdx.x < C) campre_build<T>(cams_new + (size_t)threadIdx.x * NCP, campre_new + (size_t)threadIdx.x * CAMPRE);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) campre_build<T>(cams_new + (size_t)c * NCP, campre_new + (size_t)c * CAMPRE);
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void k_chol_epilogue(
+    const double* __restrict__ E, int C, int n, LMState* __restrict__ st, const double* __restrict__ D2c,
+    const ParamSets<T> ps, double* __restrict__ delta_c, const double* __restrict__ sol, const int* __restrict__ info,
+    const int32_t* __restrict__ tie, const int32_t* __restrict__ first) {
+  __shared__ double s_scr[16];
+  __shared__ int s_fail;
+  if (st->status >= 0) return;
+  chol_epilogue_body<T>(E, C, n, st, D2c, ps, delta_c, sol, info, tie, first, s_scr, &s_fail);
 }
 
 // ------------------------------------------------------------------ K6: back-substitution + trial point + trial residual
