@@ -109,7 +109,7 @@ __device__ __forceinline__ void load_block64(const S* __restrict__ W, int npad, 
 // sunk below tau * a0: chol16_wave_t).
 template <typename S>
 __device__ __forceinline__ S* chol_big_mi_blk(S* Mi, int a, int b) { return Mi + (a * (a - 1) / 2 + b) * CholLay<S>::BS; }
-struct CholBigNoHook { __device__ __forceinline__ void operator()() const {} };
+struct CholBigNoHook { __device__ __forceinline__ void operator()(int) const {} };
 // (A T)^T for one sub-block as MFMA accumulators -- exactly the operand layout of the products that follow (chol_panel_update_diag_t)
 template <typename S>
 __device__ __forceinline__ typename Mfma<S>::acc_t chol_big_panel_T(const S* __restrict__ Ablk, const S* __restrict__ LinvT) {
@@ -142,13 +142,12 @@ __device__ __forceinline__ typename Mfma<S>::acc_t chol_big_abT(const typename M
 // inputs become final: after the last pivot only the bottom row Minv(3, 0..2) is left, three independent blocks on three waves.
 // The factor's sub-blocks are collected in Lo (6 sub-blocks of scratch: the blocks of A they come from stay readable for the
 // other waves) and copied into Dg at the end.  5 barriers (15 in round 3's version).
-// Waves 4..7 have nothing to do from sub-block column 1 on: they call `issue` while wave 0 works on the third diagonal sub-block
-// and `commit` while it works on the last -- k_chol_big_dag's walker requests its next two tiles in the one and puts them into LDS
-// in the other.  The barriers wait for LDS only (lds_barrier), so the requests stay in flight across them.
-template <typename S = double, typename Issue = CholBigNoHook, typename Commit = CholBigNoHook>
+// Waves 4..7 have nothing to do from sub-block column 1 on: they call hook(1), hook(2), hook(3) in the three phases that follow
+// (wave 0: third diagonal sub-block, last one, bottom row of the inverse) -- k_chol_big_dag's walker requests its next two tiles
+// in one phase and puts them into LDS in the next.  The barriers wait for LDS only (lds_barrier): requests stay in flight across them.
+template <typename S = double, typename Hook = CholBigNoHook>
 __device__ __forceinline__ void chol_big_factor64(S* __restrict__ Dg, S* __restrict__ Mi, S* __restrict__ Lo, int* __restrict__ s_fail,
-                                                  const S* __restrict__ a0 = nullptr, S tau = (S)0,
-                                                  Issue&& issue = Issue(), Commit&& commit = Commit()) {
+                                                  const S* __restrict__ a0 = nullptr, S tau = (S)0, Hook&& hook = Hook()) {
   using L = CholLay<S>;
   using acc_t = typename Mfma<S>::acc_t;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -201,18 +200,19 @@ __device__ __forceinline__ void chol_big_factor64(S* __restrict__ Dg, S* __restr
   else if (wid == 1) tile(1, 3, 2, true);
   else if (wid == 2) tile(1, 3, 3, false);
   else if (wid == 3) inv_blk(1, 0);
-  else issue();
+  else hook(1);
   lds_barrier();
   // ---- behind T_2
   if (wid == 0) { next_diag(2); pivots(3); }
   else if (wid == 1) inv_blk(2, 1);
   else if (wid == 2) inv_blk(2, 0);
-  else if (wid >= 4) commit();
+  else if (wid >= 4) hook(2);
   lds_barrier();
   // ---- behind T_3: the inverse's bottom row; the factor's sub-blocks go to their places
   if (wid < 3) inv_blk(3, wid);
+  else if (wid >= 4) hook(3);
   else {
-    for (int q = wid - 3; q < 6; q += 5) {
+    for (int q = 0; q < 6; ++q) {
       int a = 1;
       while (a * (a + 1) / 2 <= q) ++a;
       const int b = q - a * (a - 1) / 2;
@@ -370,7 +370,7 @@ constexpr int CHOLDAG_MAX_NBR = 22;
 constexpr long long CHOLBIG_WAIT_TICKS = 200000000LL;      // 2 s of the 100 MHz clock
 constexpr long long CHOLBIG_X_EMPTY = 0x7ff8dead5ba0e111LL; // k_chol_big_back_all: "x_b not there yet" (a NaN payload no computation produces)
 template <typename S> __host__ __device__ constexpr int choldag_img() { return 16 * CB * (sizeof(S) == 8 ? CLD : 20); }   // Dg (10 sub-blocks) + Mi (6)
-__host__ __device__ inline int choldag_nflags(int nbr) { return nbr + nbr * nbr + 1; }
+__host__ __device__ inline int choldag_nflags(int nbr) { return nbr + nbr * nbr + 1; }      // Mimg_j, W(r,c), abort
 // entries of the image: Minv[i][k] (lower) and the factor's strictly-lower sub-blocks L[i][k]
 template <typename S>
 __device__ __forceinline__ double choldag_img_minv(const S* __restrict__ img, int i, int k) {
@@ -546,19 +546,16 @@ __device__ __forceinline__ void choldag_store_block(S* __restrict__ W, int npad,
   }
 }
 
-// grid = 1 + nbr (nbr + 1) / 2; 512 threads; dynamic LDS = CHOLBIG_LDS_BLOCKS sub-blocks of S
 template <typename S>
-__global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(const double* __restrict__ E, int n, LMState* __restrict__ st,
-                                                                  double* __restrict__ D2c, S* __restrict__ W, int npad,
-                                                                  S* __restrict__ Mimg_ws, unsigned* __restrict__ flags, unsigned epoch,
-                                                                  int* __restrict__ info, int only_if_retry, S tau,
-                                                                  long long* __restrict__ dbg) {
+__device__ __forceinline__ void choldag_body(const double* __restrict__ E, int n, LMState* __restrict__ st,
+                                             double* __restrict__ D2c, S* __restrict__ W, int npad,
+                                             S* __restrict__ Mimg_ws, unsigned* __restrict__ flags, unsigned epoch,
+                                             int* __restrict__ info, S tau, long long* __restrict__ dbg) {
   using L = CholLay<S>;
   using acc_t = typename Mfma<S>::acc_t;
   constexpr bool F32 = sizeof(S) == 4;
   constexpr int IMG = choldag_img<S>();
   extern __shared__ __align__(16) unsigned char smem[];
-  if (st->status >= 0 || (only_if_retry && !st->chol_retry)) return;     // (the same record on every workgroup: nobody is left waiting)
   S* F = reinterpret_cast<S*>(smem);                     // image of a diagonal block: Dg (10 sub-blocks) + Mi (6)
   S* Ar = F + 16 * L::BS;                                // W(r,j) -> L(r,j)
   S* Ac = Ar + 16 * L::BS;                               // W(c,j) -> L(c,j);  the walker: the next diagonal tile
@@ -598,11 +595,25 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(const double* 
       V2 va[8], vb[8];
       bool got = false;
       const int ftid = threadIdx.x - 256;
-      auto issue = [&]() {
+      bool stored = false;
+      auto hook = [&](int phase) {
         if (!more) return;
-        if (F32 && ftid < BB) s_a0[(c + 1) & 1][ftid] = (S)sys.diag((c + 1) * BB + ftid);
-        if (c == 0) return;                               // (fetched in front of the loop)
-        if (!F32) return;                                 // (f64: the last 16 pivots take long enough for the whole fetch, see commit)
+        if (phase == 1 && F32 && ftid < BB) s_a0[(c + 1) & 1][ftid] = (S)sys.diag((c + 1) * BB + ftid);
+        if (c == 0) { if (phase == 3 && lane == 0) s_pref[wid - 4] = 1; return; }     // (fetched in front of the loop)
+        if (got && !stored) {                               // requested in an earlier phase: into LDS now
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = ftid + u * 256, row = e >> 5, col = (e & 31) * 2;
+            const int o = ((row >> 4) * BSUB + (col >> 4)) * L::BS + (row & 15) * L::LD + (col & 15);
+            Ar[o] = va[u].x; Ar[o + 1] = va[u].y;
+            Ac[o] = vb[u].x; Ac[o + 1] = vb[u].y;
+          }
+          stored = true;
+          if (lane == 0) s_pref[wid - 4] = 1;
+          return;
+        }
+        if (got || phase == 3) return;
+        if (!F32 && phase == 1) return;                     // (f64: phases are long and registers scarce: one look, in phase 2)
         bool ready = true;
         if (lane < 2) ready = __hip_atomic_load(lane == 0 ? fa : fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
         if (!__all(ready)) return;
@@ -614,22 +625,7 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(const double* 
           va[u] = *reinterpret_cast<const V2*>(W + (size_t)((c + 1) * BB + row) * npad + c * BB + col);
           vb[u] = *reinterpret_cast<const V2*>(W + (size_t)((c + 1) * BB + row) * npad + (c + 1) * BB + col);
         }
-      };
-      auto commit = [&]() {
-        if (!more) return;
-        if (c > 0) {
-          if (!got) {                                     // not there yet when `issue` looked: one more look, now or after the factorisation
-            bool ready = true;
-            if (lane < 2) ready = __hip_atomic_load(lane == 0 ? fa : fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
-            if (!__all(ready)) return;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int e = ftid + u * 256, row = e >> 5, col = (e & 31) * 2;
-              va[u] = *reinterpret_cast<const V2*>(W + (size_t)((c + 1) * BB + row) * npad + c * BB + col);
-              vb[u] = *reinterpret_cast<const V2*>(W + (size_t)((c + 1) * BB + row) * npad + (c + 1) * BB + col);
-            }
-          }
+        if (!F32) {                                         // (f64: straight into LDS, nothing kept in registers across a barrier)
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const int e = ftid + u * 256, row = e >> 5, col = (e & 31) * 2;
@@ -637,10 +633,11 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(const double* 
             Ar[o] = va[u].x; Ar[o + 1] = va[u].y;
             Ac[o] = vb[u].x; Ac[o + 1] = vb[u].y;
           }
+          stored = true;
+          if (lane == 0) s_pref[wid - 4] = 1;
         }
-        if (lane == 0) s_pref[wid - 4] = 1;
       };
-      chol_big_factor64<S>(F, Mi, Ac + 16 * L::BS, &s_fail, F32 ? s_a0[c & 1] : (const S*)nullptr, tau, issue, commit);
+      chol_big_factor64<S>(F, Mi, Ac + 16 * L::BS, &s_fail, F32 ? s_a0[c & 1] : (const S*)nullptr, tau, hook);
       stamp(c, 5);
       choldag_copy_img<S>(Mimg_ws + (size_t)c * IMG, F);
       stamp(c, 6);
@@ -767,6 +764,21 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(const double* 
   }
   __syncthreads();
   choldag_store_block<S>(W, npad, c, r, Ar);
+}
+
+// grid = 1 + nbr (nbr + 1) / 2; 512 threads; dynamic LDS = CHOLBIG_LDS_BLOCKS sub-blocks of S.
+// only_if_retry: the f64 instance the fp32 engine launches behind the f32 one -- it leaves at once unless that one refused the system.
+// (Both in one launch, every workgroup waiting for the walker's verdict, was measured: no faster at 64 cameras, 2-4 us at 24 -- and
+//  a workgroup that waits instead of leaving keeps its CU, which breaks the progress argument above on a shared card: the 8-rank
+//  rehearsal on one card ran into the bounded waits.)
+template <typename S>
+__global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_dag(const double* __restrict__ E, int n, LMState* __restrict__ st,
+                                                                  double* __restrict__ D2c, S* __restrict__ W, int npad,
+                                                                  S* __restrict__ Mimg_ws, unsigned* __restrict__ flags, unsigned epoch,
+                                                                  int* __restrict__ info, int only_if_retry, S tau,
+                                                                  long long* __restrict__ dbg) {
+  if (st->status >= 0 || (only_if_retry && !st->chol_retry)) return;     // (the same record on every workgroup: nobody is left waiting)
+  choldag_body<S>(E, n, st, D2c, W, npad, Mimg_ws, flags, epoch, info, tau, dbg);
 }
 
 // ------------------------------------------------------------------ back substitution

@@ -293,6 +293,7 @@ struct Engine : EngineBase {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholesky_ll<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_step), hipFuncAttributeMaxDynamicSharedMemorySize, CHOLBIG_LDS_BLOCKS * CBS * (int)sizeof(double)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_dag<double>), hipFuncAttributeMaxDynamicSharedMemorySize, CHOLBIG_LDS_BLOCKS * CBS * (int)sizeof(double)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_big_dag<float>), hipFuncAttributeMaxDynamicSharedMemorySize, CHOLBIG_LDS_BLOCKS * CholLay<float>::BS * (int)sizeof(float)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backsub_trial<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_points<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residual<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
