@@ -9,7 +9,9 @@ positive definite S and read the camera step back with ``sba_lm_get_step``: the 
     176 < n <= 256 (17..23 cameras): k_cholesky_ll      (left-looking, factor on chip, sba_chol_ll.hpp)
     SBA_CHOL=ll:                     k_cholesky_ll for every n <= 256
     SBA_CHOL=blocked, n <= 209:      k_cholesky_stream instead of k_cholesky_ll
-    larger:                          k_chol_big_*
+    larger, up to 22 block rows of 64 (24 .. 127 cameras): k_chol_big_dag (one launch: walker + tiles; fp32 engine: on f32
+                                     lanes, the f64 instance behind it on a refusal) + k_chol_big_back_all
+    SBA_CHOL_BIG=launches, or more:  k_chol_big_prepare / k_chol_big_step per block column
 
 including sizes that are not multiples of the 16-wide blocks, an ill-conditioned matrix, and an indefinite one (the step
 must come back as zero with the failure flag set, which the LM control turns into a rejected trial).
@@ -189,3 +191,64 @@ def test_shared_intrinsics_system_through_the_left_looking_kernel(monkeypatch, d
     d = ca[:, 6:9] - rig["cams0"][:, 6:9]
     assert np.max(np.abs(d - d[0])) <= 1e-9 * max(1.0, np.max(np.abs(d)))
     assert np.max(np.abs(ca - cb)) <= (1e-6 if dtype == "f64" else 1e-2) * max(1.0, np.max(np.abs(cb)))
+
+
+@pytest.mark.parametrize("C,dtype", [(24, "f32"), (47, "f64"), (47, "f32"), (64, "f64"), (64, "f32"), (100, "f64"), (127, "f32"), (128, "f64")])
+@pytest.mark.parametrize("mode", ["dag", "launches"])
+def test_large_systems_one_launch_and_per_column_launches(monkeypatch, C, dtype, mode):
+    """24 cameras and more: the one-launch factorisation (k_chol_big_dag: a walker workgroup on the diagonal, one workgroup per
+    tile behind flags, the system built from the exchange buffer inside the launch, back substitution and LM epilogue in
+    k_chol_big_back_all) and the per-column launches of rounds 1-3 (SBA_CHOL_BIG=launches; 128 cameras = 23 block rows take them
+    anyway) against numpy, at sizes whose last block row holds only the right-hand-side row (64 cameras: n = 704) and sizes that
+    are no multiple of anything (47, 127)."""
+    monkeypatch.delenv("SBA_CHOL", raising=False)
+    monkeypatch.delenv("SBA_CHOL_F32", raising=False)
+    if mode == "launches":
+        monkeypatch.setenv("SBA_CHOL_BIG", "launches")
+    else:
+        monkeypatch.delenv("SBA_CHOL_BIG", raising=False)
+    rng = np.random.default_rng(500 + C)
+    n = 11 * C
+    S = _spd(n, rng)
+    rhs = rng.standard_normal(n)
+    dU = np.abs(rng.standard_normal(n)) + 0.5
+    step, retries = _solve_on_device(C, S, rhs, dU, dtype, 1e-3, want_retries=True)
+    ref = np.linalg.solve(S + 1e-3 * np.diag(dU), rhs)
+    f32_lanes = dtype == "f32" and mode == "dag" and C <= 127
+    tol = 1e-9 if dtype == "f64" else 1e3 * (1e-6 if f32_lanes else 2e-7)
+    assert retries == 0
+    assert np.max(np.abs(step - ref)) <= tol * np.max(np.abs(ref)), np.max(np.abs(step - ref)) / np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("C", [24, 32, 64])
+def test_f32_lane_factorisation_of_large_systems(monkeypatch, C):
+    """fp32 engine, 24 cameras and more: k_chol_big_dag<float> (f32 pivots with the pivot-growth test, f32 MFMAs, f32 tiles and
+    images) with k_chol_big_dag<double> launched behind it, which only runs when the f32 factorisation refused the system.  Bars as
+    for the smaller systems: error <= cond * 1e-6 for cond <= 1e5 without a repeat; at cond 1e9 the repeat is taken and the answer
+    has f64 accuracy; an indefinite system is refused twice and ends as a zero step; SBA_CHOL_F32=0 never takes the f32 path."""
+    monkeypatch.delenv("SBA_CHOL", raising=False)
+    monkeypatch.delenv("SBA_CHOL_F32", raising=False)
+    monkeypatch.delenv("SBA_CHOL_BIG", raising=False)
+    rng = np.random.default_rng(600 + C)
+    n = 11 * C
+    rhs = rng.standard_normal(n)
+    dU = np.ones(n)
+    for cond in (1e2, 1e4, 1e5):
+        S = _spd(n, rng, cond=cond)
+        step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+        ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
+        err = np.max(np.abs(step - ref)) / np.max(np.abs(ref))
+        assert retries == 0 and err <= cond * 1e-6, (cond, retries, err)
+    S = _spd(n, rng, cond=1e9)
+    ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
+    step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+    assert retries == 1 and np.max(np.abs(step - ref)) <= 1e-5 * np.max(np.abs(ref)), (retries, np.max(np.abs(step - ref)) / np.max(np.abs(ref)))
+    S2 = S.copy()
+    S2[n - 5, n - 5] = -1.0
+    step, retries = _solve_on_device(C, S2, rhs, dU, "f32", lam=1e-6, want_retries=True)
+    assert retries == 1 and np.all(step == 0.0)
+    monkeypatch.setenv("SBA_CHOL_F32", "0")
+    S = _spd(n, rng, cond=1e4)
+    step, retries = _solve_on_device(C, S, rhs, dU, "f32", lam=1e-6, want_retries=True)
+    ref = np.linalg.solve(S + 1e-6 * np.eye(n), rhs)
+    assert retries == 0 and np.max(np.abs(step - ref)) <= 1e4 * 2e-7 * np.max(np.abs(ref))
