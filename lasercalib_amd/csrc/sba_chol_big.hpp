@@ -365,8 +365,8 @@ __global__ __launch_bounds__(CHOLBIG_THREADS) void k_chol_big_step(double* __res
 // (CHOLBIG_WAIT_TICKS, then info |= 2: a rejected LM step) and a timed-out workgroup raises an abort flag the others watch.
 // Progress does not need the whole launch to be resident (a card shared with other processes), only in-order dispatch: the
 // walker is dispatched first, and what it needs to publish Mimg_j are tiles (j, j-1) and (j, j), which are numbered below every
-// tile that waits for Mimg_j.  Up to CHOLDAG_MAX_NBR block rows the launch is resident as a whole (254 workgroups, one per CU).
-constexpr int CHOLDAG_MAX_NBR = 22;
+// tile that waits for Mimg_j.  Up to 22 block rows the launch is resident as a whole (254 workgroups, one per CU in f64).
+constexpr int CHOLDAG_MAX_NBR = 27;         // 128 cameras x 13 parameters; from 23 block rows on (277 .. 379 tiles) the launch is not resident as a whole
 constexpr long long CHOLBIG_WAIT_TICKS = 200000000LL;      // 2 s of the 100 MHz clock
 constexpr long long CHOLBIG_X_EMPTY = 0x7ff8dead5ba0e111LL; // k_chol_big_back_all: "x_b not there yet" (a NaN payload no computation produces)
 template <typename S> __host__ __device__ constexpr int choldag_img() { return 16 * CB * (sizeof(S) == 8 ? CLD : 20); }   // Dg (10 sub-blocks) + Mi (6)

@@ -114,6 +114,9 @@ struct Engine : EngineBase {
   DevBuf<double> chol_Mimg;             // k_chol_big_dag: the factored diagonal blocks and their inverses, as they lie in LDS
   unsigned chol_dag_epoch = 0;
   bool chol_big_dag = true;             // SBA_CHOL_BIG=launches keeps one launch per block column (rounds 1-3)
+  int chol_dag_max_nbr = CHOLDAG_MAX_NBR;   // SBA_CHOL_DAG_MAX_NBR: block rows up to which the one-launch factorisation is used
+  bool card_shared = false;             // sba_ipc_attach found a peer rank's exchange area on THIS device (a rehearsal of N ranks on one card):
+                                        // kernels whose workgroups wait for each other are then not used where a launch-per-step form exists
   bool chol_debug = false;
   bool schur_debug = false;
   int schur_exp = 0;                  // SBA_SCHUR_EXP: timing experiments of k_schur_fused_bf3 (its results are wrong when set)
@@ -229,6 +232,7 @@ struct Engine : EngineBase {
     if (const char* e = getenv("SBA_SCHUR_EXP")) schur_exp = atoi(e);
     if (const char* e = getenv("SBA_CHOL_BIG_BACK")) chol_big_back_one = std::string(e) != "launches";
     if (const char* e = getenv("SBA_CHOL_BIG")) chol_big_dag = std::string(e) != "launches";
+    if (const char* e = getenv("SBA_CHOL_DAG_MAX_NBR")) chol_dag_max_nbr = std::max(1, std::min(CHOLDAG_MAX_NBR, atoi(e)));
     if (const char* e = getenv("SBA_CHOL_F32")) chol_f32 = atoi(e) != 0;
     if (const char* e = getenv("SBA_CHOL_F32_TAU")) { char* end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0 && v < 1) chol_f32_tau = (float)v; }
     if (const char* e = getenv("SBA_CHOL_BIG_MIN_N")) {      // diagnostic: route smaller systems through the big path too
@@ -1254,6 +1258,15 @@ struct Engine : EngineBase {
       ipc_area[r] = static_cast<double*>(q);
       ipc_opened[r] = 1;
     }
+    // ranks that share this card: their launches compete for its CUs, and k_chol_big_dag's progress argument (in-order dispatch of
+    // ONE launch) does not cover several such launches holding each other's CUs on different XCDs -- they get the per-column launches
+    card_shared = false;
+    for (int r = 0; r < n_ranks; ++r) {
+      if (r == rank) continue;
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, ipc_area[r]) == hipSuccess) { if (at.device == device) card_shared = true; }
+      else (void)hipGetLastError();
+    }
     ipc_ptrs.upload(ipc_area, stream);
     if (ipc_fail.n == 0) ipc_fail.alloc(1);
     ipc_fail.zero(stream);
@@ -1461,7 +1474,7 @@ struct Engine : EngineBase {
     }
     if (chol_sol.n < (size_t)n_sys) { chol_sol.alloc(n_sys); chol_info.alloc(1); }
     const size_t lds = (size_t)CHOLBIG_LDS_BLOCKS * CBS * sizeof(double);
-    const bool dag = chol_big_dag && chol_big_back_one && nbr <= CHOLDAG_MAX_NBR && nbx <= CHOLBIG_MAX_NBX;     // (the per-block back substitution reads the dense copies)
+    const bool dag = chol_big_dag && !card_shared && chol_big_back_one && nbr <= chol_dag_max_nbr && nbx <= CHOLBIG_MAX_NBX;     // (the per-block back substitution reads the dense copies)
     const bool dag32 = dag && sizeof(T) == 4 && chol_f32;
     if (dag) {
       // factorisation (and k_chol_big_prepare's work) in one launch: a walker workgroup on the diagonal, workgroup = tile behind it,
