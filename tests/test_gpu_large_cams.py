@@ -201,3 +201,23 @@ def test_group_pairs_on_the_bf16_pipe_follow_the_f32_mfma_kernels(C, N, vis, tan
             assert rb.accepted == rf.accepted == rd.accepted == 1
         assert abs(rb.cost - rf.cost) <= 2e-5 * rf.cost, (rb.iteration, rb.cost, rf.cost)
         assert abs(rb.cost - rd.cost) <= 1e-4 * rd.cost, (rb.iteration, rb.cost, rd.cost)
+
+
+@pytest.mark.parametrize("C,dtype", [(24, "f32"), (47, "f64"), (64, "f32")])
+def test_second_solve_on_the_same_handle_repeats_the_first(C, dtype):
+    """A solve ends in the middle of a batch of enqueued iterations: the launches behind the end return at once.  The one-launch
+    factorisation and its back substitution hand data over through epoch flags and an "empty" marker per parity of the launch
+    count, so launches that did nothing must leave both in order for the next solve on the handle: the same parameters set again,
+    the same solve again, the same bits."""
+    rig = make_rig(C, 80, seed=40 + C, visibility=0.4, min_cams_per_point=4)
+    x0 = np.hstack((rig["cams0"].ravel(), rig["pts0"].ravel()))
+    with _native.Problem(rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"], dtype=dtype) as prob:
+        outs = []
+        for _ in range(3):
+            prob.set_params(x0)
+            cams, pts, rep, _ = prob.solve_lm(prob.make_opts(ftol=1e-6))
+            outs.append((cams.copy(), pts.copy(), rep.cost, rep.nfev, rep.status))
+    assert outs[0][4] in (2, 3, 4) and outs[0][3] >= 3
+    for o in outs[1:]:
+        assert o[3] == outs[0][3] and o[2] == outs[0][2] and o[4] == outs[0][4]
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
