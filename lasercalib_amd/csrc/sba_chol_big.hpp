@@ -596,9 +596,14 @@ __device__ __forceinline__ void choldag_body(const double* __restrict__ E, int n
       bool got = false;
       const int ftid = threadIdx.x - 256;
       bool stored = false;
+      S a0n = (S)0;
       auto hook = [&](int phase) {
         if (!more) return;
-        if (phase == 1 && F32 && ftid < BB) s_a0[(c + 1) & 1][ftid] = (S)sys.diag((c + 1) * BB + ftid);
+        // the damped diagonal of the next block (the pivot test's reference): requested in phase 1, into LDS in phase 2
+        if (F32 && ftid < BB) {
+          if (phase == 1) a0n = (S)sys.diag((c + 1) * BB + ftid);
+          else if (phase == 2) s_a0[(c + 1) & 1][ftid] = a0n;
+        }
         if (c == 0) { if (phase == 3 && lane == 0) s_pref[wid - 4] = 1; return; }     // (fetched in front of the loop)
         if (got && !stored) {                               // requested in an earlier phase: into LDS now
 #pragma unroll
