@@ -430,6 +430,42 @@ __device__ __noinline__ void choldag_block_from_sys(const CholDagSys sys, int br
   }
 }
 
+// the walker's start: blocks (0,0) (packed lower), (1,0) and (1,1) at once -- the three batches of loads in flight together
+template <typename S>
+__device__ __noinline__ void choldag_walker_start(const CholDagSys sys, S* __restrict__ F, S* __restrict__ Ar, S* __restrict__ Ac, int tid, bool three) {
+  using L = CholLay<S>;
+  constexpr int U = BB * BB / CHOLBIG_THREADS;
+  double v[3][U];
+  const int col = tid & 63;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int br = b == 0 ? 0 : 1, bc = b == 2 ? 1 : 0, j = bc * BB + col;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = br * BB + ((tid + u * CHOLBIG_THREADS) >> 6);
+      v[b][u] = (b == 0 || three) ? sys.E[(i < sys.n && j < sys.n) ? (size_t)i * sys.n + j : 0] : 0.0;
+    }
+  }
+  const double damp0 = sys.damping(col < sys.n ? col : 0);
+  const double damp1 = three ? sys.damping(BB + col < sys.n ? BB + col : 0) : 0.0;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    if (b > 0 && !three) break;
+    const int br = b == 0 ? 0 : 1, bc = b == 2 ? 1 : 0, j = bc * BB + col;
+    S* dst = b == 0 ? F : b == 1 ? Ar : Ac;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = (tid + u * CHOLBIG_THREADS) >> 6, sr = row >> 4, sc = col >> 4;
+      const int i = br * BB + row;
+      double x = v[b][u];
+      if (!(i < sys.n && j < sys.n)) x = (j <= i) ? sys.border(i, j) : 0.0;
+      else if (i == j) x += (b == 0 ? damp0 : damp1);
+      if (b == 0 && sc > sr) continue;
+      dst[(b == 0 ? L::off(sr, sc) : (sr * BSUB + sc) * L::BS) + (row & 15) * L::LD + (col & 15)] = (S)x;
+    }
+  }
+}
+
 // wave 0 polls up to two flags (lanes 0 and 1) until both carry the epoch; everybody leaves through a barrier and an acquire fence
 __device__ __forceinline__ void choldag_wait(const unsigned* f0, const unsigned* f1, unsigned epoch, unsigned* abortf, int* s_late) {
   if (threadIdx.x < 64) {
@@ -577,11 +613,8 @@ __device__ __forceinline__ void choldag_body(const double* __restrict__ E, int n
     stamp(0, 0);
     if (threadIdx.x == 0) { st->cost = E[(size_t)n * n + 3 * n]; *info = 0; }
     S* Mi = F + 10 * L::BS;
-    choldag_block_from_sys<true, S, CHOLBIG_THREADS>(sys, 0, 0, F, threadIdx.x);
-    if (nbr > 1) {                                        // (nobody writes column 0 or tile (1,1): the walker's first two tiles come from E as well)
-      choldag_block_from_sys<false, S, CHOLBIG_THREADS>(sys, 1, 0, Ar, threadIdx.x);
-      choldag_block_from_sys<false, S, CHOLBIG_THREADS>(sys, 1, 1, Ac, threadIdx.x);
-    }
+    // (nobody writes column 0 or tile (1,1): the walker's first two tiles come from E as well, together with the first diagonal block)
+    choldag_walker_start<S>(sys, F, Ar, Ac, threadIdx.x, nbr > 1);
     if (threadIdx.x < BB) s_a0[0][threadIdx.x] = (S)sys.diag(threadIdx.x);
     __syncthreads();
     for (int c = 0; c < nbr; ++c) {
