@@ -221,3 +221,37 @@ def test_second_solve_on_the_same_handle_repeats_the_first(C, dtype):
     for o in outs[1:]:
         assert o[3] == outs[0][3] and o[2] == outs[0][2] and o[4] == outs[0][4]
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_two_handles_solving_at_once_on_one_card(dtype):
+    """Two handles in two threads, no exchange between them (so neither knows of the other), 64 cameras each: two one-launch
+    factorisations (79 workgroups that wait for each other, per launch) share the card's CUs.  Each must come out with the bits of
+    the same solve done alone -- the bounded waits of the kernel must not fire when a launch is merely slowed down."""
+    import threading
+    rig = make_rig(64, 120, seed=77, visibility=0.3, min_cams_per_point=4)
+    args = (rig["cams0"], rig["pts0"], rig["points_2d"], rig["camera_ind"], rig["point_ind"])
+    with _native.Problem(*args, dtype=dtype) as prob:
+        c0, p0, r0, _ = prob.solve_lm(prob.make_opts(ftol=1e-8, max_nfev=40))
+    assert r0.status in (0, 2, 3, 4) and r0.nfev >= 5
+    outs, errs = {}, []
+
+    def work(k):
+        try:
+            with _native.Problem(*args, dtype=dtype) as p:
+                for _ in range(3):
+                    p.set_params(np.hstack((rig["cams0"].ravel(), rig["pts0"].ravel())))
+                    outs[k] = p.solve_lm(p.make_opts(ftol=1e-8, max_nfev=40))
+        except BaseException as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not errs, errs
+    for k in range(2):
+        c, p, r, _ = outs[k]
+        assert r.nfev == r0.nfev and r.cost == r0.cost and r.status == r0.status
+        assert np.array_equal(c, c0) and np.array_equal(p, p0)
