@@ -869,14 +869,14 @@ __global__ __launch_bounds__(256) void k_chol_big_back(const double* __restrict_
 // ------------------------------------------------------------------ back substitution in ONE launch (round 4)
 // The per-block launches above cost ~10 us each for a 64 x 64 matrix-vector product (launch + three dependent round trips to memory):
 // 11 of them at n = 704, 26 at n = 1664.  Here block row t is ONE workgroup for the whole substitution,
-//     y_t -= L(b,t)^T x_b   for b = last .. t + 1, as the x_b arrive;      x_t = Minv_t^T y_t,   published with a flag,
-// so the chain through the blocks is a flag hand-over between resident workgroups (at most 26 of them) instead of a launch
+//     y_t -= L(b,t)^T x_b   for b = last .. t + 1, as the x_b arrive;      x_t = Minv_t^T y_t,   published as its own flag (below),
+// so the chain through the blocks is a hand-over between resident workgroups (at most 27 of them) instead of a launch
 // boundary: the L(b,t) block a workgroup needs next is already in its registers when x_b arrives.  The waits are bounded
 // (CHOLBIG_WAIT_TICKS of the 100 MHz clock, then the solve is flagged as failed: a rejected LM step) and every workgroup of
-// the launch is resident at once -- the rule of sba_ipc.hpp.  Flags carry the launch's epoch, so they are never reset.
+// the launch is resident at once -- the rule of sba_ipc.hpp.
 template <typename S>
 __device__ __forceinline__ void chol_big_back_all_body(const S* __restrict__ W, int npad, int n, const double* __restrict__ Ld_ws,
-                                                       const double* __restrict__ Minv_ws, double* __restrict__ xv, unsigned* __restrict__ flags,
+                                                       const double* __restrict__ Minv_ws, double* __restrict__ xv,
                                                        unsigned epoch, double* __restrict__ sol, int* __restrict__ info,
                                                        const S* __restrict__ Mimg_ws, double* __restrict__ s_y, double* __restrict__ s_x,
                                                        double (*__restrict__ s_p)[BB], double* __restrict__ s_M, int& s_late,
@@ -982,10 +982,10 @@ __global__ __launch_bounds__(256) void k_chol_big_back_all(const void* __restric
     return;
   }
   if (f32_data && !st->chol_retry)
-    chol_big_back_all_body<float>(static_cast<const float*>(W), npad, n, Ld_ws, Minv_ws, xv, nullptr, epoch, sol, info,
+    chol_big_back_all_body<float>(static_cast<const float*>(W), npad, n, Ld_ws, Minv_ws, xv, epoch, sol, info,
                                   static_cast<const float*>(Mimg_ws), s_y, s_x, s_p, s_M, s_late, s_sol);
   else
-    chol_big_back_all_body<double>(static_cast<const double*>(W), npad, n, Ld_ws, Minv_ws, xv, nullptr, epoch, sol, info,
+    chol_big_back_all_body<double>(static_cast<const double*>(W), npad, n, Ld_ws, Minv_ws, xv, epoch, sol, info,
                                    static_cast<const double*>(Mimg_ws), s_y, s_x, s_p, s_M, s_late, s_sol);
   if (blockIdx.x != 0) return;
   __syncthreads();                                  // (a timed-out substitution has raised info: the epilogue then rejects the step)

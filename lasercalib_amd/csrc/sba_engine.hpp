@@ -107,8 +107,7 @@ struct Engine : EngineBase {
   int chol_big_min_n = 209;
   DevBuf<double> chol_sol, chol_work, chol_W, chol_Minv, chol_Ld, chol_yv;
   DevBuf<int> chol_info;
-  DevBuf<unsigned> chol_flags;          // k_chol_big_back_all: x_b published (value = the launch's epoch)
-  unsigned chol_epoch = 0;
+  unsigned chol_epoch = 0;              // k_chol_big_back_all: launches so far (its parity picks the copy of x the launch works in)
   bool chol_big_back_one = true;        // SBA_CHOL_BIG_BACK=launches keeps one launch per block (rounds 1-3)
   DevBuf<unsigned> chol_dag_flags;      // k_chol_big_dag: Mimg_j / W(r,c) published (value = the launch's epoch)
   DevBuf<double> chol_Mimg;             // k_chol_big_dag: the factored diagonal blocks and their inverses, as they lie in LDS
