@@ -1,24 +1,28 @@
-// sba_chol_big.hpp -- Cholesky + solve of a LARGE reduced camera system (n > 512: 47 .. 128 cameras) on many CUs.
+// sba_chol_big.hpp -- Cholesky + solve of a LARGE reduced camera system (n > 256: 24 .. 128 cameras) on many CUs.
 //
-//   A = S + lam*diag(D2c)   (n = 11*C up to 1408, f64),  A = L L^T,  delta_c = A^-1 rhs
+//   A = S + lam*diag(D2c)   (n = 11*C or 13*C, up to 1664),  A = L L^T,  delta_c = A^-1 rhs
 //
-// Right-looking, 64-wide block columns, ONE launch per block column, no library call and no spin-waits:
-//   k_chol_big_prepare   copies the damped system into a padded workspace W (npad x npad, npad = 64*nbr) and appends the
-//                        right-hand side as one more ROW (index R = 16*ceil(n/16)): the forward substitution y = L^-1 rhs
-//                        then simply falls out as row R of the factor.  Padding rows are the identity.
-//   k_chol_big_step(j)   one workgroup per trailing 64x64 tile (r, c), j < c <= r.  Every workgroup
-//                          1. factors the diagonal block W(j,j) itself, in LDS (16x16 sub-blocks, the building blocks of
-//                             sba_chol_blocked.hpp) and inverts the 64x64 factor -- redundant work, but it runs in parallel
-//                             and spares a launch boundary plus a hand-off per block column;
+// Right-looking, 64-wide block columns, no library call.  The right-hand side is appended as one more ROW (index R =
+// 16*ceil(n/16), diagonal entry BIG): the forward substitution y = L^-1 rhs then simply falls out as row R of the factor.
+// Padding rows are the identity.  Two forms of the factorisation, one back substitution:
+//   k_chol_big_dag<S>    (round 4, the default) ONE launch: a walker workgroup factors the diagonal blocks, one workgroup per tile
+//                        of the lower block triangle applies the columns behind epoch flags; the system is formed from the exchange
+//                        buffer inside the launch; S = float for the fp32 engine, with the f64 instance launched behind it for
+//                        systems the f32 one refuses.  Details at the kernel.
+//   k_chol_big_prepare + k_chol_big_step(j)   (rounds 1-3; SBA_CHOL_BIG=launches, ranks that share a card): the damped system
+//                        copied into a padded workspace W, then ONE launch per block column, no waits between workgroups: one
+//                        workgroup per trailing tile (r, c), j < c <= r, each of which
+//                          1. factors the diagonal block W(j,j) itself, in LDS, and inverts the factor -- redundant work, but it
+//                             runs in parallel and spares a launch boundary plus a hand-off per block column;
 //                          2. forms its two panel blocks L(r,j) = W(r,j) Linv^T, L(c,j) = W(c,j) Linv^T (f64 MFMA);
 //                          3. downdates its tile W(r,c) -= L(r,j) L(c,j)^T.
-//                        The workgroups of tile column c = j+1 also publish L(r,j), into the UPPER block triangle of W
-//                        (block (j,r)): the lower block (r,j) is still being read by the other workgroups of the launch.
-//                        Workgroup 0 publishes the inverse of the diagonal factor (Minv) and the factor's sub-blocks (Ld).
-//   k_chol_big_back_init gathers y (row R of L), then
-//   k_chol_big_back(b)   b = last .. 0:  x_b = Minv_b^T y_b (every workgroup, redundantly), y_t -= L(b,t)^T x_b (workgroup t < b).
-// Launches per solve: 2 + nbr + ceil(n/64), each a few microseconds; the chain of n pivots (~275 cycles each) inside
-// the diagonal factorisations is the floor.  The LM-specific parts stay in k_chol_epilogue (sba_lm_kernels.hpp).
+//                        The workgroups of tile column c = j+1 also publish L(r,j), into the UPPER block triangle of W (block
+//                        (j,r)): the lower block (r,j) is still being read by the other workgroups of the launch.  Workgroup 0
+//                        publishes the inverse of the diagonal factor (Minv) and the factor's sub-blocks (Ld).
+//   k_chol_big_back_all<T>   b = last .. 0:  x_b = Minv_b^T y_b, y_t -= L(b,t)^T x_b, block row = workgroup, in one launch, and the LM
+//                        epilogue (trial cameras, predicted reduction, failure flag) by the block row that finishes last
+//                        (k_chol_big_back_init / k_chol_big_back: one launch per block, SBA_CHOL_BIG_BACK=launches).
+// Both forms share the 64 x 64 building block chol_big_factor64 (16 x 16 sub-blocks, the pivot chains of sba_chol_blocked.hpp).
 #pragma once
 #include "sba_chol_blocked.hpp"
 
