@@ -231,6 +231,7 @@ struct Engine : EngineBase {
     if (const char* e = getenv("SBA_SCHUR_EXP")) schur_exp = atoi(e);
     if (const char* e = getenv("SBA_CHOL_BIG_BACK")) chol_big_back_one = std::string(e) != "launches";
     if (const char* e = getenv("SBA_CHOL_BIG")) chol_big_dag = std::string(e) != "launches";
+    if (const char* e = getenv("SBA_LINP_PF")) linp_pf = atoi(e) != 0;
     if (const char* e = getenv("SBA_CHOL_DAG_MAX_NBR")) chol_dag_max_nbr = std::max(1, std::min(CHOLDAG_MAX_NBR, atoi(e)));
     if (const char* e = getenv("SBA_CHOL_F32")) chol_f32 = atoi(e) != 0;
     if (const char* e = getenv("SBA_CHOL_F32_TAU")) { char* end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0 && v < 1) chol_f32_tau = (float)v; }
@@ -696,17 +697,21 @@ struct Engine : EngineBase {
   }
   // st == nullptr: unconditional (used outside the LM loop); otherwise the launch is a no-op once the solve has
   // terminated or when the last step was rejected and nothing has to be re-linearized
+  bool linp_folds_pf(const LMState* st) const { return st != nullptr && linp_lw != 0 && linp_pf && h_state && h_state->free_cams && !lin_pts() && !fused(); }
   void launch_linearize_points(const LMState* st) {
     if (nblk == 0) return;
     if (linp_lw) {
       const uint16_t* tm = dense ? (const uint16_t*)nullptr : grp_mask.p;
       const int32_t* ts = dense ? (const int32_t*)nullptr : grp_start.p;
+      // inside the LM loop with free cameras the launch also forms the trial's point factors (k_point_factor's work: launch_schur skips it)
+      T* pfp = linp_folds_pf(st) ? pfac.p : nullptr;
+      const unsigned char* fx = has_fixed ? pt_fixed_mask.p : (const unsigned char*)nullptr;
       if (linp_lw == 64)
         hipLaunchKernelGGL((k_linearize_points_wave<T, 64>), dim3(nlinp), dim3(PM_BLOCK), 0, stream, st ? ps_lm() : ps_now(), st, C, uv_pm.p,
-                           has_w ? w_pm.p : nullptr, N, tm, ts, V.p, gp.p, D2p.p, cost_part.p, gmax_part.p);
+                           has_w ? w_pm.p : nullptr, N, tm, ts, V.p, gp.p, D2p.p, cost_part.p, gmax_part.p, pfp, fx);
       else
         hipLaunchKernelGGL((k_linearize_points_wave<T, 32>), dim3(nlinp), dim3(PM_BLOCK), 0, stream, st ? ps_lm() : ps_now(), st, C, uv_pm.p,
-                           has_w ? w_pm.p : nullptr, N, tm, ts, V.p, gp.p, D2p.p, cost_part.p, gmax_part.p);
+                           has_w ? w_pm.p : nullptr, N, tm, ts, V.p, gp.p, D2p.p, cost_part.p, gmax_part.p, pfp, fx);
       return;
     }
     const size_t lds = (size_t)PM_BLOCK * 9 * sizeof(double) + lds_cams();
@@ -854,7 +859,7 @@ struct Engine : EngineBase {
         return;
       }
     }
-    if (N > 0)
+    if (N > 0 && !linp_folds_pf(d_state.p))
       hipLaunchKernelGGL(k_point_factor<T>, dim3((N + 255) / 256), dim3(256), 0, stream, V.p, gp.p, D2p.p, d_state.p, N, pfac.p,
                          has_fixed ? pt_fixed_mask.p : (const unsigned char*)nullptr);
     // pairs are stored diagonal ones first: [0, ngroups) are (g,g); the rest are (ga<gb)
@@ -988,6 +993,7 @@ struct Engine : EngineBase {
   bool backsub_pack = false;
   bool backsub_wave = false;         // 33 .. 128 cameras: k_backsub_dense<T, 64>
   int linp_lw = 0;                   // 24 .. 128 cameras with (point, camera) tables: k_linearize_points_wave<T, 32 / 64>; 0 = k_linearize_points
+  bool linp_pf = true;               // ... which also forms the point factors (SBA_LINP_PF=0: k_point_factor in a launch of its own)
   int nlinp = 0;                     // ... its (persistent) workgroups = entries of cost_part / gmax_part
   int n_linp_blocks() const { return linp_lw ? nlinp : nblk; }
   bool backsub_dense() const { return dense_one_group || backsub_masked || backsub_wide || backsub_wave; }

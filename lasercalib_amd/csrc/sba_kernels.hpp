@@ -679,32 +679,36 @@ __global__ __launch_bounds__(1024) void k_reduce_cams(const double* __restrict__
 // instead of 12 doubles and run no sqrt/divide of their own.
 constexpr int PF = 12;
 template <typename T>
-__global__ void k_point_factor(const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
-                               const LMState* __restrict__ st, int N, T* __restrict__ pf, const unsigned char* __restrict__ fixed) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= N || st->status >= 0) return;
-  const double lam = st->lam;
+__device__ __forceinline__ void point_factor_one(const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
+                                                 double lam, size_t p, T* __restrict__ pf, const unsigned char* __restrict__ fixed) {
   double v6[6], li[6];
-  v6[0] = V[(size_t)p * 6 + 0] + lam * fmax_pos(D2p[(size_t)p * 3 + 0]);
-  v6[1] = V[(size_t)p * 6 + 1];
-  v6[2] = V[(size_t)p * 6 + 2];
-  v6[3] = V[(size_t)p * 6 + 3] + lam * fmax_pos(D2p[(size_t)p * 3 + 1]);
-  v6[4] = V[(size_t)p * 6 + 4];
-  v6[5] = V[(size_t)p * 6 + 5] + lam * fmax_pos(D2p[(size_t)p * 3 + 2]);
-  T* o = pf + (size_t)p * PF;
+  v6[0] = V[p * 6 + 0] + lam * fmax_pos(D2p[p * 3 + 0]);
+  v6[1] = V[p * 6 + 1];
+  v6[2] = V[p * 6 + 2];
+  v6[3] = V[p * 6 + 3] + lam * fmax_pos(D2p[p * 3 + 1]);
+  v6[4] = V[p * 6 + 4];
+  v6[5] = V[p * 6 + 5] + lam * fmax_pos(D2p[p * 3 + 2]);
+  T* o = pf + p * PF;
   // degenerate point, or a point held fixed: contributes nothing to the Schur complement, its step is zero in the back substitution
   if ((fixed && fixed[p]) || !chol3_inv<double>(v6, li)) {
 #pragma unroll
     for (int k = 0; k < PF; ++k) o[k] = (T)0;
     return;
   }
-  const double g0 = gp[(size_t)p * 3], g1 = gp[(size_t)p * 3 + 1], g2 = gp[(size_t)p * 3 + 2];
+  const double g0 = gp[p * 3], g1 = gp[p * 3 + 1], g2 = gp[p * 3 + 2];
 #pragma unroll
   for (int k = 0; k < 6; ++k) o[k] = (T)li[k];
   o[6] = (T)(li[0] * g0);
   o[7] = (T)(li[1] * g0 + li[2] * g1);
   o[8] = (T)(li[3] * g0 + li[4] * g1 + li[5] * g2);
   o[9] = (T)1; o[10] = (T)0; o[11] = (T)0;
+}
+template <typename T>
+__global__ void k_point_factor(const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ D2p,
+                               const LMState* __restrict__ st, int N, T* __restrict__ pf, const unsigned char* __restrict__ fixed) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N || st->status >= 0) return;
+  point_factor_one<T>(V, gp, D2p, st->lam, (size_t)p, pf, fixed);
 }
 
 // ------------------------------------------------------------------ DPP row reductions (lane = (point, camera) kernels)

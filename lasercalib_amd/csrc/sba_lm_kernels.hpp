@@ -738,12 +738,28 @@ __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points_wave(
     const ParamSets<T> ps, const LMState* __restrict__ st, int C, const typename Vec2<T>::type* __restrict__ uv, const T* __restrict__ w, int N,
     const uint16_t* __restrict__ vis /* [groups][N] visibility masks, or NULL: dense (observation (p, c) at p C + c) */,
     const int32_t* __restrict__ pt_start /* [groups][N] first observation of the point in the group */,
-    double* __restrict__ V, double* __restrict__ gp, double* __restrict__ D2p, double* __restrict__ cost_part, double* __restrict__ gmax_part) {
+    double* __restrict__ V, double* __restrict__ gp, double* __restrict__ D2p, double* __restrict__ cost_part, double* __restrict__ gmax_part,
+    T* __restrict__ pf /* non-null (inside the LM loop, free cameras): the damped point factors of THIS trial are formed here as well, for the
+                          points this workgroup linearises -- k_point_factor's work without its launch; after a rejected step (nothing to
+                          re-linearise, but a new lambda) that is all the launch does */,
+    const unsigned char* __restrict__ fixed) {
   static_assert(LW == 32 || LW == 64, "a point per wave half or per wave");
   constexpr int CPL = LW == 64 ? 2 : 1, MAXC = LW == 64 ? 128 : 32, PPC = PM_BLOCK / LW;
   __shared__ T s_cam[MAXC * CAMPRE];
   __shared__ double s_scr[PM_BLOCK / 64];
-  if (st && (st->status >= 0 || !st->need_lin)) return;
+  if (st && st->status >= 0) return;
+  const int nch = (N + PPC - 1) / PPC;
+  if (st && !st->need_lin) {
+    if (pf) {
+      const double lam = st->lam;
+      const int nown = (nch - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+      for (int i = threadIdx.x; i < nown * PPC; i += PM_BLOCK) {
+        const int p = ((int)blockIdx.x + (i / PPC) * (int)gridDim.x) * PPC + i % PPC;
+        if (p < N) point_factor_one<T>(V, gp, D2p, lam, (size_t)p, pf, fixed);
+      }
+    }
+    return;
+  }
   const int cur_ = ps_cur(ps, st);
   const T* __restrict__ ptsT = ps.ptsT[cur_];
   stage_campre(ps.campre[cur_], s_cam, C);
@@ -755,7 +771,6 @@ __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points_wave(
     else return wave64_sum(v);
   };
   double sq = 0, gmax = 0;
-  const int nch = (N + PPC - 1) / PPC;
   for (int ch = blockIdx.x; ch < nch; ch += gridDim.x) {
     const int p = ch * PPC + q;
     const bool pt_ok = p < N;
@@ -804,6 +819,14 @@ __global__ __launch_bounds__(PM_BLOCK) void k_linearize_points_wave(
   const double cs = block_sum(sq, s_scr);
   const double gm = block_max(gmax, s_scr);
   if (threadIdx.x == 0) { cost_part[blockIdx.x] = 0.5 * cs; gmax_part[blockIdx.x] = gm; }
+  if (pf && st) {                                 // (the barriers of the block sums stand between the V / g_p / D2p stores above and these reads)
+    const double lam = st->lam;
+    const int nown = (nch - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int i = threadIdx.x; i < nown * PPC; i += PM_BLOCK) {
+      const int p = ((int)blockIdx.x + (i / PPC) * (int)gridDim.x) * PPC + i % PPC;
+      if (p < N) point_factor_one<T>(V, gp, D2p, lam, (size_t)p, pf, fixed);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ start of a solve
