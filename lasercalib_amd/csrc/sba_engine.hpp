@@ -1272,6 +1272,7 @@ struct Engine : EngineBase {
       if (hipPointerGetAttributes(&at, ipc_area[r]) == hipSuccess) { if (at.device == device) card_shared = true; }
       else (void)hipGetLastError();
     }
+    if (chol_debug) fprintf(stderr, "[sba_ipc_attach] rank %d of %d: %s\n", rank, n_ranks, card_shared ? "a peer's exchange area lives on this device: ranks share the card (per-column launches for the large Cholesky)" : "no peer on this device");
     ipc_ptrs.upload(ipc_area, stream);
     if (ipc_fail.n == 0) ipc_fail.alloc(1);
     ipc_fail.zero(stream);
