@@ -979,13 +979,14 @@ __global__ __launch_bounds__(256) void k_chol_big_back_all(const void* __restric
                                                            const int32_t* __restrict__ tie, const int32_t* __restrict__ first) {
   __shared__ double s_y[BB], s_x[BB], s_p[4][BB], s_M[BB * BB], s_sol[CHOLBIG_MAX_NBX * BB], s_scr[16];
   __shared__ int s_late, s_flag;
-  if (st->status >= 0) {                            // (the same record on every workgroup: nobody is left waiting)
+  const int st_status = st->status, st_retry = st->chol_retry;      // (both requested at once: two dependent trips to memory otherwise)
+  if (st_status >= 0) {                             // (the same record on every workgroup: nobody is left waiting)
     // a launch that has nothing to do (the solve has ended, the iterations enqueued behind it drain) still empties its slice of the
     // other copy of x: the next launch -- of the next solve on this handle -- counts on finding it empty
     if (threadIdx.x < BB) xv[(size_t)((epoch + 1) & 1) * npad + blockIdx.x * BB + threadIdx.x] = __longlong_as_double(CHOLBIG_X_EMPTY);
     return;
   }
-  if (f32_data && !st->chol_retry)
+  if (f32_data && !st_retry)
     chol_big_back_all_body<float>(static_cast<const float*>(W), npad, n, Ld_ws, Minv_ws, xv, epoch, sol, info,
                                   static_cast<const float*>(Mimg_ws), s_y, s_x, s_p, s_M, s_late, s_sol);
   else
