@@ -376,19 +376,20 @@ constexpr long long CHOLBIG_X_EMPTY = 0x7ff8dead5ba0e111LL; // k_chol_big_back_a
 template <typename S> __host__ __device__ constexpr int choldag_img() { return 16 * CB * (sizeof(S) == 8 ? CLD : 20); }   // Dg (10 sub-blocks) + Mi (6)
 __host__ __device__ inline int choldag_nflags(int nbr) { return nbr + nbr * nbr + 1; }      // Mimg_j, W(r,c), abort
 // entries of the image: Minv[i][k] (lower) and the factor's strictly-lower sub-blocks L[i][k]
+// (returned in the image's own type: a conversion at the load would make the caller wait for the data there and then)
 template <typename S>
-__device__ __forceinline__ double choldag_img_minv(const S* __restrict__ img, int i, int k) {
+__device__ __forceinline__ S choldag_img_minv(const S* __restrict__ img, int i, int k) {
   using L = CholLay<S>;
   const int si = i >> 4, sk = k >> 4;
-  if (si == sk) return (double)img[L::off(si, si) + (k & 15) * L::LD + (i & 15)];                              // Linv[i][k] = T[k][i]
-  if (si > sk) return (double)img[10 * L::BS + (si * (si - 1) / 2 + sk) * L::BS + (i & 15) * L::LD + (k & 15)];
-  return 0.0;
+  if (si == sk) return img[L::off(si, si) + (k & 15) * L::LD + (i & 15)];                              // Linv[i][k] = T[k][i]
+  if (si > sk) return img[10 * L::BS + (si * (si - 1) / 2 + sk) * L::BS + (i & 15) * L::LD + (k & 15)];
+  return (S)0;
 }
 template <typename S>
-__device__ __forceinline__ double choldag_img_l(const S* __restrict__ img, int i, int k) {
+__device__ __forceinline__ S choldag_img_l(const S* __restrict__ img, int i, int k) {
   using L = CholLay<S>;
   const int si = i >> 4, sk = k >> 4;
-  return (si > sk) ? (double)img[L::off(si, sk) + (i & 15) * L::LD + (k & 15)] : 0.0;
+  return (si > sk) ? img[L::off(si, sk) + (i & 15) * L::LD + (k & 15)] : (S)0;
 }
 
 // the damped, augmented system the factorisation works on (what k_chol_big_prepare writes into W)
@@ -890,24 +891,32 @@ __device__ __forceinline__ void chol_big_back_all_body(const S* __restrict__ W, 
   const int t = blockIdx.x, i = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int R = cholbig_rhs_row(n), Rb = R / BB, Rl = R % BB;
   // y_t = row R of the factor (columns of block t), Minv_t, and the first L block: all requested before anything is waited for
-  double yk = 0;
+  // (values stay in the type they were loaded in until they are used: the requests of this prologue are all in flight together)
+  S yk = (S)0;
+  double yk_dense = 0;                               // (the dense copies of the per-column launches are doubles whatever S is)
   if (threadIdx.x < BB) {
     const int k = t * BB + threadIdx.x;
-    if (k < n) yk = (t < Rb) ? (double)W[(size_t)(t * BB + Rl) * npad + Rb * BB + threadIdx.x]
-                             : (Mimg_ws ? choldag_img_l<S>(Mimg_ws + (size_t)Rb * IMG, Rl, threadIdx.x) : Ld_ws[(size_t)Rb * BB * BB + Rl * BB + threadIdx.x]);
+    if (k < n) {
+      if (t < Rb) yk = W[(size_t)(t * BB + Rl) * npad + Rb * BB + threadIdx.x];
+      else if (Mimg_ws) yk = choldag_img_l<S>(Mimg_ws + (size_t)Rb * IMG, Rl, threadIdx.x);
+      else yk_dense = Ld_ws[(size_t)Rb * BB * BB + Rl * BB + threadIdx.x];
+    }
   }
   const double* Mg = Minv_ws + (size_t)t * BB * BB;
-  double mreg[BB * BB / 256];
+  S mreg[BB * BB / 256];
+  double mreg_dense[BB * BB / 256];
 #pragma unroll
   for (int u = 0; u < BB * BB / 256; ++u) {
     const int e = threadIdx.x + 256 * u;
-    mreg[u] = Mimg_ws ? choldag_img_minv<S>(Mimg_ws + (size_t)t * IMG, e >> 6, e & 63) : Mg[e];
+    mreg[u] = (S)0; mreg_dense[u] = 0;
+    if (Mimg_ws) mreg[u] = choldag_img_minv<S>(Mimg_ws + (size_t)t * IMG, e >> 6, e & 63);
+    else mreg_dense[u] = Mg[e];
   }
-  double lreg[BB / 4];                               // L(b,t)[k][i], k = part + 4 u
+  S lreg[BB / 4];                                    // L(b,t)[k][i], k = part + 4 u (kept as loaded: a conversion here would wait for the data)
   auto fetch_L = [&](int b) {
     const S* Lb = W + (size_t)(t * BB) * npad + b * BB;
 #pragma unroll
-    for (int u = 0; u < BB / 4; ++u) lreg[u] = (double)Lb[(size_t)(part + 4 * u) * npad + i];
+    for (int u = 0; u < BB / 4; ++u) lreg[u] = Lb[(size_t)(part + 4 * u) * npad + i];
   };
   if (nbx - 1 > t) fetch_L(nbx - 1);
   // x travels as its own flag: xv has one copy per parity of the epoch, filled with a NaN nobody computes (CHOLBIG_X_EMPTY) until the
@@ -917,9 +926,9 @@ __device__ __forceinline__ void chol_big_back_all_body(const S* __restrict__ W, 
   double* xnext = xv + (size_t)((epoch + 1) & 1) * npad;
   if (threadIdx.x < BB) xnext[t * BB + threadIdx.x] = __longlong_as_double(CHOLBIG_X_EMPTY);
   if (threadIdx.x == 0) s_late = 0;
-  if (threadIdx.x < BB) s_y[threadIdx.x] = yk;
+  if (threadIdx.x < BB) s_y[threadIdx.x] = (double)yk + yk_dense;
 #pragma unroll
-  for (int u = 0; u < BB * BB / 256; ++u) s_M[threadIdx.x + 256 * u] = mreg[u];
+  for (int u = 0; u < BB * BB / 256; ++u) s_M[threadIdx.x + 256 * u] = (double)mreg[u] + mreg_dense[u];
   __syncthreads();
   for (int b = nbx - 1; b > t; --b) {
     if (threadIdx.x < BB) {                          // wave 0 waits for x_b and brings it in
@@ -941,7 +950,7 @@ __device__ __forceinline__ void chol_big_back_all_body(const S* __restrict__ W, 
     if (s_late) break;
     double u_ = 0;
 #pragma unroll
-    for (int u = 0; u < BB / 4; ++u) u_ += lreg[u] * s_x[part + 4 * u];
+    for (int u = 0; u < BB / 4; ++u) u_ += (double)lreg[u] * s_x[part + 4 * u];
     if (b - 1 > t) fetch_L(b - 1);                   // the next block travels while this one is folded
     s_p[part][i] = u_;
     __syncthreads();
