@@ -437,11 +437,13 @@ __device__ __noinline__ void choldag_block_from_sys(const CholDagSys sys, int br
 
 // the walker's start: blocks (0,0) (packed lower), (1,0) and (1,1) at once -- the three batches of loads in flight together
 template <typename S>
-__device__ __noinline__ void choldag_walker_start(const CholDagSys sys, S* __restrict__ F, S* __restrict__ Ar, S* __restrict__ Ac, int tid, bool three) {
+__device__ __noinline__ void choldag_walker_start(const CholDagSys sys, S* __restrict__ F, S* __restrict__ Ar, S* __restrict__ Ac, int tid, bool three,
+                                                  S* __restrict__ a0out /* [64]: the damped diagonal of block (0,0), the pivot test's reference */) {
   using L = CholLay<S>;
   constexpr int U = BB * BB / CHOLBIG_THREADS;
   double v[3][U];
   const int col = tid & 63;
+  const double ediag = (tid < BB && tid < sys.n) ? sys.E[(size_t)tid * sys.n + tid] : 0.0;      // (requested with the batch below)
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     const int br = b == 0 ? 0 : 1, bc = b == 2 ? 1 : 0, j = bc * BB + col;
@@ -453,6 +455,7 @@ __device__ __noinline__ void choldag_walker_start(const CholDagSys sys, S* __res
   }
   const double damp0 = sys.damping(col < sys.n ? col : 0);
   const double damp1 = three ? sys.damping(BB + col < sys.n ? BB + col : 0) : 0.0;
+  if (tid < BB) a0out[tid] = (S)(tid < sys.n ? ediag + damp0 : sys.border(tid, tid));
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     if (b > 0 && !three) break;
@@ -616,11 +619,11 @@ __device__ __forceinline__ void choldag_body(const double* __restrict__ E, int n
     // SBA_CHOL_DEBUG: stamps of the 100 MHz clock at the links of the chain
     auto stamp = [&](int c, int k) { if (dbg && threadIdx.x == 0) dbg[c * 8 + k] = wall_clock64(); };
     stamp(0, 0);
-    if (threadIdx.x == 0) { st->cost = E[(size_t)n * n + 3 * n]; *info = 0; }
+    if (threadIdx.x == 0) *info = 0;
     S* Mi = F + 10 * L::BS;
-    // (nobody writes column 0 or tile (1,1): the walker's first two tiles come from E as well, together with the first diagonal block)
-    choldag_walker_start<S>(sys, F, Ar, Ac, threadIdx.x, nbr > 1);
-    if (threadIdx.x < BB) s_a0[0][threadIdx.x] = (S)sys.diag(threadIdx.x);
+    // (nobody writes column 0 or tile (1,1): the walker's first two tiles come from E as well, together with the first diagonal block
+    //  and the reference diagonal of the pivot test -- one batch of loads)
+    choldag_walker_start<S>(sys, F, Ar, Ac, threadIdx.x, nbr > 1, s_a0[0]);
     __syncthreads();
     for (int c = 0; c < nbr; ++c) {
       stamp(c, 4);
@@ -719,6 +722,7 @@ __device__ __forceinline__ void choldag_body(const double* __restrict__ E, int n
       __syncthreads();
     }
     if (threadIdx.x == 0) {
+      st->cost = E[(size_t)n * n + 3 * n];              // (k_chol_big_prepare's other duty; here, off the start of the chain)
       if (F32) { st->chol_retry = s_fail ? 1 : 0; if (s_fail) st->chol_f64_retries += 1; }
       else if (s_fail) atomicOr(info, 1);
       if (s_late) atomicOr(info, 2);
